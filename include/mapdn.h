@@ -1,0 +1,192 @@
+/*
+ * mapdn.h — C ABI of libmapdn_hip.so: batched MI355X (gfx950) implementation of the hot path of
+ * Future-Power-Networks/MAPDN's VoltageControl environment.
+ *
+ * The reference has no FFI: the path sits behind a Python class
+ *   VoltageControl(MultiAgentEnv)   environments/var_voltage_control/voltage_control_env.py:24
+ * whose numeric work is `pp.runpp(self.powergrid)` (voltage_control_env.py:557, pandapower 2.7.0).
+ * Each entry point below names the reference method(s) whose arithmetic it replaces, batched over
+ * B independent env instances that share one network topology.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (MAPDN_E_*); mapdn_last_error() gives text;
+ *     nothing throws across the boundary.
+ *   - `mapdn_handle` is opaque; one handle == one (device, env batch).  The library owns topology
+ *     constants, profile tables and workspace; THE CALLER OWNS EVERY I/O BUFFER and passes raw
+ *     device pointers (e.g. torch.Tensor.data_ptr()) plus the hipStream_t to enqueue on
+ *     (`void* stream`, NULL = default stream).
+ *   - step-path calls only enqueue kernels; they never allocate and never synchronise.
+ *   - batched I/O tensors are env-major C-contiguous: actions [B, ns], obs [B, n_agents, obs_size],
+ *     state [B, state_size], voltages [B, nb], reward [B], terminated [B], info [B, 11].
+ *   - one handle is used by one host thread at a time; handles are independent of each other.
+ */
+#ifndef MAPDN_H
+#define MAPDN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAPDN_OK 0
+#define MAPDN_E_INVALID (-1)   /* bad argument / inconsistent netspec                        */
+#define MAPDN_E_TOPOLOGY (-2)  /* net not connected, or meshed (this build solves radial nets) */
+#define MAPDN_E_HIP (-3)       /* HIP runtime error (no device, OOM, launch failure)           */
+#define MAPDN_E_STATE (-4)     /* call order violated (e.g. step before set_profiles/reset)    */
+
+#define MAPDN_N_INFO 11        /* keys of `info`, voltage_control_env.py:586-606,621 — column order:
+                                  percentage_of_v_out_of_control, percentage_of_lower_than_lower_v,
+                                  percentage_of_higher_than_upper_v, totally_controllable_ratio,
+                                  average_voltage_deviation, average_voltage, max_voltage_drop_deviation,
+                                  max_voltage_rise_deviation, total_line_loss, q_loss, destroy */
+
+/* voltage_barrier/voltage_barrier_registry.py:9-15 */
+enum { MAPDN_BARRIER_L1 = 0, MAPDN_BARRIER_L2 = 1, MAPDN_BARRIER_COURANT_BELTRAMI = 2,
+       MAPDN_BARRIER_BOWL = 3, MAPDN_BARRIER_BUMP = 4 };
+
+/* bits of `state_space` (args/env_args/var_voltage_control.yaml:11) */
+enum { MAPDN_SS_PV = 1, MAPDN_SS_DEMAND = 2, MAPDN_SS_REACTIVE = 4, MAPDN_SS_VM_PU = 8,
+       MAPDN_SS_VA_DEGREE = 16, MAPDN_SS_ALL = 31 };
+
+enum { MAPDN_F32 = 0, MAPDN_F64 = 1 };
+
+/* The columns of the pandapower net (`model.p`, voltage_control_env.py:400-405) that runpp and the
+ * env read.  Host pointers, copied during mapdn_create.  Bus ids are 0..n_bus-1. */
+typedef struct mapdn_netspec {
+  int32_t n_bus;
+  const double* bus_vn_kv;          /* [n_bus]                                             */
+  const int32_t* bus_zone;          /* [n_bus] 0 = "main", k = "zone{k}"  (bus.zone)       */
+  int32_t n_line;                   /* net.line                                            */
+  const int32_t* line_from_bus;
+  const int32_t* line_to_bus;
+  const double* line_r_ohm_per_km;
+  const double* line_x_ohm_per_km;
+  const double* line_c_nf_per_km;
+  const double* line_g_us_per_km;
+  const double* line_length_km;
+  const int32_t* line_parallel;
+  const uint8_t* line_in_service;
+  int32_t n_branch_pu;              /* generic per-unit pi branches (e.g. trafos after T->pi) */
+  const int32_t* br_from_bus;
+  const int32_t* br_to_bus;
+  const double* br_r_pu;
+  const double* br_x_pu;
+  const double* br_b_pu;
+  const double* br_ratio;           /* 0 => 1                                              */
+  const double* br_shift_deg;
+  int32_t n_shunt;                  /* net.shunt (consumer sign, MW/MVAr at 1 p.u.)        */
+  const int32_t* shunt_bus;
+  const double* shunt_p_mw;
+  const double* shunt_q_mvar;
+  int32_t n_load;
+  const int32_t* load_bus;          /* net.load.bus                                        */
+  int32_t n_sgen;
+  const int32_t* sgen_bus;          /* net.sgen.bus                                        */
+  const int32_t* sgen_zone;         /* net.sgen.name as zone id (voltage_control_env.py:532) */
+  int32_t ext_grid_bus;
+  double ext_grid_vm_pu;
+  double sn_mva;
+  double f_hz;
+} mapdn_netspec;
+
+/* Constructor kwargs of VoltageControl (args/env_args/var_voltage_control.yaml:3-20). */
+typedef struct mapdn_env_config {
+  int32_t barrier_type;             /* MAPDN_BARRIER_*                                     */
+  double voltage_weight;
+  double q_weight;
+  double line_weight;
+  int32_t use_line_weight;          /* line_weight != None   (voltage_control_env.py:612)  */
+  int32_t use_q_weight;             /* q_weight != None      (voltage_control_env.py:614)  */
+  double v_lower, v_upper;
+  int32_t episode_limit;
+  double action_low, action_high;   /* bias -/+ scale (voltage_control_env.py:76)          */
+  int32_t reset_action;
+  int32_t state_space;              /* MAPDN_SS_* mask                                     */
+  uint64_t seed;
+  int64_t env_id_offset;            /* global id of local env 0 (multi-GPU sharding)       */
+} mapdn_env_config;
+
+typedef struct mapdn_dims_t {
+  int32_t n_envs, n_bus, n_line, n_load, n_sgen, n_agents, n_actions, obs_size, state_size, n_info;
+  int32_t is_radial;
+  int32_t max_zone_size;
+} mapdn_dims_t;
+
+typedef struct mapdn_handle mapdn_handle;
+
+/* last error text: of `h`, or of the last failed mapdn_create when h == NULL */
+const char* mapdn_last_error(const mapdn_handle* h);
+
+/* VoltageControl.__init__ up to (not including) data loading — voltage_control_env.py:36-94.
+ * Builds per-unit Ybus (pandapower pd2ppc/makeYbus), the elimination order and all gather index
+ * tables on the host, uploads them to `device`, allocates state for n_envs envs.
+ * device == -1 builds a host-only handle (plan, dims, ybus/obs-index export; no device calls). */
+int mapdn_create(const mapdn_netspec* net, const mapdn_env_config* cfg, int32_t n_envs,
+                 int32_t device, mapdn_handle** out);
+void mapdn_destroy(mapdn_handle* h);
+int mapdn_dims(const mapdn_handle* h, mapdn_dims_t* out);
+
+/* _load_pv_data/_load_active_demand_data/_load_reactive_demand_data (voltage_control_env.py:407-438)
+ * after CSV parsing and *_scale: HOST row-major tables pv [T, ns], load_p [T, nl], load_q [T, nl].
+ * Also derives the per-column std/100 (:70-72) and s_max = 1.2*max (:515-520).  Synchronous. */
+int mapdn_set_profiles(mapdn_handle* h, const double* pv, const double* load_p, const double* load_q,
+                       int64_t n_rows, int32_t time_delta_min, int32_t days);
+
+/* reset() / manual_reset() — voltage_control_env.py:96-176.  start_rows: device int64 [B] giving
+ * `start` of :445 per env, or NULL to sample (hour, day, interval) per env from the keyed RNG.
+ * Retries unsolvable initial states up to `max_tries` times (reference: unbounded loop, :108). */
+int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, int32_t max_tries,
+                void* stream);
+
+/* step(actions, add_noise) — voltage_control_env.py:178-211 (= _take_action :548-566 with the
+ * pandapower runpp inside, _calc_reward :574-623, _set_demand_and_pv :491-513).
+ * actions: device [B, ns] of actions_dtype; reward f64 [B]; terminated u8 [B]; info f64 [B, 11].
+ * Envs already terminated are frozen: reward 0, terminated 1, info unchanged (zeros). */
+int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int32_t add_noise,
+               double* reward, uint8_t* terminated, double* info, void* stream);
+
+/* get_obs() — voltage_control_env.py:232-316 (distributed mode): [B, n_agents, obs_size]. */
+int mapdn_get_obs(mapdn_handle* h, void* obs, int32_t dtype, void* stream);
+/* get_state() — voltage_control_env.py:213-230: [B, state_size]. */
+int mapdn_get_state(mapdn_handle* h, void* state, int32_t dtype, void* stream);
+
+/* tester getters — voltage_control_env.py:625-647; any pointer may be NULL.
+ * vm_pu, va_degree, p_mw, q_mvar: f64 [B, nb]; pl_mw: f64 [B, n_line]; sgen_p, sgen_q: f64 [B, ns] */
+int mapdn_get_results(mapdn_handle* h, double* vm_pu, double* va_degree, double* p_mw, double* q_mvar,
+                      double* pl_mw, double* sgen_p, double* sgen_q, void* stream);
+/* current load table values f64 [B, nl] (net.load.p_mw / q_mvar) */
+int mapdn_get_loads(mapdn_handle* h, double* load_p, double* load_q, void* stream);
+
+/* `start` of voltage_control_env.py:445 for every env: device int64 [B] */
+int mapdn_get_start_rows(mapdn_handle* h, int64_t* start_rows, void* stream);
+
+/* Pure power flow == pp.runpp(net) (voltage_control_env.py:557) on explicit element powers:
+ * p_load, q_load f64 [B, nl]; p_sgen, q_sgen f64 [B, ns] (MW / MVAr) ->
+ * vm_pu, va_degree f64 [B, nb]; iterations i32 [B]; converged u8 [B].  Does not touch env state. */
+int mapdn_solve_only(mapdn_handle* h, const double* p_load, const double* q_load, const double* p_sgen,
+                     const double* q_sgen, double* vm_pu, double* va_degree, int32_t* iterations,
+                     uint8_t* converged, void* stream);
+
+/* Host-side debug export of the per-unit admittance matrix the library built (for parity tests):
+ * dense row-major complex [nb, nb] as (re, im) pairs. */
+int mapdn_get_ybus_dense(const mapdn_handle* h, double* ybus_re_im);
+/* Host-side export of the integer gather tables of get_obs: kind/index per obs column
+ * [n_agents*obs_size] (kinds: 0 zero pad, 1 p_mw, 2 q_mvar, 3 pv, 4 q, 5 vm_pu, 6 va rad). */
+int mapdn_get_obs_index(const mapdn_handle* h, int32_t* kind, int32_t* index);
+
+/* counters (host, synchronises the given stream): number of envs whose last reset exhausted
+ * max_tries; mean / max NR iterations of the last solve */
+int mapdn_stats(mapdn_handle* h, int64_t* reset_failures, double* mean_iters, int32_t* max_iters,
+                void* stream);
+
+/* seconds-resolution device timing of the dominant kernel for bench.py: enables hipEvent pairs
+ * around every NR-solve launch on its stream; mapdn_nr_time_ms returns the accumulated time and
+ * launch count since the last call and resets them (synchronises). */
+int mapdn_nr_timing(mapdn_handle* h, int32_t enable);
+int mapdn_nr_time_ms(mapdn_handle* h, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAPDN_H */

@@ -1,0 +1,192 @@
+"""ctypes binding of libmapdn_hip.so (C ABI: include/mapdn.h).
+
+There is NO fallback: if the shared library is missing or a call fails, this raises.  Nothing in
+the product path imports ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .netspec import NetSpec
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmapdn_hip.so")
+
+N_INFO = 11
+INFO_KEYS = (
+    "percentage_of_v_out_of_control", "percentage_of_lower_than_lower_v",
+    "percentage_of_higher_than_upper_v", "totally_controllable_ratio",
+    "average_voltage_deviation", "average_voltage", "max_voltage_drop_deviation",
+    "max_voltage_rise_deviation", "total_line_loss", "q_loss", "destroy",
+)
+BARRIER_IDS = dict(l1=0, l2=1, courant_beltrami=2, bowl=3, bump=4)
+SS_BITS = dict(pv=1, demand=2, reactive=4, vm_pu=8, va_degree=16)
+F32, F64 = 0, 1
+
+EXPORTS = (
+    "mapdn_last_error", "mapdn_create", "mapdn_destroy", "mapdn_dims", "mapdn_set_profiles", "mapdn_reset",
+    "mapdn_step", "mapdn_get_start_rows", "mapdn_get_obs", "mapdn_get_state", "mapdn_get_results", "mapdn_get_loads",
+    "mapdn_solve_only", "mapdn_get_ybus_dense", "mapdn_get_obs_index", "mapdn_stats", "mapdn_nr_timing",
+    "mapdn_nr_time_ms",
+)
+
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int32)
+_pu8 = C.POINTER(C.c_uint8)
+
+
+class CNetSpec(C.Structure):
+    _fields_ = [
+        ("n_bus", C.c_int32), ("bus_vn_kv", _pd), ("bus_zone", _pi),
+        ("n_line", C.c_int32), ("line_from_bus", _pi), ("line_to_bus", _pi),
+        ("line_r_ohm_per_km", _pd), ("line_x_ohm_per_km", _pd), ("line_c_nf_per_km", _pd),
+        ("line_g_us_per_km", _pd), ("line_length_km", _pd), ("line_parallel", _pi), ("line_in_service", _pu8),
+        ("n_branch_pu", C.c_int32), ("br_from_bus", _pi), ("br_to_bus", _pi), ("br_r_pu", _pd), ("br_x_pu", _pd),
+        ("br_b_pu", _pd), ("br_ratio", _pd), ("br_shift_deg", _pd),
+        ("n_shunt", C.c_int32), ("shunt_bus", _pi), ("shunt_p_mw", _pd), ("shunt_q_mvar", _pd),
+        ("n_load", C.c_int32), ("load_bus", _pi),
+        ("n_sgen", C.c_int32), ("sgen_bus", _pi), ("sgen_zone", _pi),
+        ("ext_grid_bus", C.c_int32), ("ext_grid_vm_pu", C.c_double), ("sn_mva", C.c_double), ("f_hz", C.c_double),
+    ]
+
+
+class CEnvConfig(C.Structure):
+    _fields_ = [
+        ("barrier_type", C.c_int32), ("voltage_weight", C.c_double), ("q_weight", C.c_double),
+        ("line_weight", C.c_double), ("use_line_weight", C.c_int32), ("use_q_weight", C.c_int32),
+        ("v_lower", C.c_double), ("v_upper", C.c_double), ("episode_limit", C.c_int32),
+        ("action_low", C.c_double), ("action_high", C.c_double), ("reset_action", C.c_int32),
+        ("state_space", C.c_int32), ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
+    ]
+
+
+class CDims(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in (
+        "n_envs", "n_bus", "n_line", "n_load", "n_sgen", "n_agents", "n_actions", "obs_size", "state_size",
+        "n_info", "is_radial", "max_zone_size")]
+
+
+class MapdnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmapdn_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it was not built — never falls back to CPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m mapdn_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.mapdn_last_error.restype = C.c_char_p
+    lib.mapdn_last_error.argtypes = [vp]
+    lib.mapdn_create.argtypes = [C.POINTER(CNetSpec), C.POINTER(CEnvConfig), C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.mapdn_destroy.argtypes = [vp]
+    lib.mapdn_destroy.restype = None
+    lib.mapdn_dims.argtypes = [vp, C.POINTER(CDims)]
+    lib.mapdn_set_profiles.argtypes = [vp, _pd, _pd, _pd, C.c_int64, C.c_int32, C.c_int32]
+    lib.mapdn_reset.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
+    lib.mapdn_step.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
+    lib.mapdn_get_start_rows.argtypes = [vp, vp, vp]
+    lib.mapdn_get_obs.argtypes = [vp, vp, C.c_int32, vp]
+    lib.mapdn_get_state.argtypes = [vp, vp, C.c_int32, vp]
+    lib.mapdn_get_results.argtypes = [vp] + [vp] * 7 + [vp]
+    lib.mapdn_get_loads.argtypes = [vp, vp, vp, vp]
+    lib.mapdn_solve_only.argtypes = [vp] + [vp] * 8 + [vp]
+    lib.mapdn_get_ybus_dense.argtypes = [vp, _pd]
+    lib.mapdn_get_obs_index.argtypes = [vp, _pi, _pi]
+    lib.mapdn_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int32), vp]
+    lib.mapdn_nr_timing.argtypes = [vp, C.c_int32]
+    lib.mapdn_nr_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    for name in EXPORTS:
+        if name not in ("mapdn_last_error", "mapdn_destroy"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, handle=None):
+    if rc != 0:
+        msg = load().mapdn_last_error(handle)
+        raise MapdnError(rc, msg.decode() if msg else "?")
+
+
+def _p(a, typ):
+    return a.ctypes.data_as(typ) if a.size else C.cast(None, typ)
+
+
+def make_cnetspec(net: NetSpec):
+    """Returns (CNetSpec, keepalive) — keepalive holds the numpy arrays the struct points into."""
+    keep = net  # NetSpec arrays are contiguous with the right dtypes (NetSpec.__post_init__)
+    s = CNetSpec()
+    s.n_bus = net.n_bus
+    s.bus_vn_kv = _p(net.bus_vn_kv, _pd)
+    s.bus_zone = _p(net.bus_zone, _pi)
+    s.n_line = net.n_line
+    s.line_from_bus = _p(net.line_from_bus, _pi)
+    s.line_to_bus = _p(net.line_to_bus, _pi)
+    s.line_r_ohm_per_km = _p(net.line_r_ohm_per_km, _pd)
+    s.line_x_ohm_per_km = _p(net.line_x_ohm_per_km, _pd)
+    s.line_c_nf_per_km = _p(net.line_c_nf_per_km, _pd)
+    s.line_g_us_per_km = _p(net.line_g_us_per_km, _pd)
+    s.line_length_km = _p(net.line_length_km, _pd)
+    s.line_parallel = _p(net.line_parallel, _pi)
+    s.line_in_service = _p(net.line_in_service, _pu8)
+    s.n_branch_pu = net.n_branch_pu
+    s.br_from_bus = _p(net.br_from_bus, _pi)
+    s.br_to_bus = _p(net.br_to_bus, _pi)
+    s.br_r_pu = _p(net.br_r_pu, _pd)
+    s.br_x_pu = _p(net.br_x_pu, _pd)
+    s.br_b_pu = _p(net.br_b_pu, _pd)
+    s.br_ratio = _p(net.br_ratio, _pd)
+    s.br_shift_deg = _p(net.br_shift_deg, _pd)
+    s.n_shunt = int(net.shunt_bus.shape[0])
+    s.shunt_bus = _p(net.shunt_bus, _pi)
+    s.shunt_p_mw = _p(net.shunt_p_mw, _pd)
+    s.shunt_q_mvar = _p(net.shunt_q_mvar, _pd)
+    s.n_load = net.n_load
+    s.load_bus = _p(net.load_bus, _pi)
+    s.n_sgen = net.n_sgen
+    s.sgen_bus = _p(net.sgen_bus, _pi)
+    s.sgen_zone = _p(net.sgen_zone, _pi)
+    s.ext_grid_bus = int(net.ext_grid_bus)
+    s.ext_grid_vm_pu = float(net.ext_grid_vm_pu)
+    s.sn_mva = float(net.sn_mva)
+    s.f_hz = float(net.f_hz)
+    return s, keep
+
+
+def make_cconfig(args: dict, env_id_offset: int = 0) -> CEnvConfig:
+    c = CEnvConfig()
+    bt = args.get("voltage_barrier_type", "l1")
+    if bt not in BARRIER_IDS:
+        raise KeyError(bt)   # reference: Voltage_Barrier[name] KeyError (voltage_barrier_backend.py:8)
+    c.barrier_type = BARRIER_IDS[bt]
+    c.voltage_weight = float(args.get("voltage_weight", 1.0))
+    qw, lw = args.get("q_weight", 0.1), args.get("line_weight", None)
+    c.q_weight = 0.0 if qw is None else float(qw)
+    c.line_weight = 0.0 if lw is None else float(lw)
+    c.use_q_weight = int(qw is not None)
+    c.use_line_weight = int(lw is not None)
+    c.v_lower = float(args.get("v_lower", 0.95))
+    c.v_upper = float(args.get("v_upper", 1.05))
+    c.episode_limit = int(args["episode_limit"])
+    c.action_low = -float(args["action_scale"]) + float(args["action_bias"])
+    c.action_high = float(args["action_scale"]) + float(args["action_bias"])
+    c.reset_action = int(bool(args.get("reset_action", True)))
+    ss = args.get("state_space", ["pv", "demand", "reactive", "vm_pu", "va_degree"])
+    c.state_space = sum(SS_BITS[k] for k in set(ss) if k in SS_BITS)
+    c.seed = int(args.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF
+    c.env_id_offset = int(env_id_offset)
+    return c

@@ -1,0 +1,39 @@
+"""Build libmapdn_hip.so in-tree with hipcc for gfx950 (no torch, no cmake)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmapdn_hip.so")
+SOURCES = ["plan.cpp", "kernels.hip", "capi.hip"]
+HEADERS = ["plan.hpp", "kernels.hpp", os.path.join("..", "..", "include", "mapdn.h")]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-Wall",
+           "-Wno-unused-result", "-o", LIB]
+    cmd = [c for c in cmd if c]
+    # .cpp host files are compiled as plain C++ by hipcc; .hip as HIP
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,430 @@
+// capi.hip — C ABI of libmapdn_hip.so (declared in include/mapdn.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "plan.hpp"
+
+using namespace mapdn;
+
+struct mapdn_handle {
+  Plan plan;
+  mapdn_env_config cfg;
+  Dev d;
+  int device = 0;
+  std::string err;
+  std::vector<void*> allocs;
+  bool have_profiles = false, was_reset = false, host_only = false;
+  int32_t *obs_kind = nullptr, *obs_idx = nullptr, *state_kind = nullptr, *state_idx = nullptr;
+  int32_t *zero_kind = nullptr, *iota_idx = nullptr, *pos_idx = nullptr;
+  double *t_pl = nullptr, *t_ql = nullptr, *t_pv = nullptr, *t_q = nullptr;
+  double* table = nullptr; double* stdv = nullptr; double* smax = nullptr;
+  long long* stats_dev = nullptr;
+  // NR kernel timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev;   // pairs
+  size_t ev_used = 0;
+  double acc_ms = 0.0;
+  int64_t acc_launches = 0;
+};
+
+static std::string g_create_err;
+
+#define NEEDDEV(h) do { if ((h)->host_only) { (h)->err = "host-only handle (device == -1): no device entry points"; return MAPDN_E_STATE; } } while (0)
+#define HIPCHK(h, call)                                                                         \
+  do {                                                                                          \
+    hipError_t _e = (call);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(_e);                             \
+      return MAPDN_E_HIP;                                                                       \
+    }                                                                                           \
+  } while (0)
+
+template <typename T>
+static int dalloc(mapdn_handle* h, T** p, size_t count) {
+  void* q = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  HIPCHK(h, hipMalloc(&q, bytes));
+  h->allocs.push_back(q);
+  HIPCHK(h, hipMemset(q, 0, bytes));
+  *p = (T*)q;
+  return MAPDN_OK;
+}
+
+template <typename T>
+static int dupload(mapdn_handle* h, const T** p, const std::vector<T>& v) {
+  T* q = nullptr;
+  int rc = dalloc(h, &q, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIPCHK(h, hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *p = q;
+  return MAPDN_OK;
+}
+
+extern "C" {
+
+const char* mapdn_last_error(const mapdn_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_env_config* cfg, int32_t B, int32_t device) {
+  if (!net || !cfg) { h->err = "null netspec/config"; return MAPDN_E_INVALID; }
+  if (B < 1) { h->err = "n_envs must be >= 1"; return MAPDN_E_INVALID; }
+  if (cfg->barrier_type < 0 || cfg->barrier_type > MAPDN_BARRIER_BUMP) { h->err = "unknown voltage_barrier_type"; return MAPDN_E_INVALID; }
+  if (!cfg->use_line_weight && !cfg->use_q_weight) {   // voltage_control_env.py:616-617
+    h->err = "NotImplementedError: Please at least give one weight, either q_weight or line_weight."; return MAPDN_E_INVALID; }
+  if (cfg->episode_limit < 2) { h->err = "episode_limit must be >= 2"; return MAPDN_E_INVALID; }
+  int rc = build_plan(*net, *cfg, h->plan, h->err);
+  if (rc) return rc;
+  h->cfg = *cfg;
+  h->device = device;
+  std::memset(&h->d, 0, sizeof(h->d));
+  h->d.B = B;
+  if (device == -1) { h->host_only = true; return MAPDN_OK; }   // plan only (CPU tests): no device work
+  int ndev = 0;
+  HIPCHK(h, hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) { h->err = "device index out of range"; return MAPDN_E_HIP; }
+  HIPCHK(h, hipSetDevice(device));
+  const Plan& P = h->plan;
+  Dev& d = h->d;
+  d.B = B; d.Bp = (B + 63) / 64 * 64; d.nb = P.nb; d.n = P.n; d.nl = P.nl; d.ns = P.ns; d.n_line = P.n_line;
+  d.ncol = P.ns + 2 * P.nl;
+  d.vroot = P.vroot; d.sn = P.sn_mva; d.tol = P.tol; d.max_it = 10;   // runpp max_iteration="auto" -> 10
+  d.yrr0 = P.yrr[0]; d.yrr1 = P.yrr[1];
+  d.barrier_type = cfg->barrier_type; d.use_line_weight = cfg->use_line_weight; d.episode_limit = cfg->episode_limit;
+  d.reset_action = cfg->reset_action; d.voltage_weight = cfg->voltage_weight; d.q_weight = cfg->q_weight;
+  d.line_weight = cfg->line_weight; d.v_lower = cfg->v_lower; d.v_upper = cfg->v_upper;
+  d.action_low = cfg->action_low; d.action_high = cfg->action_high;
+  d.seed_lo = (uint32_t)(cfg->seed & 0xffffffffull); d.seed_hi = (uint32_t)(cfg->seed >> 32);
+  d.env_id_offset = cfg->env_id_offset;
+#define UP(field, vec) do { rc = dupload(h, &d.field, vec); if (rc) return rc; } while (0)
+  UP(par, P.par); UP(flags, P.flags); UP(yc, P.yc); UP(bus_of_pos, P.bus_of_pos);
+  UP(load_ptr, P.load_ptr); UP(load_idx, P.load_idx); UP(sgen_ptr, P.sgen_ptr); UP(sgen_idx, P.sgen_idx);
+  UP(shunt_p, P.shunt_p); UP(shunt_q, P.shunt_q); UP(lines, P.lines);
+#undef UP
+  const size_t Bp = d.Bp;
+#define AL(field, rows) do { rc = dalloc(h, &d.field, (size_t)(rows) * Bp); if (rc) return rc; } while (0)
+  AL(cur_pv, d.ns); AL(cur_q, d.ns); AL(q_new, d.ns); AL(cur_pl, d.nl); AL(cur_ql, d.nl);
+  AL(vm, d.nb); AL(va, d.nb); AL(res_p, d.nb); AL(res_q, d.nb); AL(pb, d.nb); AL(qb, d.nb); AL(pl, d.n_line);
+  AL(line_loss, 1); AL(sum_rewards, 1); AL(steps, 1); AL(start_row, 1); AL(draw, 1); AL(done, 1); AL(pending, 1);
+  AL(active, 1); AL(adv_row, 1); AL(adv_draw, 1); AL(iters, 1); AL(conv, 1);
+  AL(Sr, d.n); AL(Si, d.n); AL(Ve, d.n + 1); AL(Vf, d.n + 1); AL(Vm, d.n + 1); AL(Va, d.n + 1);
+  AL(G, 4 * d.n); AL(H, 2 * d.n); AL(accS, 2 * d.n); AL(accD, 4 * d.n); AL(accR, 2 * d.n); AL(X, 2 * d.n);
+#undef AL
+  {  // root row of the trial-voltage arrays is constant: V_root = vroot + 0j
+    std::vector<double> row(Bp, d.vroot);
+    HIPCHK(h, hipMemcpy(d.Ve + (size_t)d.n * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d.Vm + (size_t)d.n * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<uint8_t> ones(Bp, 1);
+    HIPCHK(h, hipMemcpy(d.done, ones.data(), Bp, hipMemcpyHostToDevice));   // nothing is steppable before reset
+  }
+  const int32_t* tmp;
+  rc = dupload(h, &tmp, P.obs_kind); if (rc) return rc; h->obs_kind = (int32_t*)tmp;
+  rc = dupload(h, &tmp, P.obs_idx); if (rc) return rc; h->obs_idx = (int32_t*)tmp;
+  rc = dupload(h, &tmp, P.state_kind); if (rc) return rc; h->state_kind = (int32_t*)tmp;
+  rc = dupload(h, &tmp, P.state_idx); if (rc) return rc; h->state_idx = (int32_t*)tmp;
+  const int maxn = std::max(std::max(d.nb, d.n_line), std::max(d.nl, d.ns));
+  std::vector<int32_t> zk(maxn, 0), io(maxn);
+  for (int i = 0; i < maxn; ++i) io[i] = i;
+  rc = dupload(h, &tmp, zk); if (rc) return rc; h->zero_kind = (int32_t*)tmp;
+  rc = dupload(h, &tmp, io); if (rc) return rc; h->iota_idx = (int32_t*)tmp;
+  rc = dupload(h, &tmp, P.pos_of_bus); if (rc) return rc; h->pos_idx = (int32_t*)tmp;
+  rc = dalloc(h, &h->t_pl, (size_t)d.nl * Bp); if (rc) return rc;
+  rc = dalloc(h, &h->t_ql, (size_t)d.nl * Bp); if (rc) return rc;
+  rc = dalloc(h, &h->t_pv, (size_t)d.ns * Bp); if (rc) return rc;
+  rc = dalloc(h, &h->t_q, (size_t)d.ns * Bp); if (rc) return rc;
+  rc = dalloc(h, &h->stats_dev, 4); if (rc) return rc;
+  return MAPDN_OK;
+}
+
+int mapdn_create(const mapdn_netspec* net, const mapdn_env_config* cfg, int32_t n_envs, int32_t device, mapdn_handle** out) {
+  if (!out) { g_create_err = "null out pointer"; return MAPDN_E_INVALID; }
+  *out = nullptr;
+  mapdn_handle* h = new mapdn_handle();
+  int rc = create_impl(h, net, cfg, n_envs, device);
+  if (rc) { g_create_err = h->err; mapdn_destroy(h); return rc; }
+  *out = h;
+  return MAPDN_OK;
+}
+
+void mapdn_destroy(mapdn_handle* h) {
+  if (!h) return;
+  for (void* p : h->allocs) (void)hipFree(p);
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  delete h;
+}
+
+int mapdn_dims(const mapdn_handle* h, mapdn_dims_t* out) {
+  if (!h || !out) return MAPDN_E_INVALID;
+  const Plan& P = h->plan;
+  out->n_envs = h->d.B; out->n_bus = P.nb; out->n_line = P.n_line; out->n_load = P.nl; out->n_sgen = P.ns;
+  out->n_agents = P.n_agents; out->n_actions = 1; out->obs_size = P.obs_size; out->state_size = P.state_size;
+  out->n_info = MAPDN_N_INFO; out->is_radial = P.radial ? 1 : 0; out->max_zone_size = P.max_zone;
+  return MAPDN_OK;
+}
+
+int mapdn_set_profiles(mapdn_handle* h, const double* pv, const double* load_p, const double* load_q,
+                       int64_t T, int32_t time_delta_min, int32_t days) {
+  if (!h) return MAPDN_E_INVALID;
+  if (!pv || !load_p || !load_q || T < 2) { h->err = "set_profiles: null table or too few rows"; return MAPDN_E_INVALID; }
+  if (time_delta_min <= 0 || 60 % time_delta_min) { h->err = "set_profiles: time_delta_min must divide 60"; return MAPDN_E_INVALID; }
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  Dev& d = h->d;
+  const int ns = d.ns, nl = d.nl, ncol = d.ncol;
+  d.per_hour = 60 / time_delta_min; d.per_day = 24 * d.per_hour;
+  const int episode_days = d.episode_limit / d.per_day + 1;          // voltage_control_env.py:397
+  d.n_start_days = days - episode_days;                              // :398
+  if (d.n_start_days < 1) { h->err = "set_profiles: table too short for one episode (pv_days - episode_days < 1)"; return MAPDN_E_INVALID; }
+  const int64_t max_start = (d.per_hour - 1) + 23 * d.per_hour + (int64_t)(d.n_start_days - 1) * d.per_day;
+  if (max_start + d.episode_limit + 1 >= T) { h->err = "set_profiles: sampled episodes could run past the end of the table"; return MAPDN_E_INVALID; }
+  std::vector<double> tab((size_t)T * ncol), stdv(ncol), smax(ns);
+  for (int64_t t = 0; t < T; ++t) {
+    double* r = &tab[(size_t)t * ncol];
+    std::memcpy(r, pv + (size_t)t * ns, ns * sizeof(double));
+    std::memcpy(r + ns, load_p + (size_t)t * nl, nl * sizeof(double));
+    std::memcpy(r + ns + nl, load_q + (size_t)t * nl, nl * sizeof(double));
+  }
+  for (int c = 0; c < ncol; ++c) {   // population std over the whole table / 100 (:70-72)
+    double mean = 0.0;
+    for (int64_t t = 0; t < T; ++t) mean += tab[(size_t)t * ncol + c];
+    mean /= (double)T;
+    double var = 0.0;
+    for (int64_t t = 0; t < T; ++t) { const double x = tab[(size_t)t * ncol + c] - mean; var += x * x; }
+    stdv[c] = std::sqrt(var / (double)T) / 100.0;
+  }
+  for (int j = 0; j < ns; ++j) {     // s_max = 1.2 * max_t pv (:518-520)
+    double m = tab[j];
+    for (int64_t t = 1; t < T; ++t) m = std::max(m, tab[(size_t)t * ncol + j]);
+    smax[j] = 1.2 * m;
+  }
+  if (h->have_profiles) {   // replace: free the old table
+    for (double* p : {h->table, h->stdv, h->smax}) {
+      auto it = std::find(h->allocs.begin(), h->allocs.end(), (void*)p);
+      if (it != h->allocs.end()) { (void)hipFree(*it); h->allocs.erase(it); }
+    }
+  }
+  const double* tmp;
+  int rc = dupload(h, &tmp, tab); if (rc) return rc; h->table = (double*)tmp;
+  rc = dupload(h, &tmp, stdv); if (rc) return rc; h->stdv = (double*)tmp;
+  rc = dupload(h, &tmp, smax); if (rc) return rc; h->smax = (double*)tmp;
+  d.table = h->table; d.stdv = h->stdv; d.smax = h->smax; d.T = T;
+  h->have_profiles = true;
+  return MAPDN_OK;
+}
+
+static void nr_launch(mapdn_handle* h, hipStream_t st) {
+  if (!h->timing) { launch_nr(h->d, st); return; }
+  if (h->ev_used + 2 > h->ev.size()) {
+    if (h->ev.size() >= 2 * 8192) {   // pool full: drain
+      double ms; int64_t n; mapdn_nr_time_ms(h, &ms, &n); h->acc_ms = ms; h->acc_launches = n;
+    } else {
+      hipEvent_t a, b;
+      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+      h->ev.push_back(a); h->ev.push_back(b);
+    }
+  }
+  hipEvent_t a = h->ev[h->ev_used], b = h->ev[h->ev_used + 1];
+  h->ev_used += 2;
+  (void)hipEventRecord(a, st);
+  launch_nr(h->d, st);
+  (void)hipEventRecord(b, st);
+}
+
+int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, int32_t max_tries, void* stream) {
+  if (!h) return MAPDN_E_INVALID;
+  if (!h->have_profiles) { h->err = "reset before set_profiles"; return MAPDN_E_STATE; }
+  if (max_tries < 1) max_tries = 1;
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const Dev& d = h->d;
+  for (int t = 0; t < max_tries; ++t) {
+    launch_reset_begin(d, start_rows, t == 0, st);
+    launch_advance(d, add_noise, st);
+    launch_qnew(d, nullptr, MAPDN_F64, MODE_RESET, st);
+    launch_sbus(d, d.cur_pl, d.cur_ql, d.cur_pv, d.q_new, st);
+    nr_launch(h, st);
+    launch_commit_reward(d, MODE_RESET, add_noise, nullptr, nullptr, nullptr, st);
+  }
+  HIPCHK(h, hipGetLastError());
+  h->was_reset = true;
+  return MAPDN_OK;
+}
+
+int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int32_t add_noise, double* reward,
+               uint8_t* terminated, double* info, void* stream) {
+  if (!h) return MAPDN_E_INVALID;
+  if (!h->was_reset) { h->err = "step before reset"; return MAPDN_E_STATE; }
+  if (!actions || !reward || !terminated || !info) { h->err = "step: null buffer"; return MAPDN_E_INVALID; }
+  if (actions_dtype != MAPDN_F32 && actions_dtype != MAPDN_F64) { h->err = "step: bad actions dtype"; return MAPDN_E_INVALID; }
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const Dev& d = h->d;
+  launch_qnew(d, actions, actions_dtype, MODE_STEP, st);
+  launch_sbus(d, d.cur_pl, d.cur_ql, d.cur_pv, d.q_new, st);
+  nr_launch(h, st);
+  launch_commit_reward(d, MODE_STEP, add_noise, reward, terminated, info, st);
+  launch_advance(d, add_noise, st);
+  HIPCHK(h, hipGetLastError());
+  return MAPDN_OK;
+}
+
+static GatherSrc obs_sources(const Dev& d) {
+  GatherSrc g;
+  for (int k = 0; k < G_NKIND; ++k) { g.base[k] = nullptr; g.scale[k] = 1.0; }
+  g.base[G_P_ADDBACK] = d.pb; g.base[G_Q_ADDBACK] = d.qb; g.base[G_SGEN_P] = d.cur_pv; g.base[G_SGEN_Q] = d.cur_q;
+  g.base[G_VM] = d.vm; g.base[G_VA_RAD] = d.va; g.base[G_P] = d.res_p; g.base[G_Q] = d.res_q;
+  g.base[G_VA_DEG] = d.va; g.scale[G_VA_DEG] = 180.0 / M_PI;
+  return g;
+}
+
+int mapdn_get_obs(mapdn_handle* h, void* obs, int32_t dtype, void* stream) {
+  if (!h || !obs) return MAPDN_E_INVALID;
+  if (!h->was_reset) { h->err = "get_obs before reset"; return MAPDN_E_STATE; }
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  launch_addback(h->d, st);
+  launch_gather(h->d, obs_sources(h->d), h->obs_kind, h->obs_idx, obs, dtype, h->plan.n_agents * h->plan.obs_size, st);
+  HIPCHK(h, hipGetLastError());
+  return MAPDN_OK;
+}
+
+int mapdn_get_state(mapdn_handle* h, void* state, int32_t dtype, void* stream) {
+  if (!h || !state) return MAPDN_E_INVALID;
+  if (!h->was_reset) { h->err = "get_state before reset"; return MAPDN_E_STATE; }
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  launch_gather(h->d, obs_sources(h->d), h->state_kind, h->state_idx, state, dtype, h->plan.state_size, st);
+  HIPCHK(h, hipGetLastError());
+  return MAPDN_OK;
+}
+
+static void transpose_out(mapdn_handle* h, const double* src, double scale, const int32_t* idx, double* out, int n, hipStream_t st) {
+  GatherSrc g;
+  for (int k = 0; k < G_NKIND; ++k) { g.base[k] = nullptr; g.scale[k] = 1.0; }
+  g.base[0] = src; g.scale[0] = scale;
+  launch_gather(h->d, g, h->zero_kind, idx, out, MAPDN_F64, n, st);
+}
+
+int mapdn_get_results(mapdn_handle* h, double* vm_pu, double* va_degree, double* p_mw, double* q_mvar, double* pl_mw,
+                      double* sgen_p, double* sgen_q, void* stream) {
+  if (!h) return MAPDN_E_INVALID;
+  if (!h->was_reset) { h->err = "get_results before reset"; return MAPDN_E_STATE; }
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const Dev& d = h->d;
+  if (vm_pu) transpose_out(h, d.vm, 1.0, h->iota_idx, vm_pu, d.nb, st);
+  if (va_degree) transpose_out(h, d.va, 180.0 / M_PI, h->iota_idx, va_degree, d.nb, st);
+  if (p_mw) transpose_out(h, d.res_p, 1.0, h->iota_idx, p_mw, d.nb, st);
+  if (q_mvar) transpose_out(h, d.res_q, 1.0, h->iota_idx, q_mvar, d.nb, st);
+  if (pl_mw) transpose_out(h, d.pl, 1.0, h->iota_idx, pl_mw, d.n_line, st);
+  if (sgen_p) transpose_out(h, d.cur_pv, 1.0, h->iota_idx, sgen_p, d.ns, st);
+  if (sgen_q) transpose_out(h, d.cur_q, 1.0, h->iota_idx, sgen_q, d.ns, st);
+  HIPCHK(h, hipGetLastError());
+  return MAPDN_OK;
+}
+
+int mapdn_get_loads(mapdn_handle* h, double* load_p, double* load_q, void* stream) {
+  if (!h) return MAPDN_E_INVALID;
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (load_p) transpose_out(h, h->d.cur_pl, 1.0, h->iota_idx, load_p, h->d.nl, st);
+  if (load_q) transpose_out(h, h->d.cur_ql, 1.0, h->iota_idx, load_q, h->d.nl, st);
+  HIPCHK(h, hipGetLastError());
+  return MAPDN_OK;
+}
+
+int mapdn_get_start_rows(mapdn_handle* h, int64_t* start_rows, void* stream) {
+  if (!h || !start_rows) return MAPDN_E_INVALID;
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(start_rows, h->d.start_row, (size_t)h->d.B * sizeof(int64_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MAPDN_OK;
+}
+
+int mapdn_solve_only(mapdn_handle* h, const double* p_load, const double* q_load, const double* p_sgen, const double* q_sgen,
+                     double* vm_pu, double* va_degree, int32_t* iterations, uint8_t* converged, void* stream) {
+  if (!h) return MAPDN_E_INVALID;
+  if (!p_load || !q_load || !p_sgen || !q_sgen) { h->err = "solve_only: null input"; return MAPDN_E_INVALID; }
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const Dev& d = h->d;
+  launch_to_envminor(d, p_load, h->t_pl, d.nl, st);
+  launch_to_envminor(d, q_load, h->t_ql, d.nl, st);
+  launch_to_envminor(d, p_sgen, h->t_pv, d.ns, st);
+  launch_to_envminor(d, q_sgen, h->t_q, d.ns, st);
+  HIPCHK(h, hipMemsetAsync(d.active, 1, d.B, st));
+  if (d.Bp > d.B) HIPCHK(h, hipMemsetAsync(d.active + d.B, 0, d.Bp - d.B, st));
+  launch_sbus(d, h->t_pl, h->t_ql, h->t_pv, h->t_q, st);
+  nr_launch(h, st);
+  if (vm_pu) transpose_out(h, d.Vm, 1.0, h->pos_idx, vm_pu, d.nb, st);
+  if (va_degree) transpose_out(h, d.Va, 180.0 / M_PI, h->pos_idx, va_degree, d.nb, st);
+  if (iterations) launch_copy_i32(d.iters, iterations, d.B, st);
+  if (converged) launch_copy_u8(d.conv, converged, d.B, st);
+  HIPCHK(h, hipGetLastError());
+  return MAPDN_OK;
+}
+
+int mapdn_get_ybus_dense(const mapdn_handle* h, double* out) {
+  if (!h || !out) return MAPDN_E_INVALID;
+  const Plan& P = h->plan;
+  for (size_t i = 0; i < P.ybus.size(); ++i) { out[2 * i] = P.ybus[i].real(); out[2 * i + 1] = P.ybus[i].imag(); }
+  return MAPDN_OK;
+}
+
+int mapdn_get_obs_index(const mapdn_handle* h, int32_t* kind, int32_t* index) {
+  if (!h || !kind || !index) return MAPDN_E_INVALID;
+  std::memcpy(kind, h->plan.obs_kind.data(), h->plan.obs_kind.size() * sizeof(int32_t));
+  std::memcpy(index, h->plan.obs_idx.data(), h->plan.obs_idx.size() * sizeof(int32_t));
+  return MAPDN_OK;
+}
+
+int mapdn_stats(mapdn_handle* h, int64_t* reset_failures, double* mean_iters, int32_t* max_iters, void* stream) {
+  if (!h) return MAPDN_E_INVALID;
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  launch_stats(h->d, h->stats_dev, st);
+  long long host[4];
+  HIPCHK(h, hipMemcpyAsync(host, h->stats_dev, sizeof(host), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (reset_failures) *reset_failures = host[0];
+  if (mean_iters) *mean_iters = host[2] ? (double)host[1] / (double)host[2] : 0.0;
+  if (max_iters) *max_iters = (int32_t)host[3];
+  return MAPDN_OK;
+}
+
+int mapdn_nr_timing(mapdn_handle* h, int32_t enable) {
+  if (!h) return MAPDN_E_INVALID;
+  h->timing = enable != 0;
+  return MAPDN_OK;
+}
+
+int mapdn_nr_time_ms(mapdn_handle* h, double* total_ms, int64_t* launches) {
+  if (!h) return MAPDN_E_INVALID;
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  double ms = h->acc_ms; int64_t n = h->acc_launches;
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    HIPCHK(h, hipEventSynchronize(h->ev[i + 1]));
+    float t = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]));
+    ms += t; n += 1;
+  }
+  h->ev_used = 0; h->acc_ms = 0.0; h->acc_launches = 0;
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  return MAPDN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// kernels.hpp — device-visible argument block + host launchers of kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "plan.hpp"
+
+namespace mapdn {
+
+enum { MODE_STEP = 0, MODE_RESET = 1 };
+enum { STREAM_PV = 0, STREAM_LOAD_P = 1, STREAM_LOAD_Q = 2, STREAM_ACTION = 3, STREAM_START = 4 };
+
+// Everything a kernel needs, passed by value (kernarg segment -> scalar loads).
+// Layout rule: per-env arrays are env-minor, X[item][Bp]; Bp = B rounded up to 64.
+struct Dev {
+  int32_t B, Bp, nb, n, nl, ns, n_line, ncol;
+  double vroot, sn, tol;
+  int32_t max_it;
+  // ---- topology plan (shared by all envs; wave-uniform reads)
+  const int32_t* par; const uint32_t* flags; const double* yc; double yrr0, yrr1;
+  const int32_t* bus_of_pos;
+  const int32_t *load_ptr, *load_idx, *sgen_ptr, *sgen_idx;
+  const double *shunt_p, *shunt_q;
+  const LineFlow* lines;
+  // ---- profile tables: [T][ncol], columns = pv | load_p | load_q
+  const double* table; const double* stdv; const double* smax;
+  int64_t T; int32_t n_start_days, per_hour, per_day;
+  // ---- config
+  int32_t barrier_type, use_line_weight, episode_limit, reset_action;
+  double voltage_weight, q_weight, line_weight, v_lower, v_upper, action_low, action_high;
+  uint32_t seed_lo, seed_hi; int64_t env_id_offset;
+  // ---- env state
+  double *cur_pv, *cur_q, *cur_pl, *cur_ql, *q_new;   // [ns|nl][Bp]  MW / MVAr
+  double *vm, *va, *res_p, *res_q;                    // [nb][Bp] by bus id; va in rad
+  double *pb, *qb;                                    // [nb][Bp] res_bus p/q with PV add-back
+  double *pl;                                         // [n_line][Bp] res_line.pl_mw
+  double *line_loss, *sum_rewards;                    // [Bp]
+  int32_t* steps; int64_t* start_row; uint32_t* draw;
+  uint8_t *done, *pending, *active;
+  int64_t* adv_row; uint32_t* adv_draw;
+  // ---- NR scratch, elimination-position order
+  double *Sr, *Si, *Ve, *Vf, *Vm, *Va;                // [n][Bp]
+  double *G, *H, *accS, *accD, *accR, *X;             // [4n|2n][Bp]
+  int32_t* iters; uint8_t* conv;
+};
+
+struct GatherSrc {
+  const double* base[G_NKIND];
+  double scale[G_NKIND];
+};
+
+void launch_qnew(const Dev& d, const void* actions, int dtype, int mode, hipStream_t st);
+void launch_sbus(const Dev& d, const double* pl, const double* ql, const double* pv, const double* q, hipStream_t st);
+void launch_nr(const Dev& d, hipStream_t st);
+void launch_commit_reward(const Dev& d, int mode, int add_noise, double* reward, uint8_t* term, double* info, hipStream_t st);
+void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);
+void launch_advance(const Dev& d, int add_noise, hipStream_t st);
+void launch_addback(const Dev& d, hipStream_t st);
+void launch_gather(const Dev& d, const GatherSrc& g, const int32_t* kind, const int32_t* idx, void* out, int dtype, int C, hipStream_t st);
+void launch_to_envminor(const Dev& d, const double* src, double* dst, int n, hipStream_t st);
+void launch_copy_i32(const int32_t* s, int32_t* dd, int B, hipStream_t st);
+void launch_copy_u8(const uint8_t* s, uint8_t* dd, int B, hipStream_t st);
+void launch_iota(int32_t* kind, int32_t* idx, int n, int k, hipStream_t st);
+void launch_stats(const Dev& d, long long* out, hipStream_t st);
+
+}  // namespace mapdn

@@ -1,0 +1,234 @@
+// plan.cpp — see plan.hpp.  Host only (no HIP).
+#include "plan.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+
+namespace mapdn {
+
+namespace {
+
+struct PiBranch {
+  int32_t f, t;
+  cplx yff, yft, ytf, ytt;
+};
+
+// pandapower build_branch._calc_line_parameter + pypower makeYbus, one branch at a time
+PiBranch pi_from_line(const mapdn_netspec& net, int l) {
+  const int f = net.line_from_bus[l], t = net.line_to_bus[l];
+  const double vn = net.bus_vn_kv[f];
+  const double base_r = vn * vn / net.sn_mva;
+  const double len = net.line_length_km[l];
+  const double par = (double)net.line_parallel[l];
+  const double r = net.line_r_ohm_per_km[l] * len / base_r / par;
+  const double x = net.line_x_ohm_per_km[l] * len / base_r / par;
+  const double b = 2.0 * net.f_hz * M_PI * net.line_c_nf_per_km[l] * 1e-9 * base_r * len * par;
+  const double g = net.line_g_us_per_km[l] * 1e-6 * base_r * len * par;
+  const cplx bc(b, -g);                       // ppc BR_B = b - 1j*g
+  const cplx ys = 1.0 / cplx(r, x);
+  const cplx ytt = ys + cplx(0, 1) * bc / 2.0;
+  return PiBranch{f, t, ytt, -ys, -ys, ytt};  // tap == 1
+}
+
+PiBranch pi_from_pu(const mapdn_netspec& net, int k) {
+  const double ratio = net.br_ratio[k] == 0.0 ? 1.0 : net.br_ratio[k];
+  const cplx tap = std::polar(ratio, net.br_shift_deg[k] * M_PI / 180.0);
+  const cplx ys = 1.0 / cplx(net.br_r_pu[k], net.br_x_pu[k]);
+  const cplx ytt = ys + cplx(0, 1) * cplx(net.br_b_pu[k], 0.0) / 2.0;
+  return PiBranch{net.br_from_bus[k], net.br_to_bus[k], ytt / (tap * std::conj(tap)),
+                  -ys / std::conj(tap), -ys / tap, ytt};
+}
+
+}  // namespace
+
+int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, std::string& err) {
+  const int nb = net.n_bus;
+  if (nb < 2) { err = "netspec: need at least 2 buses"; return MAPDN_E_INVALID; }
+  if (net.ext_grid_bus < 0 || net.ext_grid_bus >= nb) { err = "netspec: ext_grid_bus out of range"; return MAPDN_E_INVALID; }
+  if (!(net.sn_mva > 0)) { err = "netspec: sn_mva must be > 0"; return MAPDN_E_INVALID; }
+  auto bad_bus = [&](int b) { return b < 0 || b >= nb; };
+  for (int l = 0; l < net.n_line; ++l)
+    if (bad_bus(net.line_from_bus[l]) || bad_bus(net.line_to_bus[l]) || net.line_from_bus[l] == net.line_to_bus[l]) {
+      err = "netspec: line " + std::to_string(l) + " has invalid endpoints"; return MAPDN_E_INVALID; }
+  for (int k = 0; k < net.n_branch_pu; ++k)
+    if (bad_bus(net.br_from_bus[k]) || bad_bus(net.br_to_bus[k]) || net.br_from_bus[k] == net.br_to_bus[k]) {
+      err = "netspec: branch " + std::to_string(k) + " has invalid endpoints"; return MAPDN_E_INVALID; }
+  for (int i = 0; i < net.n_load; ++i) if (bad_bus(net.load_bus[i])) { err = "netspec: load bus out of range"; return MAPDN_E_INVALID; }
+  for (int i = 0; i < net.n_sgen; ++i) {
+    if (bad_bus(net.sgen_bus[i])) { err = "netspec: sgen bus out of range"; return MAPDN_E_INVALID; }
+    // reference: `.loc[sgen_bus]` on the zone frame raises KeyError otherwise (voltage_control_env.py:239)
+    if (net.bus_zone[net.sgen_bus[i]] != net.sgen_zone[i]) {
+      err = "netspec: sgen " + std::to_string(i) + " sits on a bus outside its own zone (reference get_obs would raise KeyError)";
+      return MAPDN_E_INVALID; }
+    if (net.sgen_zone[i] <= 0) { err = "netspec: sgen zone must be a non-main zone"; return MAPDN_E_INVALID; }
+  }
+  for (int i = 0; i < net.n_shunt; ++i) if (bad_bus(net.shunt_bus[i])) { err = "netspec: shunt bus out of range"; return MAPDN_E_INVALID; }
+  if (net.n_sgen < 1) { err = "netspec: need at least one sgen (agent)"; return MAPDN_E_INVALID; }
+
+  P.nb = nb; P.n = nb - 1; P.nl = net.n_load; P.ns = net.n_sgen; P.n_line = net.n_line;
+  P.root_bus = net.ext_grid_bus; P.vroot = net.ext_grid_vm_pu; P.sn_mva = net.sn_mva;
+  P.tol = 1e-8 / net.sn_mva;   // runpp tolerance_mva=1e-8 on a per-unit mismatch
+
+  // ---- Ybus (dense on the host; nb <= a few hundred) -------------------------------------------
+  P.ybus.assign((size_t)nb * nb, cplx(0, 0));
+  auto Y = [&](int i, int j) -> cplx& { return P.ybus[(size_t)i * nb + j]; };
+  std::vector<PiBranch> line_pi(net.n_line);
+  auto stamp = [&](const PiBranch& b) {
+    Y(b.f, b.f) += b.yff; Y(b.f, b.t) += b.yft; Y(b.t, b.f) += b.ytf; Y(b.t, b.t) += b.ytt;
+  };
+  std::vector<std::vector<int>> adj(nb);
+  auto link = [&](int f, int t) {
+    if (std::find(adj[f].begin(), adj[f].end(), t) == adj[f].end()) { adj[f].push_back(t); adj[t].push_back(f); }
+  };
+  for (int l = 0; l < net.n_line; ++l) {
+    if (!net.line_in_service[l]) continue;
+    line_pi[l] = pi_from_line(net, l);
+    stamp(line_pi[l]); link(line_pi[l].f, line_pi[l].t);
+  }
+  for (int k = 0; k < net.n_branch_pu; ++k) { PiBranch b = pi_from_pu(net, k); stamp(b); link(b.f, b.t); }
+  P.shunt_p.assign(nb, 0.0); P.shunt_q.assign(nb, 0.0);
+  std::vector<double> sh_p_bus(nb, 0.0), sh_q_bus(nb, 0.0);
+  for (int i = 0; i < net.n_shunt; ++i) {   // pandapower shunt: GS = p_mw, BS = -q_mvar
+    Y(net.shunt_bus[i], net.shunt_bus[i]) += cplx(net.shunt_p_mw[i], -net.shunt_q_mvar[i]) / net.sn_mva;
+    sh_p_bus[net.shunt_bus[i]] += net.shunt_p_mw[i]; sh_q_bus[net.shunt_bus[i]] += net.shunt_q_mvar[i];
+  }
+
+  // ---- radial check + reverse-preorder elimination order ----------------------------------------
+  size_t n_edges = 0;
+  for (int i = 0; i < nb; ++i) { std::sort(adj[i].begin(), adj[i].end()); n_edges += adj[i].size(); }
+  n_edges /= 2;
+  std::vector<int> parent_bus(nb, -1), preorder;
+  preorder.reserve(nb);
+  {
+    std::vector<char> seen(nb, 0);
+    std::vector<int> stack{P.root_bus};
+    seen[P.root_bus] = 1;
+    while (!stack.empty()) {
+      int u = stack.back(); stack.pop_back();
+      preorder.push_back(u);
+      // push in reverse so the smallest-index neighbour is visited first (deterministic)
+      for (auto it = adj[u].rbegin(); it != adj[u].rend(); ++it)
+        if (!seen[*it]) { seen[*it] = 1; parent_bus[*it] = u; stack.push_back(*it); }
+    }
+  }
+  if ((int)preorder.size() != nb) { err = "topology: network is not connected to the ext_grid bus (pandapower would drop unsupplied buses; not supported)"; return MAPDN_E_TOPOLOGY; }
+  P.radial = (n_edges == (size_t)nb - 1);
+  if (!P.radial) { err = "topology: meshed network (" + std::to_string(n_edges) + " bus pairs for " + std::to_string(nb) + " buses); this build solves radial feeders only"; return MAPDN_E_TOPOLOGY; }
+
+  // NOTE on the stack-DFS above: a node is "seen" when pushed, so preorder is a valid
+  // parent-before-child order, but a child is not necessarily visited right after its parent.
+  // Re-derive a true DFS preorder (child chains contiguous) recursively over the parent map.
+  {
+    std::vector<std::vector<int>> children(nb);
+    for (int v : preorder) if (parent_bus[v] >= 0) children[parent_bus[v]].push_back(v);
+    // visit the child with the largest subtree LAST-in-preorder => it ends up adjacent (k, k+1)... any
+    // child can take the register-carried slot; pick the deepest subtree to keep long chains in registers.
+    std::vector<int> sub(nb, 1);
+    for (auto it = preorder.rbegin(); it != preorder.rend(); ++it) if (parent_bus[*it] >= 0) sub[parent_bus[*it]] += sub[*it];
+    for (int u = 0; u < nb; ++u)
+      std::stable_sort(children[u].begin(), children[u].end(), [&](int a, int b) { return sub[a] > sub[b]; });
+    std::vector<int> order; order.reserve(nb);
+    std::vector<int> stack{P.root_bus};
+    while (!stack.empty()) {
+      int u = stack.back(); stack.pop_back();
+      order.push_back(u);
+      for (auto it = children[u].rbegin(); it != children[u].rend(); ++it) stack.push_back(*it);
+    }
+    preorder.swap(order);   // true preorder: parent, then first child's whole subtree, ...
+  }
+  P.bus_of_pos.assign(nb, -1); P.pos_of_bus.assign(nb, -1);
+  for (int i = 1; i < nb; ++i) {           // reverse preorder, root excluded -> positions 0..n-1
+    int bus = preorder[nb - i];
+    P.bus_of_pos[i - 1] = bus; P.pos_of_bus[bus] = i - 1;
+  }
+  P.bus_of_pos[P.n] = P.root_bus; P.pos_of_bus[P.root_bus] = P.n;
+  P.par.assign(P.n, 0); P.flags.assign(P.n, 0u); P.yc.assign((size_t)P.n * 6, 0.0);
+  for (int k = 0; k < P.n; ++k) {
+    int bus = P.bus_of_pos[k], pb = parent_bus[bus], p = P.pos_of_bus[pb];
+    if (p <= k) { err = "internal: elimination order violated"; return MAPDN_E_INVALID; }
+    P.par[k] = p;
+    cplx ykk = Y(bus, bus), ykp = Y(bus, pb), ypk = Y(pb, bus);
+    double* c = &P.yc[(size_t)k * 6];
+    c[0] = ykk.real(); c[1] = ykk.imag(); c[2] = ykp.real(); c[3] = ykp.imag(); c[4] = ypk.real(); c[5] = ypk.imag();
+    if (p == P.n) P.flags[k] |= F_PARENT_ROOT;
+    else if (p == k + 1) P.flags[k] |= F_PARENT_NEXT;
+  }
+  {
+    std::vector<char> has_scratch_child(P.n + 1, 0);
+    for (int k = 0; k < P.n; ++k) {
+      uint32_t f = P.flags[k];
+      if (f & F_PARENT_ROOT) continue;
+      if (f & F_PARENT_NEXT) { P.flags[k + 1] |= F_CARRY_IN; continue; }
+      int p = P.par[k];
+      if (!has_scratch_child[p]) { has_scratch_child[p] = 1; P.flags[k] |= F_SCRATCH_FIRST; }
+      P.flags[p] |= F_SCRATCH_IN;
+    }
+  }
+  P.yrr[0] = Y(P.root_bus, P.root_bus).real(); P.yrr[1] = Y(P.root_bus, P.root_bus).imag();
+
+  // ---- res_line flows ---------------------------------------------------------------------------
+  P.lines.resize(net.n_line);
+  for (int l = 0; l < net.n_line; ++l) {
+    LineFlow& L = P.lines[l];
+    if (!net.line_in_service[l]) { L.fpos = L.tpos = -1; continue; }
+    const PiBranch& b = line_pi[l];
+    L.fpos = P.pos_of_bus[b.f]; L.tpos = P.pos_of_bus[b.t];
+    L.yff[0] = b.yff.real(); L.yff[1] = b.yff.imag(); L.yft[0] = b.yft.real(); L.yft[1] = b.yft.imag();
+    L.ytf[0] = b.ytf.real(); L.ytf[1] = b.ytf.imag(); L.ytt[0] = b.ytt.real(); L.ytt[1] = b.ytt.imag();
+  }
+
+  // ---- element CSR by position ------------------------------------------------------------------
+  auto csr = [&](int n_el, const int32_t* el_bus, std::vector<int32_t>& ptr, std::vector<int32_t>& idx) {
+    ptr.assign(nb + 1, 0); idx.assign(n_el, 0);
+    for (int i = 0; i < n_el; ++i) ptr[P.pos_of_bus[el_bus[i]] + 1]++;
+    for (int k = 0; k < nb; ++k) ptr[k + 1] += ptr[k];
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int i = 0; i < n_el; ++i) idx[fill[P.pos_of_bus[el_bus[i]]]++] = i;   // ascending element index
+  };
+  csr(net.n_load, net.load_bus, P.load_ptr, P.load_idx);
+  csr(net.n_sgen, net.sgen_bus, P.sgen_ptr, P.sgen_idx);
+  for (int b = 0; b < nb; ++b) { P.shunt_p[P.pos_of_bus[b]] = sh_p_bus[b]; P.shunt_q[P.pos_of_bus[b]] = sh_q_bus[b]; }
+  P.sgen_bus.assign(net.sgen_bus, net.sgen_bus + net.n_sgen);
+
+  // ---- get_obs (distributed mode) — voltage_control_env.py:245-274 --------------------------------
+  const int ss = cfg.state_space;
+  P.n_agents = net.n_sgen;
+  std::vector<std::vector<int>> zone_rows(net.n_sgen);
+  size_t max_len = 0; P.max_zone = 0;
+  auto obs_len = [&](size_t z) {
+    return ((ss & MAPDN_SS_DEMAND) ? 2 * z : 0) + ((ss & MAPDN_SS_PV) ? 1 : 0) + ((ss & MAPDN_SS_REACTIVE) ? 1 : 0) +
+           ((ss & MAPDN_SS_VM_PU) ? z : 0) + ((ss & MAPDN_SS_VA_DEGREE) ? z : 0);
+  };
+  for (int i = 0; i < net.n_sgen; ++i) {
+    for (int b = 0; b < nb; ++b) if (net.bus_zone[b] == net.sgen_zone[i]) zone_rows[i].push_back(b);  // ascending bus index (:536)
+    max_len = std::max(max_len, obs_len(zone_rows[i].size()));
+    P.max_zone = std::max<int32_t>(P.max_zone, (int32_t)zone_rows[i].size());
+  }
+  P.obs_size = (int32_t)max_len;
+  if (P.obs_size == 0) { err = "config: empty state_space"; return MAPDN_E_INVALID; }
+  P.obs_kind.assign((size_t)P.n_agents * P.obs_size, G_ZERO);
+  P.obs_idx.assign((size_t)P.n_agents * P.obs_size, 0);
+  for (int i = 0; i < net.n_sgen; ++i) {
+    size_t c = (size_t)i * P.obs_size;
+    auto put = [&](int32_t kind, int32_t idx) { P.obs_kind[c] = kind; P.obs_idx[c] = idx; ++c; };
+    const auto& rows = zone_rows[i];
+    if (ss & MAPDN_SS_DEMAND) { for (int b : rows) put(G_P_ADDBACK, b); for (int b : rows) put(G_Q_ADDBACK, b); }  // :254-257
+    if (ss & MAPDN_SS_PV) put(G_SGEN_P, i);                                                                        // :258-259
+    if (ss & MAPDN_SS_REACTIVE) put(G_SGEN_Q, i);                                                                  // :260-261
+    if (ss & MAPDN_SS_VM_PU) for (int b : rows) put(G_VM, b);                                                      // :262-263
+    if (ss & MAPDN_SS_VA_DEGREE) for (int b : rows) put(G_VA_RAD, b);                                              // :264-266
+  }
+  // ---- get_state — voltage_control_env.py:213-230 -------------------------------------------------
+  P.state_kind.clear(); P.state_idx.clear();
+  auto sput = [&](int32_t kind, int32_t idx) { P.state_kind.push_back(kind); P.state_idx.push_back(idx); };
+  if (ss & MAPDN_SS_DEMAND) { for (int b = 0; b < nb; ++b) sput(G_P, b); for (int b = 0; b < nb; ++b) sput(G_Q, b); }
+  if (ss & MAPDN_SS_PV) for (int j = 0; j < net.n_sgen; ++j) sput(G_SGEN_P, j);
+  if (ss & MAPDN_SS_REACTIVE) for (int j = 0; j < net.n_sgen; ++j) sput(G_SGEN_Q, j);
+  if (ss & MAPDN_SS_VM_PU) for (int b = 0; b < nb; ++b) sput(G_VM, b);
+  if (ss & MAPDN_SS_VA_DEGREE) for (int b = 0; b < nb; ++b) sput(G_VA_DEG, b);
+  P.state_size = (int32_t)P.state_kind.size();
+  return MAPDN_OK;
+}
+
+}  // namespace mapdn

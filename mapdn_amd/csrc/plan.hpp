@@ -1,0 +1,69 @@
+// plan.hpp — host-side, topology-only precomputation shared by every env of a batch.
+//
+// Replaces what pandapower rebuilds on every runpp call (pd2ppc -> ppc branch table -> makeYbus;
+// reference call site voltage_control_env.py:557) by a one-time build: per-unit pi-branches, Ybus,
+// a leaf-to-root elimination order of the radial feeder (so the block-2x2 LU of the NR Jacobian has
+// zero fill), element->bus CSR lists, and the integer gather tables of get_obs / get_state
+// (voltage_control_env.py:213-316).
+#pragma once
+#include <complex>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mapdn.h"
+
+namespace mapdn {
+
+using cplx = std::complex<double>;
+
+// node flags of the elimination schedule (wave-uniform control flow in the NR kernel)
+enum : uint32_t {
+  F_PARENT_ROOT = 1u,    // parent is the slack bus: no off-diagonal Jacobian block
+  F_PARENT_NEXT = 2u,    // parent is node k+1: Schur update / S contribution carried in registers
+  F_CARRY_IN = 4u,       // node k-1 is a child of k (its contribution arrives in registers)
+  F_SCRATCH_IN = 8u,     // k has children other than k-1: their contributions sit in scratch
+  F_SCRATCH_FIRST = 16u, // k is the first scratch-child of its parent: store, don't add
+};
+
+// gather source kinds (obs/state column descriptors)
+enum : int32_t {
+  G_ZERO = 0, G_P_ADDBACK = 1, G_Q_ADDBACK = 2, G_SGEN_P = 3, G_SGEN_Q = 4, G_VM = 5, G_VA_RAD = 6,
+  G_P = 7, G_Q = 8, G_VA_DEG = 9, G_NKIND = 10
+};
+
+struct LineFlow {      // pi-model admittances of one net.line row for res_line.pl_mw
+  int32_t fpos, tpos;  // elimination positions (n == root); -1 if out of service
+  double yff[2], yft[2], ytf[2], ytt[2];
+};
+
+struct Plan {
+  int32_t nb = 0, n = 0;              // buses, non-slack nodes
+  int32_t nl = 0, ns = 0, n_line = 0; // loads, sgens, net.line rows
+  int32_t root_bus = 0;
+  double vroot = 1.0, sn_mva = 1.0, tol = 1e-8;
+  bool radial = false;
+
+  std::vector<int32_t> bus_of_pos, pos_of_bus;  // [nb]; pos n == root
+  std::vector<int32_t> par;                     // [n] parent position
+  std::vector<uint32_t> flags;                  // [n]
+  std::vector<double> yc;                       // [n*6] ykk, ykp, ypk (re, im)
+  double yrr[2] = {0, 0};
+  std::vector<cplx> ybus;                       // dense [nb*nb], debug export only
+
+  std::vector<LineFlow> lines;                  // [n_line]
+  // element -> bus CSR by position (0..nb-1, root last)
+  std::vector<int32_t> load_ptr, load_idx, sgen_ptr, sgen_idx;
+  std::vector<double> shunt_p, shunt_q;         // [nb] by position, MW/MVAr at 1 p.u.
+  std::vector<int32_t> sgen_bus;                // [ns] bus ids
+
+  // get_obs / get_state tables
+  int32_t n_agents = 0, obs_size = 0, state_size = 0, max_zone = 0;
+  std::vector<int32_t> obs_kind, obs_idx;       // [n_agents*obs_size]
+  std::vector<int32_t> state_kind, state_idx;   // [state_size]
+};
+
+// returns MAPDN_OK or an error code, filling `err`
+int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& out, std::string& err);
+
+}  // namespace mapdn
