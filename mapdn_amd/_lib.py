@@ -83,6 +83,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import it FIRST so that our
+    # NEEDED libamdhip64.so.7 resolves to the runtime torch already loaded: one HIP runtime per
+    # process, shared streams and device pointers.  (Loading ours first drags in /opt/rocm's copy
+    # and the second runtime then fails with "no ROCm-capable device".)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -m mapdn_amd.build` "

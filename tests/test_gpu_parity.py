@@ -287,3 +287,37 @@ def test_dropin_b1_adapter():
     assert env.get_avail_actions().shape == (1, 6, 1)
     assert env._get_res_bus_v().shape == (33,) and env._get_res_line_loss().shape == (32,)
     env.close()
+
+
+# ---- committed golden fixtures (tests/golden/, oracle outputs; see make_golden.py) -----------------
+import os as _os
+_G = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("case", ["case33", "case141", "case322"])
+def test_golden_solves(case):
+    g = np.load(_os.path.join(_G, f"solve_{case}.npz"))
+    B = g["vm_pu"].shape[0]
+    net, prof, env = make(case, B)
+    vm, va, it, cv = env.solve(g["p_load"], g["q_load"], g["p_sgen"], g["q_sgen"])
+    assert cv.all() and np.array_equal(it.cpu().numpy(), g["iterations"])
+    assert np.abs(vm.cpu().numpy() - g["vm_pu"]).max() < V_TOL
+    assert np.abs(va.cpu().numpy() - g["va_degree"]).max() < 1e-7
+    env.close()
+
+
+@pytest.mark.parametrize("case", ["case33", "case141"])
+def test_golden_episode(case):
+    g = np.load(_os.path.join(_G, f"episode_{case}.npz"))
+    T, B = g["reward"].shape
+    net, prof, env = make(case, B, voltage_barrier_type=str(g["barrier"]), seed=int(g["seed"]))
+    obs, state = env.reset()
+    assert np.array_equal(env.start_rows().cpu().numpy(), g["start_rows"])
+    assert np.abs(obs.cpu().numpy() - g["obs"][0]).max() < 1e-9
+    for t in range(T):
+        r, term, info = env.step(torch.as_tensor(g["actions"][t], device="cuda:0"))
+        assert np.abs(r.cpu().numpy() - g["reward"][t]).max() < 1e-9
+        assert np.abs(info.cpu().numpy() - g["info"][t]).max() < 1e-9
+        assert np.abs(env.get_obs().cpu().numpy() - g["obs"][t + 1]).max() < 1e-9
+        assert np.abs(env.get_state().cpu().numpy() - g["state"][t + 1]).max() < 1e-7
+    env.close()
