@@ -175,6 +175,11 @@ int mapdn_get_ybus_dense(const mapdn_handle* h, double* ybus_re_im);
  * [n_agents*obs_size] (kinds: 0 zero pad, 1 p_mw, 2 q_mvar, 3 pv, 4 q, 5 vm_pu, 6 va rad). */
 int mapdn_get_obs_index(const mapdn_handle* h, int32_t* kind, int32_t* index);
 
+/* Host-side export of the NR elimination schedule for W cooperating waves (plan check, CPU tests):
+ * rows [W * (*n_rows)] node position per (wave, row) or -1, parent [n] parent position per node
+ * (n = n_bus-1 means the slack).  Call with rows == NULL to query *n_rows first. */
+int mapdn_get_schedule(const mapdn_handle* h, int32_t n_waves, int32_t* n_rows, int32_t* rows, int32_t* parent);
+
 /* counters (host, synchronises the given stream): number of envs whose last reset exhausted
  * max_tries; mean / max NR iterations of the last solve */
 int mapdn_stats(mapdn_handle* h, int64_t* reset_failures, double* mean_iters, int32_t* max_iters,

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,6 +15,7 @@ using namespace mapdn;
 
 struct mapdn_handle {
   Plan plan;
+  Schedule sched;
   mapdn_env_config cfg;
   Dev d;
   int device = 0;
@@ -21,7 +23,7 @@ struct mapdn_handle {
   std::vector<void*> allocs;
   bool have_profiles = false, was_reset = false, host_only = false;
   int32_t *obs_kind = nullptr, *obs_idx = nullptr, *state_kind = nullptr, *state_idx = nullptr;
-  int32_t *zero_kind = nullptr, *iota_idx = nullptr, *pos_idx = nullptr;
+  int32_t *zero_kind = nullptr, *iota_idx = nullptr, *vm_row = nullptr, *va_row = nullptr;
   double *t_pl = nullptr, *t_ql = nullptr, *t_pv = nullptr, *t_q = nullptr;
   double* table = nullptr; double* stdv = nullptr; double* smax = nullptr;
   long long* stats_dev = nullptr;
@@ -66,6 +68,17 @@ static int dupload(mapdn_handle* h, const T** p, const std::vector<T>& v) {
   return MAPDN_OK;
 }
 
+// waves per env group / envs per wave for a padded batch of Bp envs (MI355X: 256 CUs x 4 SIMDs)
+static void choose_nr_geometry(int Bp, int& W, int& L) {
+  const int groups64 = Bp / 64;
+  if (groups64 >= 2048) { W = 1; L = 64; }
+  else if (groups64 >= 1024) { W = 2; L = 64; }
+  else if (groups64 >= 512) { W = 4; L = 64; }
+  else if (groups64 >= 128) { W = 8; L = 64; }
+  else if (groups64 >= 64) { W = 8; L = 32; }
+  else { W = 8; L = 16; }
+}
+
 extern "C" {
 
 const char* mapdn_last_error(const mapdn_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -101,23 +114,17 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   d.seed_lo = (uint32_t)(cfg->seed & 0xffffffffull); d.seed_hi = (uint32_t)(cfg->seed >> 32);
   d.env_id_offset = cfg->env_id_offset;
 #define UP(field, vec) do { rc = dupload(h, &d.field, vec); if (rc) return rc; } while (0)
-  UP(par, P.par); UP(flags, P.flags); UP(yc, P.yc); UP(bus_of_pos, P.bus_of_pos);
+  UP(bus_of_pos, P.bus_of_pos); UP(root_children, P.root_children); UP(root_y, P.root_y);
+  d.n_root_children = (int32_t)P.root_children.size();
   UP(load_ptr, P.load_ptr); UP(load_idx, P.load_idx); UP(sgen_ptr, P.sgen_ptr); UP(sgen_idx, P.sgen_idx);
   UP(shunt_p, P.shunt_p); UP(shunt_q, P.shunt_q); UP(lines, P.lines);
-#undef UP
   const size_t Bp = d.Bp;
 #define AL(field, rows) do { rc = dalloc(h, &d.field, (size_t)(rows) * Bp); if (rc) return rc; } while (0)
   AL(cur_pv, d.ns); AL(cur_q, d.ns); AL(q_new, d.ns); AL(cur_pl, d.nl); AL(cur_ql, d.nl);
   AL(vm, d.nb); AL(va, d.nb); AL(res_p, d.nb); AL(res_q, d.nb); AL(pb, d.nb); AL(qb, d.nb); AL(pl, d.n_line);
-  AL(line_loss, 1); AL(sum_rewards, 1); AL(steps, 1); AL(start_row, 1); AL(draw, 1); AL(done, 1); AL(pending, 1);
+  AL(sum_rewards, 1); AL(steps, 1); AL(start_row, 1); AL(draw, 1); AL(done, 1); AL(pending, 1);
   AL(active, 1); AL(adv_row, 1); AL(adv_draw, 1); AL(iters, 1); AL(conv, 1);
-  AL(Sr, d.n); AL(Si, d.n); AL(Ve, d.n + 1); AL(Vf, d.n + 1); AL(Vm, d.n + 1); AL(Va, d.n + 1);
-  AL(G, 4 * d.n); AL(H, 2 * d.n); AL(accS, 2 * d.n); AL(accD, 4 * d.n); AL(accR, 2 * d.n); AL(X, 2 * d.n);
-#undef AL
-  {  // root row of the trial-voltage arrays is constant: V_root = vroot + 0j
-    std::vector<double> row(Bp, d.vroot);
-    HIPCHK(h, hipMemcpy(d.Ve + (size_t)d.n * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(d.Vm + (size_t)d.n * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
+  {
     std::vector<uint8_t> ones(Bp, 1);
     HIPCHK(h, hipMemcpy(d.done, ones.data(), Bp, hipMemcpyHostToDevice));   // nothing is steppable before reset
   }
@@ -131,12 +138,49 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   for (int i = 0; i < maxn; ++i) io[i] = i;
   rc = dupload(h, &tmp, zk); if (rc) return rc; h->zero_kind = (int32_t*)tmp;
   rc = dupload(h, &tmp, io); if (rc) return rc; h->iota_idx = (int32_t*)tmp;
-  rc = dupload(h, &tmp, P.pos_of_bus); if (rc) return rc; h->pos_idx = (int32_t*)tmp;
   rc = dalloc(h, &h->t_pl, (size_t)d.nl * Bp); if (rc) return rc;
   rc = dalloc(h, &h->t_ql, (size_t)d.nl * Bp); if (rc) return rc;
   rc = dalloc(h, &h->t_pv, (size_t)d.ns * Bp); if (rc) return rc;
   rc = dalloc(h, &h->t_q, (size_t)d.ns * Bp); if (rc) return rc;
   rc = dalloc(h, &h->stats_dev, 4); if (rc) return rc;
+  // ---- NR launch geometry: W waves per env group x L envs per wave.  Small batches are spread
+  // over more wavefronts (idle SIMDs are free); big batches use full 64-env waves with one worker.
+  // Override with MAPDN_NR_WAVES / MAPDN_NR_LANES.
+  int W, L;
+  choose_nr_geometry(d.Bp, W, L);
+  if (const char* s = getenv("MAPDN_NR_WAVES")) W = atoi(s);
+  if (const char* s = getenv("MAPDN_NR_LANES")) L = atoi(s);
+  if (!(W == 1 || W == 2 || W == 4 || W == 8 || W == 16) || !(L == 64 || L == 32 || L == 16)) {
+    h->err = "MAPDN_NR_WAVES must be 1/2/4/8/16 and MAPDN_NR_LANES 64/32/16"; return MAPDN_E_INVALID; }
+  build_schedule(P, W, h->sched);
+  // LDS budget (160 KB per CU on gfx950): halve the envs per wave until the slots fit
+  while (L > 16 && nr_lds_bytes(W, L, h->sched.n_cslots, h->sched.n_xslots) > 160 * 1024) L /= 2;
+  if (nr_lds_bytes(W, L, h->sched.n_cslots, h->sched.n_xslots) > 160 * 1024) {
+    h->err = "NR schedule needs more LDS than one CU has; lower MAPDN_NR_WAVES"; return MAPDN_E_INVALID; }
+  d.nr_waves = W; d.nr_lanes = L;
+  d.nr_rows = h->sched.R; d.nr_cslots = h->sched.n_cslots; d.nr_xslots = h->sched.n_xslots;
+  if (nr_set_lds_limit(W, nr_lds_bytes(W, L, d.nr_cslots, d.nr_xslots)) != 0) {
+    h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return MAPDN_E_HIP; }
+  UP(sched, h->sched.steps); UP(clist, h->sched.clist);
+  {  // operand blocks: one per (wave,row) step + one for the slack bus; a single buffer resource addresses them
+    const int nblk = W * h->sched.R;
+    std::vector<int32_t> blk(P.n + 1, nblk);
+    for (int i = 0; i < nblk; ++i) { const int k = h->sched.steps[i].k; if (k >= 0) blk[k] = i; }
+    UP(blk_of_pos, blk);
+    const size_t rows = (size_t)(nblk + 1) * NRF, bytes = rows * Bp * sizeof(double);
+    if (bytes >= (size_t)0xFFFFFFFFu) { h->err = "env batch too large: NR scratch exceeds the 4 GiB one buffer resource addresses; use fewer envs per handle"; return MAPDN_E_INVALID; }
+    rc = dalloc(h, &d.nrbuf, rows * Bp); if (rc) return rc;
+    d.nrbuf_bytes = (uint32_t)bytes;
+    std::vector<double> row(Bp, d.vroot);   // slack block: V = vroot + 0j (va = 0 from the memset)
+    double* rootblk = d.nrbuf + (size_t)nblk * NRF * Bp;
+    HIPCHK(h, hipMemcpy(rootblk + (size_t)NF_EK * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(rootblk + (size_t)NF_VM * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<int32_t> vmrow(P.nb), varow(P.nb);
+    for (int b = 0; b < P.nb; ++b) { const int bi = blk[P.pos_of_bus[b]]; vmrow[b] = bi * NRF + NF_VM; varow[b] = bi * NRF + NF_VA; }
+    rc = dupload(h, &tmp, vmrow); if (rc) return rc; h->vm_row = (int32_t*)tmp;
+    rc = dupload(h, &tmp, varow); if (rc) return rc; h->va_row = (int32_t*)tmp;
+  }
+#undef UP
   return MAPDN_OK;
 }
 
@@ -248,7 +292,8 @@ int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, i
     launch_qnew(d, nullptr, MAPDN_F64, MODE_RESET, st);
     launch_sbus(d, d.cur_pl, d.cur_ql, d.cur_pv, d.q_new, st);
     nr_launch(h, st);
-    launch_commit_reward(d, MODE_RESET, add_noise, nullptr, nullptr, nullptr, st);
+    launch_commit(d, MODE_RESET, st);
+    launch_reward(d, MODE_RESET, nullptr, nullptr, nullptr, st);
   }
   HIPCHK(h, hipGetLastError());
   h->was_reset = true;
@@ -268,7 +313,8 @@ int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int3
   launch_qnew(d, actions, actions_dtype, MODE_STEP, st);
   launch_sbus(d, d.cur_pl, d.cur_ql, d.cur_pv, d.q_new, st);
   nr_launch(h, st);
-  launch_commit_reward(d, MODE_STEP, add_noise, reward, terminated, info, st);
+  launch_commit(d, MODE_STEP, st);
+  launch_reward(d, MODE_STEP, reward, terminated, info, st);
   launch_advance(d, add_noise, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
@@ -367,8 +413,8 @@ int mapdn_solve_only(mapdn_handle* h, const double* p_load, const double* q_load
   if (d.Bp > d.B) HIPCHK(h, hipMemsetAsync(d.active + d.B, 0, d.Bp - d.B, st));
   launch_sbus(d, h->t_pl, h->t_ql, h->t_pv, h->t_q, st);
   nr_launch(h, st);
-  if (vm_pu) transpose_out(h, d.Vm, 1.0, h->pos_idx, vm_pu, d.nb, st);
-  if (va_degree) transpose_out(h, d.Va, 180.0 / M_PI, h->pos_idx, va_degree, d.nb, st);
+  if (vm_pu) transpose_out(h, d.nrbuf, 1.0, h->vm_row, vm_pu, d.nb, st);
+  if (va_degree) transpose_out(h, d.nrbuf, 180.0 / M_PI, h->va_row, va_degree, d.nb, st);
   if (iterations) launch_copy_i32(d.iters, iterations, d.B, st);
   if (converged) launch_copy_u8(d.conv, converged, d.B, st);
   HIPCHK(h, hipGetLastError());
@@ -386,6 +432,16 @@ int mapdn_get_obs_index(const mapdn_handle* h, int32_t* kind, int32_t* index) {
   if (!h || !kind || !index) return MAPDN_E_INVALID;
   std::memcpy(kind, h->plan.obs_kind.data(), h->plan.obs_kind.size() * sizeof(int32_t));
   std::memcpy(index, h->plan.obs_idx.data(), h->plan.obs_idx.size() * sizeof(int32_t));
+  return MAPDN_OK;
+}
+
+int mapdn_get_schedule(const mapdn_handle* h, int32_t W, int32_t* n_rows, int32_t* rows, int32_t* parent) {
+  if (!h || !n_rows || W < 1 || W > 16) return MAPDN_E_INVALID;
+  Schedule S;
+  build_schedule(h->plan, W, S);
+  *n_rows = S.R;
+  if (rows) for (size_t i = 0; i < S.steps.size(); ++i) rows[i] = S.steps[i].k;
+  if (parent) std::memcpy(parent, h->plan.par.data(), h->plan.par.size() * sizeof(int32_t));
   return MAPDN_OK;
 }
 

@@ -1,12 +1,13 @@
 // kernels.hip — gfx950 (MI355X, CDNA4) kernels of the batched VoltageControl hot path.
 //
 // Mapping: ONE LANE == ONE ENV.  All per-env state is "env-minor" SoA, X[item][Bp] (Bp = B rounded
-// up to 64), so the 64 lanes of a wavefront touch 64 consecutive doubles (one 512-B coalesced
-// request) for every item they process.  Because all envs share the topology, the elimination
-// schedule, the Ybus entries and every index are wave-uniform: they are read through the scalar
-// cache (s_load) and all branches on them are scalar branches — no divergence, no LDS traffic and
-// no cross-lane exchange in the solve.  Cross-lane work is limited to the wave vote that ends the
-// Newton loop and to the LDS-tiled transposes between env-minor state and env-major I/O tensors.
+// up to 64), so the lanes of a wavefront touch consecutive doubles (one coalesced request) for
+// every item they process.  Because all envs share the topology, the elimination schedule, the Ybus
+// entries and every index are wave-uniform: they are read through the scalar cache and all branches
+// on them are scalar branches — no divergence.  Parallelism inside one env comes from W wavefronts
+// per env group that eliminate independent subtrees of the feeder concurrently and exchange the
+// few cross-subtree values through LDS slots; the LDS-tiled transposes convert between env-minor
+// state and env-major I/O tensors.
 //
 // What is computed follows pandapower 2.7.0's runpp (pypower newtonpf; reference call site
 // voltage_control_env.py:557) and MAPDN's VoltageControl methods cited at each kernel.
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(256) k_qnew(Dev d, const AT* __restrict__ acti
 // =================================================================================================
 // K1b  Sbus — pandapower build_bus._calc_pq_elements_and_add_on_ppc + makeSbus:
 //      Sbus[k] = -(sum load - sum sgen)/sn_mva, by element->bus CSR (no atomics).
-//      thread = (position k, env e); writes in elimination-position order for the NR kernel.
+//      thread = (position k, env e); writes into the NR operand block of node k.
 // =================================================================================================
 __global__ void __launch_bounds__(256)
 k_sbus(Dev d, const double* __restrict__ pl, const double* __restrict__ ql, const double* __restrict__ pv,
@@ -93,170 +94,363 @@ k_sbus(Dev d, const double* __restrict__ pl, const double* __restrict__ ql, cons
     const size_t o = (size_t)d.sgen_idx[i] * d.Bp + e;
     P -= pv[o]; Q -= q[o];
   }
-  const size_t o = (size_t)k * d.Bp + e;
-  d.Sr[o] = -P / d.sn;
-  d.Si[o] = -Q / d.sn;
+  double* blk = d.nrbuf + (size_t)d.blk_of_pos[k] * NRF * d.Bp + e;
+  blk[(size_t)NF_SR * d.Bp] = -P / d.sn;
+  blk[(size_t)NF_SI * d.Bp] = -Q / d.sn;
 }
 
 // =================================================================================================
 // K2-K5  Newton-Raphson power flow — pandapower/pypower/newtonpf.py (flat start, polar form, full
 //        Jacobian every iteration, ||F||inf < tol, <= 10 iterations), for a radial feeder.
 //
-//  One wavefront = 64 envs; each lane runs the complete solve of its env.  Per iteration:
-//   forward sweep over nodes in leaf->root order (parents after children), fusing
+//  Lane = env.  Per iteration:
+//   forward sweep over the feeder tree in leaf->root order, fusing
 //     * I = Ybus V and the mismatch F = V conj(I) - Sbus            (dSbus_dV / _evaluate_Fx)
 //     * the four Jacobian entries of every Ybus non-zero              (create_jacobian_matrix)
 //     * block-2x2 Gaussian elimination J y = F without fill          (replaces SuperLU spsolve)
 //   then, unless converged, a backward sweep (root->leaf) that back-substitutes and applies
-//   Va -= y_theta, Vm -= y_V, V = Vm e^{jVa} with the abs/angle re-normalisation of newtonpf.
-//  Children send S / Schur contributions to their parent through registers when the parent is the
-//  next node of the schedule (feeder chains) and through per-env scratch at junctions.
+//   Va += dx_a, Vm += dx_m, V = Vm e^{jVa} with the abs/angle re-normalisation of newtonpf.
+//
+//  Parallelism inside one env: the W wavefronts of a workgroup share the same L envs and follow a
+//  host-built Hu schedule (plan.cpp::build_schedule): in every row each wave eliminates one node of
+//  an independent subtree (or idles), so the critical path per sweep is ~tree depth instead of n.
+//  A wave may use only its first L lanes (64/32/16) so that small batches still cover many CUs.
+//
+//  Data movement:
+//   * every (wave,row) step owns one OPERAND BLOCK in global scratch, [ek fk ep fp sr si va vm h0 h1
+//     G0..G3][Bp] — own voltage, PARENT's voltage, Sbus, LU factors — addressed as
+//     block(w,r) + field through one buffer resource (scalar base, loop-invariant lane+field VGPR
+//     offsets).  Addresses of step r+1 depend on nothing loaded in step r, so its operands are
+//     prefetched while step r computes; blocks are private to their wave: no global ordering needed.
+//   * everything that crosses waves goes through LDS slots [slot][item][lane] allocated by the host
+//     with interval colouring: a child's S/Schur contribution to its parent (forward), and the
+//     parent's x AND new voltage pushed to its children (backward; the child stores it as ep/fp of
+//     its own block for the next forward sweep).  Values stay in registers instead when the same
+//     wave handles the parent in the adjacent row.  Rows are separated by an LDS-only barrier
+//     (s_waitcnt lgkmcnt(0); s_barrier): global loads/stores stay in flight across rows.
+//   * step constants (Y entries, flags, slot ids) are one 80-byte record, prefetched a row ahead.
+//  The linear system is solved for z = [dtheta ; d|V|/|V|] (|V| columns scaled by |V_k|): the
+//  entries are j(S - A_kk), S + A_kk on the diagonal and -jA_ik, A_ik off it — no division by |V|;
+//  1/det uses v_rcp_f64 + two Newton steps; the update rotates V by the small step angle
+//  (polynomial sin/cos, full sincos only when a lane diverges).  Children are summed in a canonical
+//  order, so results are bit-identical for every W and L.
 // =================================================================================================
-__global__ void __launch_bounds__(64) k_nr_tree(Dev d) {
-  const int e = blockIdx.x * 64 + threadIdx.x;
-  const size_t S = (size_t)d.Bp;
-  const int n = d.n;
+struct FwdOps { double ek, fk, ep, fp, sr, si; };
+struct BwdOps { double h0, h1, g0, g1, g2, g3, e, f, va, vm; };
+
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// 1/x from v_rcp_f64 + two Newton steps (<= 1-2 ulp; operands are well-scaled 2x2 determinants)
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double t = fma(-x, r, 1.0);
+  r = fma(r, t, r);
+  t = fma(-x, r, 1.0);
+  return fma(r, t, r);
+}
+
+// cos/sin of a Newton angle step |x| <= 0.5: Taylor to x^16 / x^17 (remainder < 2e-23)
+__device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
+  const double z = x * x;
+  double ps = 1.0 / 355687428096000.0;                         // 1/17!
+  ps = fma(ps, z, -1.0 / 1307674368000.0);                     // -1/15!
+  ps = fma(ps, z, 1.0 / 6227020800.0);                         // 1/13!
+  ps = fma(ps, z, -1.0 / 39916800.0);                          // -1/11!
+  ps = fma(ps, z, 1.0 / 362880.0);                             // 1/9!
+  ps = fma(ps, z, -1.0 / 5040.0);                              // -1/7!
+  ps = fma(ps, z, 1.0 / 120.0);                                // 1/5!
+  ps = fma(ps, z, -1.0 / 6.0);                                 // -1/3!
+  *s = fma(ps * z, x, x);
+  double pc = 1.0 / 20922789888000.0;                          // 1/16!
+  pc = fma(pc, z, -1.0 / 87178291200.0);                       // -1/14!
+  pc = fma(pc, z, 1.0 / 479001600.0);                          // 1/12!
+  pc = fma(pc, z, -1.0 / 3628800.0);                           // -1/10!
+  pc = fma(pc, z, 1.0 / 40320.0);                              // 1/8!
+  pc = fma(pc, z, -1.0 / 720.0);                               // -1/6!
+  pc = fma(pc, z, 1.0 / 24.0);                                 // 1/4!
+  pc = fma(pc, z, -0.5);                                       // -1/2!
+  *c = fma(pc, z, 1.0);
+}
+
+// buffer_load_dwordx2 v, v_lane_field, s[rsrc], s_block offen : zero VALU address math
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bst(double x, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, voff, soff, 0);
+}
+
+template <int W>
+__global__ void __launch_bounds__(64 * W) k_nr_wtree(Dev d) {
+  extern __shared__ double lds[];
+  const unsigned lane = threadIdx.x & 63u;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned L = (unsigned)d.nr_lanes;
+  if (lane >= L) return;                         // the wave keeps running (and hitting barriers) with exec = L lanes
+  const unsigned e = blockIdx.x * L + lane;
+  const int R = d.nr_rows;
   const double vroot = d.vroot, tol = d.tol;
-  const int32_t* __restrict__ par = d.par;
-  const uint32_t* __restrict__ flags = d.flags;
-  const double* __restrict__ yc = d.yc;
-  const double* __restrict__ Sr = d.Sr + e;
-  const double* __restrict__ Si = d.Si + e;
-  double* __restrict__ Ve = d.Ve + e;
-  double* __restrict__ Vf = d.Vf + e;
-  double* __restrict__ Vm = d.Vm + e;
-  double* __restrict__ Va = d.Va + e;
-  double* __restrict__ G = d.G + e;        // [4n]
-  double* __restrict__ H = d.H + e;        // [2n]
-  double* __restrict__ AS = d.accS + e;    // [2n]
-  double* __restrict__ AD = d.accD + e;    // [4n]
-  double* __restrict__ AR = d.accR + e;    // [2n]
-  double* __restrict__ X = d.X + e;        // [2n]
+  // schedule data through the CONSTANT address space: wave-uniform s_load (scalar cache), never
+  // vector memory — so record fetches neither occupy vmcnt nor serialise with the operand loads
+  typedef const __attribute__((address_space(4))) StepRec* crec_t;
+  typedef const __attribute__((address_space(4))) int32_t* cint_t;
+  const crec_t seq_c = (crec_t)(unsigned long long)(d.sched + (size_t)w * R);
+  const cint_t clist = (cint_t)(unsigned long long)d.clist;
+  auto rec = [&](int r) {                        // field-wise copy out of the constant address space
+    StepRec T;
+    T.ykk[0] = seq_c[r].ykk[0]; T.ykk[1] = seq_c[r].ykk[1]; T.ykp[0] = seq_c[r].ykp[0]; T.ykp[1] = seq_c[r].ykp[1];
+    T.ypk[0] = seq_c[r].ypk[0]; T.ypk[1] = seq_c[r].ypk[1];
+    T.k = seq_c[r].k; T.p = 0; T.flags = seq_c[r].flags; T.cptr = seq_c[r].cptr;
+    T.oslot = seq_c[r].oslot; T.xslot = seq_c[r].xslot; T.pxslot = seq_c[r].pxslot; T.pad = 0;
+    return T;
+  };
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d.nrbuf, 0, d.nrbuf_bytes, 0x00020000);
+  const unsigned rb = (unsigned)d.Bp * 8u;       // bytes per row
+  const unsigned bb = (unsigned)NRF * rb;        // bytes per operand block
+  const unsigned sb0 = (unsigned)(w * R) * bb;   // this wave's first block
+  unsigned vo[NRF];                              // lane + field offsets (loop-invariant VGPRs)
+#pragma unroll
+  for (int f = 0; f < NRF; ++f) vo[f] = e * 8u + (unsigned)f * rb;
+  double* cs = lds + lane;                                  // contribution slots: cs[(slot*8 + item)*L]
+  double* xs = lds + (size_t)d.nr_cslots * 8 * L + lane;    // x/V slots:          xs[(slot*4 + item)*L]
+  uint8_t* s_ok = (uint8_t*)(lds + ((size_t)d.nr_cslots * 8 + (size_t)d.nr_xslots * 4) * L);   // [W][64]
 
   bool done = d.active[e] == 0;
   bool conv = false;
   int it = 0;
-  if (__all(done)) {   // nothing to solve in this wavefront (e.g. reset retry with no pending env)
-    d.iters[e] = 0; d.conv[e] = 0;
+  if (__all(done)) {                             // identical in all W waves of the group
+    if (w == 0) { d.iters[e] = 0; d.conv[e] = 0; }
     return;
   }
-
-  // flat start: every bus at the ext_grid set-point, angle 0 (runpp init="auto")
-  for (int k = 0; k < n; ++k) {
-    Ve[k * S] = vroot; Vf[k * S] = 0.0; Vm[k * S] = vroot; Va[k * S] = 0.0;
+  for (int r = 0; r < R; ++r) {                  // flat start (runpp init="auto"): every bus at the slack set-point
+    if (seq_c[r].k < 0) continue;
+    const unsigned sb = sb0 + (unsigned)r * bb;
+    bst(vroot, rs, vo[NF_EK], sb); bst(0.0, rs, vo[NF_FK], sb); bst(vroot, rs, vo[NF_EP], sb); bst(0.0, rs, vo[NF_FP], sb);
+    bst(0.0, rs, vo[NF_VA], sb); bst(vroot, rs, vo[NF_VM], sb);
   }
+
+  bool allok;
+  double cS0, cS1, cD0, cD1, cD2, cD3, cR0, cR1;   // register carry child -> parent (same wave, next row)
+  double x0, x1, xe, xf;                           // register carry parent -> child in the backward sweep
+
+  // operand loads are unconditional (idle steps own a dummy block): they depend on nothing but r
+  auto load_fwd = [&](unsigned sb, FwdOps& o) {
+    o.ek = bld(rs, vo[NF_EK], sb); o.fk = bld(rs, vo[NF_FK], sb); o.ep = bld(rs, vo[NF_EP], sb); o.fp = bld(rs, vo[NF_FP], sb);
+    o.sr = bld(rs, vo[NF_SR], sb); o.si = bld(rs, vo[NF_SI], sb);
+  };
+  auto load_bwd = [&](unsigned sb, BwdOps& o) {
+    o.h0 = bld(rs, vo[NF_H0], sb); o.h1 = bld(rs, vo[NF_H1], sb);
+    o.g0 = bld(rs, vo[NF_G0], sb); o.g1 = bld(rs, vo[NF_G1], sb); o.g2 = bld(rs, vo[NF_G2], sb); o.g3 = bld(rs, vo[NF_G3], sb);
+    o.e = bld(rs, vo[NF_EK], sb); o.f = bld(rs, vo[NF_FK], sb); o.va = bld(rs, vo[NF_VA], sb); o.vm = bld(rs, vo[NF_VM], sb);
+  };
+
+  auto fwd_step = [&](const StepRec& T, unsigned sb, const FwdOps& o) {
+    if (T.k < 0) return;
+    const uint32_t fl = T.flags;
+    const double gkk = T.ykk[0], bkk = T.ykk[1], gkp = T.ykp[0], bkp = T.ykp[1], gpk = T.ypk[0], bpk = T.ypk[1];
+    const double ek = o.ek, fk = o.fk, ep = o.ep, fp = o.fp;
+    // A_kp = V_k conj(Y_kp V_p),  A_pk = V_p conj(Y_pk V_k),  A_kk = |V_k|^2 conj(Y_kk)
+    const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
+    const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
+    const double ur = gpk * ek - bpk * fk, ui = gpk * fk + bpk * ek;
+    const double apk_r = ep * ur + fp * ui, apk_i = fp * ur - ep * ui;
+    const double v2 = ek * ek + fk * fk;
+    const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
+    double aS0 = 0, aS1 = 0, aD0 = 0, aD1 = 0, aD2 = 0, aD3 = 0, aR0 = 0, aR1 = 0;
+    if (fl & S_CARRY_IN) { aS0 = cS0; aS1 = cS1; aD0 = cD0; aD1 = cD1; aD2 = cD2; aD3 = cD3; aR0 = cR0; aR1 = cR1; }
+    const int nch = (int)(fl >> 16);
+    for (int j = 0; j < nch; ++j) {
+      const double* c = cs + (size_t)clist[T.cptr + j] * 8 * L;
+      aS0 += c[0]; aS1 += c[L]; aD0 += c[2 * L]; aD1 += c[3 * L]; aD2 += c[4 * L]; aD3 += c[5 * L];
+      aR0 += c[6 * L]; aR1 += c[7 * L];
+    }
+    // S_k = V_k conj(sum_j Y_kj V_j), mismatch F_k = S_k - Sbus_k
+    const double sr = akk_r + akp_r + aS0, si = akk_i + akp_i + aS1;
+    const double Fp = sr - o.sr, Fq = si - o.si;
+    allok = allok && (fabs(Fp) < tol) && (fabs(Fq) < tol);
+    const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) - aD1;
+    const double D2 = (sr - akk_r) - aD2, D3 = (si + akk_i) - aD3;
+    const double r0 = Fp - aR0, r1 = Fq - aR1;
+    const double idet = rcp_nr(D0 * D3 - D1 * D2);
+    const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
+    const double h0 = I0 * r0 + I1 * r1, h1 = I2 * r0 + I3 * r1;
+    bst(h0, rs, vo[NF_H0], sb); bst(h1, rs, vo[NF_H1], sb);
+    if (!(fl & S_PARENT_ROOT)) {
+      // U = J'(k,p) = [[Im A_kp, Re A_kp], [-Re A_kp, Im A_kp]],  L = J'(p,k) likewise from A_pk
+      const double G0 = I0 * akp_i - I1 * akp_r, G1 = I0 * akp_r + I1 * akp_i;
+      const double G2 = I2 * akp_i - I3 * akp_r, G3 = I2 * akp_r + I3 * akp_i;
+      bst(G0, rs, vo[NF_G0], sb); bst(G1, rs, vo[NF_G1], sb); bst(G2, rs, vo[NF_G2], sb); bst(G3, rs, vo[NF_G3], sb);
+      const double s0 = apk_i * G0 + apk_r * G2, s1 = apk_i * G1 + apk_r * G3;
+      const double s2 = apk_i * G2 - apk_r * G0, s3 = apk_i * G3 - apk_r * G1;
+      const double t0 = apk_i * h0 + apk_r * h1, t1 = apk_i * h1 - apk_r * h0;
+      if (fl & S_CARRY_OUT) {
+        cS0 = apk_r; cS1 = apk_i; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
+      } else {
+        double* c = cs + (size_t)T.oslot * 8 * L;
+        c[0] = apk_r; c[L] = apk_i; c[2 * L] = s0; c[3 * L] = s1; c[4 * L] = s2; c[5 * L] = s3; c[6 * L] = t0; c[7 * L] = t1;
+      }
+    }
+  };
+  auto bwd_step = [&](const StepRec& T, unsigned sb, const BwdOps& o) {
+    if (T.k < 0) return;
+    const uint32_t fl = T.flags;
+    double y0 = o.h0, y1 = o.h1, pe = 0.0, pf = 0.0;
+    if (!(fl & S_PARENT_ROOT)) {
+      double p0, p1;
+      if (fl & S_CARRY_OUT) { p0 = x0; p1 = x1; pe = xe; pf = xf; }
+      else { const double* xp = xs + (size_t)T.pxslot * 4 * L; p0 = xp[0]; p1 = xp[L]; pe = xp[2 * L]; pf = xp[3 * L]; }
+      y0 -= o.g0 * p0 + o.g1 * p1;
+      y1 -= o.g2 * p0 + o.g3 * p1;
+    }
+    // newtonpf update: Va += dx_a, Vm += dx_m, V = Vm e^{jVa}, Vm = |V|, Va = angle(V), with
+    // dx_a = -y0, dx_m = -|V| y1  =>  V <- V (1 - y1) e^{-j y0}   (rotation by the small step)
+    double s, c;
+    const double dth = -y0;
+    if (__any(!(fabs(dth) <= 0.5))) sincos(dth, &s, &c);       // wave-uniform, only when diverging
+    else sincos_small(dth, &s, &c);
+    const double sc = 1.0 - y1;
+    const double en = sc * (o.e * c - o.f * s), fn = sc * (o.e * s + o.f * c);
+    x0 = y0; x1 = y1; xe = en; xf = fn;
+    if (fl & S_X_OUT) { double* xo = xs + (size_t)T.xslot * 4 * L; xo[0] = y0; xo[L] = y1; xo[2 * L] = en; xo[3 * L] = fn; }
+    double va = o.va + dth;
+    double vm = o.vm * sc;
+    if (vm < 0.0) { vm = -vm; va += M_PI; }
+    if (va > M_PI) va -= 2.0 * M_PI;
+    else if (va <= -M_PI) va += 2.0 * M_PI;
+    if (!done) {
+      bst(va, rs, vo[NF_VA], sb); bst(vm, rs, vo[NF_VM], sb); bst(en, rs, vo[NF_EK], sb); bst(fn, rs, vo[NF_FK], sb);
+      if (!(fl & S_PARENT_ROOT)) { bst(pe, rs, vo[NF_EP], sb); bst(pf, rs, vo[NF_FP], sb); }
+    }
+  };
 
   for (;;) {
     // ------------------------------------------------------------------ forward sweep
-    bool allok = true;
-    double cS0 = 0, cS1 = 0, cD0 = 0, cD1 = 0, cD2 = 0, cD3 = 0, cR0 = 0, cR1 = 0;  // register carry
-    double ne = Ve[0], nf = Vf[0], nvm = Vm[0];                                       // own V of node k
-    for (int k = 0; k < n; ++k) {
-      const uint32_t fl = flags[k];
-      const int p = par[k];
-      const double gkk = yc[6 * k + 0], bkk = yc[6 * k + 1], gkp = yc[6 * k + 2], bkp = yc[6 * k + 3],
-                   gpk = yc[6 * k + 4], bpk = yc[6 * k + 5];
-      const double ek = ne, fk = nf, vmk = nvm;
-      double ep, fp, vmp;
-      if (fl & F_PARENT_ROOT) { ep = vroot; fp = 0.0; vmp = vroot; }
-      else { ep = Ve[p * S]; fp = Vf[p * S]; vmp = Vm[p * S]; }
-      if (k + 1 < n) {
-        if (fl & F_PARENT_NEXT) { ne = ep; nf = fp; nvm = vmp; }
-        else { ne = Ve[(k + 1) * S]; nf = Vf[(k + 1) * S]; nvm = Vm[(k + 1) * S]; }
+    // rows are processed in pairs with ping-pong operand sets (A/B): the loads of row r+1 are in
+    // flight while row r computes, without register copies.
+    allok = true;
+    cS0 = cS1 = cD0 = cD1 = cD2 = cD3 = cR0 = cR1 = 0.0;
+    {
+      StepRec TA = rec(0), TB;
+      FwdOps oA = {}, oB = {};
+      unsigned sb = sb0;
+      load_fwd(sb, oA);
+      int r = 0;
+      for (; r + 1 < R; r += 2) {
+        TB = rec(r + 1); load_fwd(sb + bb, oB);
+        fwd_step(TA, sb, oA);
+        if (W > 1) lds_barrier();
+        if (r + 2 < R) { TA = rec(r + 2); load_fwd(sb + 2 * bb, oA); }
+        fwd_step(TB, sb + bb, oB);
+        if (W > 1) lds_barrier();
+        sb += 2 * bb;
       }
-      // A_kp = V_k conj(Y_kp V_p),  A_pk = V_p conj(Y_pk V_k),  A_kk = |V_k|^2 conj(Y_kk)
-      const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
-      const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
-      const double ur = gpk * ek - bpk * fk, ui = gpk * fk + bpk * ek;
-      const double apk_r = ep * ur + fp * ui, apk_i = fp * ur - ep * ui;
-      const double v2 = ek * ek + fk * fk;
-      const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
-      // contributions of the children
-      double aS0 = 0, aS1 = 0, aD0 = 0, aD1 = 0, aD2 = 0, aD3 = 0, aR0 = 0, aR1 = 0;
-      if (fl & F_SCRATCH_IN) {
-        aS0 = AS[(2 * k) * S]; aS1 = AS[(2 * k + 1) * S];
-        aD0 = AD[(4 * k) * S]; aD1 = AD[(4 * k + 1) * S]; aD2 = AD[(4 * k + 2) * S]; aD3 = AD[(4 * k + 3) * S];
-        aR0 = AR[(2 * k) * S]; aR1 = AR[(2 * k + 1) * S];
-      }
-      if (fl & F_CARRY_IN) {
-        aS0 += cS0; aS1 += cS1; aD0 += cD0; aD1 += cD1; aD2 += cD2; aD3 += cD3; aR0 += cR0; aR1 += cR1;
-      }
-      // S_k = V_k conj(sum_j Y_kj V_j) and the mismatch F_k = S_k - Sbus_k
-      const double sr = akk_r + akp_r + aS0, si = akk_i + akp_i + aS1;
-      const double Fp = sr - Sr[k * S], Fq = si - Si[k * S];
-      allok = allok && (fabs(Fp) < tol) && (fabs(Fq) < tol);
-      // diagonal Jacobian block: dS/dVa = j(S - A_kk); dS/dVm = (S + A_kk)/|V_k|
-      const double ivm = 1.0 / vmk;
-      const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) * ivm - aD1;
-      const double D2 = (sr - akk_r) - aD2, D3 = (si + akk_i) * ivm - aD3;
-      const double r0 = Fp - aR0, r1 = Fq - aR1;
-      const double idet = 1.0 / (D0 * D3 - D1 * D2);
-      const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
-      const double h0 = I0 * r0 + I1 * r1, h1 = I2 * r0 + I3 * r1;
-      H[(2 * k) * S] = h0; H[(2 * k + 1) * S] = h1;
-      if (!(fl & F_PARENT_ROOT)) {
-        // off-diagonal blocks: U = J(k,p) from A_kp, L = J(p,k) from A_pk
-        const double ivmp = 1.0 / vmp;
-        const double U0 = akp_i, U1 = akp_r * ivmp, U2 = -akp_r, U3 = akp_i * ivmp;
-        const double G0 = I0 * U0 + I1 * U2, G1 = I0 * U1 + I1 * U3, G2 = I2 * U0 + I3 * U2, G3 = I2 * U1 + I3 * U3;
-        G[(4 * k) * S] = G0; G[(4 * k + 1) * S] = G1; G[(4 * k + 2) * S] = G2; G[(4 * k + 3) * S] = G3;
-        const double L0 = apk_i, L1 = apk_r * ivm, L2 = -apk_r, L3 = apk_i * ivm;
-        const double s0 = L0 * G0 + L1 * G2, s1 = L0 * G1 + L1 * G3, s2 = L2 * G0 + L3 * G2, s3 = L2 * G1 + L3 * G3;
-        const double t0 = L0 * h0 + L1 * h1, t1 = L2 * h0 + L3 * h1;
-        if (fl & F_PARENT_NEXT) {
-          cS0 = apk_r; cS1 = apk_i; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
-        } else if (fl & F_SCRATCH_FIRST) {
-          AS[(2 * p) * S] = apk_r; AS[(2 * p + 1) * S] = apk_i;
-          AD[(4 * p) * S] = s0; AD[(4 * p + 1) * S] = s1; AD[(4 * p + 2) * S] = s2; AD[(4 * p + 3) * S] = s3;
-          AR[(2 * p) * S] = t0; AR[(2 * p + 1) * S] = t1;
-        } else {
-          AS[(2 * p) * S] += apk_r; AS[(2 * p + 1) * S] += apk_i;
-          AD[(4 * p) * S] += s0; AD[(4 * p + 1) * S] += s1; AD[(4 * p + 2) * S] += s2; AD[(4 * p + 3) * S] += s3;
-          AR[(2 * p) * S] += t0; AR[(2 * p + 1) * S] += t1;
-        }
-      }
+      if (r < R) { fwd_step(TA, sb, oA); if (W > 1) lds_barrier(); }
+    }
+    if (W > 1) {                                 // AND of the per-wave verdicts, per env
+      s_ok[w * 64 + lane] = allok ? 1 : 0;
+      lds_barrier();
+#pragma unroll
+      for (int ww = 0; ww < W; ++ww) allok = allok && (s_ok[ww * 64 + lane] != 0);
     }
     if (!done) {
       conv = allok;
       if (conv || it == d.max_it) done = true;
     }
-    if (__all(done)) break;   // wave vote: the only cross-lane operation of the solve
+    if (__all(done)) break;                      // same lanes, same values in every wave of the group
     // ------------------------------------------------------------------ backward sweep + update
-    double x0 = 0, x1 = 0;
-    for (int k = n - 1; k >= 0; --k) {
-      const uint32_t fl = flags[k];
-      double y0 = H[(2 * k) * S], y1 = H[(2 * k + 1) * S];
-      if (!(fl & F_PARENT_ROOT)) {
-        double p0, p1;
-        if (fl & F_PARENT_NEXT) { p0 = x0; p1 = x1; }
-        else { const int p = par[k]; p0 = X[(2 * p) * S]; p1 = X[(2 * p + 1) * S]; }
-        y0 -= G[(4 * k) * S] * p0 + G[(4 * k + 1) * S] * p1;
-        y1 -= G[(4 * k + 2) * S] * p0 + G[(4 * k + 3) * S] * p1;
+    x0 = x1 = xe = xf = 0.0;
+    {
+      StepRec TA = rec(R - 1), TB;
+      BwdOps oA = {}, oB = {};
+      unsigned sb = sb0 + (unsigned)(R - 1) * bb;
+      load_bwd(sb, oA);
+      int r = R - 1;
+      for (; r - 1 >= 0; r -= 2) {
+        TB = rec(r - 1); load_bwd(sb - bb, oB);
+        bwd_step(TA, sb, oA);
+        if (W > 1) lds_barrier();
+        if (r - 2 >= 0) { TA = rec(r - 2); load_bwd(sb - 2 * bb, oA); }
+        bwd_step(TB, sb - bb, oB);
+        if (W > 1) lds_barrier();
+        sb -= 2 * bb;
       }
-      x0 = y0; x1 = y1;
-      if (fl & F_SCRATCH_IN) { X[(2 * k) * S] = y0; X[(2 * k + 1) * S] = y1; }
-      if (!done) {
-        // dx = -J^-1 F ; Va += dx_a ; Vm += dx_m ; V = Vm e^{jVa} ; Vm = |V| ; Va = angle(V)
-        double va = Va[k * S] - y0;
-        double vm = Vm[k * S] - y1;
-        if (vm < 0.0) { vm = -vm; va += M_PI; }
-        if (va > M_PI) va -= 2.0 * M_PI;
-        else if (va <= -M_PI) va += 2.0 * M_PI;
-        double s, c;
-        sincos(va, &s, &c);
-        Va[k * S] = va; Vm[k * S] = vm; Ve[k * S] = vm * c; Vf[k * S] = vm * s;
-      }
+      if (r >= 0) { bwd_step(TA, sb, oA); if (W > 1) lds_barrier(); }
     }
     if (!done) ++it;
   }
-  d.iters[e] = it;
-  d.conv[e] = conv ? 1 : 0;
+  if (w == 0) { d.iters[e] = it; d.conv[e] = conv ? 1 : 0; }
 }
 
 // =================================================================================================
-// K6/K7  results + reward — pandapower pfsoln/_extract_results (res_bus, res_line) and
-//        VoltageControl._calc_reward (voltage_control_env.py:574-623), step() bookkeeping
-//        (:185-209) including the unsolvable branch (:188-196).  thread = env.
+// K6  commit — pandapower pfsoln/_extract_results: res_bus (vm_pu, va, p_mw, q_mvar incl. the slack
+//     injection), res_line.pl_mw, sgen.q_mvar, for envs whose solve converged.  Fully parallel:
+//     thread = (item, env) with item in [buses | lines | sgens].  Does not touch done/pending.
+// =================================================================================================
+__device__ __forceinline__ bool commit_cond(const Dev& d, int mode, int e) {
+  if (!d.conv[e]) return false;
+  return mode == MODE_STEP ? (d.done[e] == 0) : (d.pending[e] != 0);
+}
+
+__global__ void __launch_bounds__(256) k_commit(Dev d, int mode) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.B) return;
+  if (!commit_cond(d, mode, e)) return;
+  const size_t S = (size_t)d.Bp;
+  int y = blockIdx.y;
+  if (y < d.nb) {                                           // ---- bus at elimination position k (k == n: slack)
+    const int k = y, bus = d.bus_of_pos[k];
+    const double* blk = d.nrbuf + (size_t)d.blk_of_pos[k] * NRF * S + e;
+    const double vm = blk[(size_t)NF_VM * S], va = blk[(size_t)NF_VA * S];
+    d.vm[(size_t)bus * S + e] = vm;
+    d.va[(size_t)bus * S + e] = va;
+    double P = 0.0, Q = 0.0;
+    if (k < d.n) {
+      for (int i = d.load_ptr[k]; i < d.load_ptr[k + 1]; ++i) { const size_t o = (size_t)d.load_idx[i] * S + e; P += d.cur_pl[o]; Q += d.cur_ql[o]; }
+      for (int i = d.sgen_ptr[k]; i < d.sgen_ptr[k + 1]; ++i) { const size_t o = (size_t)d.sgen_idx[i] * S + e; P -= d.cur_pv[o]; Q -= d.q_new[o]; }
+    } else {
+      // slack: res_bus = -(V conj(I)) * sn, I = Y_rr V_r + sum_children Y_rk V_k   (consumer sign)
+      double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;
+      for (int j = 0; j < d.n_root_children; ++j) {
+        const double* cb = d.nrbuf + (size_t)d.blk_of_pos[d.root_children[j]] * NRF * S + e;
+        const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ek = cb[(size_t)NF_EK * S], fk = cb[(size_t)NF_FK * S];
+        ir += g * ek - b * fk; ii += g * fk + b * ek;
+      }
+      P = -(d.vroot * ir) * d.sn; Q = (d.vroot * ii) * d.sn;
+    }
+    P += d.shunt_p[k] * vm * vm; Q += d.shunt_q[k] * vm * vm;
+    d.res_p[(size_t)bus * S + e] = P; d.res_q[(size_t)bus * S + e] = Q;
+    return;
+  }
+  y -= d.nb;
+  if (y < d.n_line) {                                       // ---- res_line.pl_mw = Re(Sf + St) * sn
+    const LineFlow Ln = d.lines[y];
+    double pl = 0.0;
+    if (Ln.fpos >= 0) {
+      const double* fb = d.nrbuf + (size_t)d.blk_of_pos[Ln.fpos] * NRF * S + e;
+      const double* tb = d.nrbuf + (size_t)d.blk_of_pos[Ln.tpos] * NRF * S + e;
+      const double ef = fb[(size_t)NF_EK * S], ff = fb[(size_t)NF_FK * S], et = tb[(size_t)NF_EK * S], ft = tb[(size_t)NF_FK * S];
+      const double ifr = Ln.yff[0] * ef - Ln.yff[1] * ff + Ln.yft[0] * et - Ln.yft[1] * ft;
+      const double ifi = Ln.yff[0] * ff + Ln.yff[1] * ef + Ln.yft[0] * ft + Ln.yft[1] * et;
+      const double itr = Ln.ytf[0] * ef - Ln.ytf[1] * ff + Ln.ytt[0] * et - Ln.ytt[1] * ft;
+      const double iti = Ln.ytf[0] * ff + Ln.ytf[1] * ef + Ln.ytt[0] * ft + Ln.ytt[1] * et;
+      pl = ((ef * ifr + ff * ifi) + (et * itr + ft * iti)) * d.sn;
+    }
+    d.pl[(size_t)y * S + e] = pl;
+    return;
+  }
+  y -= d.n_line;
+  d.cur_q[(size_t)y * S + e] = d.q_new[(size_t)y * S + e];   // ---- sgen.q_mvar of the accepted solve
+}
+
+// =================================================================================================
+// K7  reward — VoltageControl._calc_reward (voltage_control_env.py:574-623) on the committed (or,
+//     if the solve failed, rolled-back == previous) state, the unsolvable branch (:188-196) and
+//     step() bookkeeping (:199-209).  thread = env; the loops are independent coalesced loads.
 // =================================================================================================
 __device__ __forceinline__ double barrier(int type, double v) {
   switch (type) {
@@ -282,78 +476,25 @@ __device__ __forceinline__ double barrier(int type, double v) {
 }
 
 __global__ void __launch_bounds__(64)
-k_commit_reward(Dev d, int mode, int add_noise, double* __restrict__ reward, uint8_t* __restrict__ terminated,
-                double* __restrict__ info) {
+k_reward(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ terminated, double* __restrict__ info) {
   const int e = blockIdx.x * 64 + threadIdx.x;
   if (e >= d.B) return;
   const size_t S = (size_t)d.Bp;
   d.adv_row[e] = -1;
-  if (mode == MODE_STEP && d.done[e]) {           // frozen env
+  if (mode == MODE_RESET) {
+    if (d.pending[e] && d.conv[e]) { d.pending[e] = 0; d.done[e] = 0; }
+    return;
+  }
+  if (d.done[e]) {                                 // frozen env
     reward[e] = 0.0; terminated[e] = 1;
     for (int c = 0; c < MAPDN_N_INFO; ++c) info[(size_t)e * MAPDN_N_INFO + c] = 0.0;
     return;
   }
-  if (mode == MODE_RESET && !d.pending[e]) return;
   const bool ok = d.conv[e] != 0;
-  double q_fail = 0.0;
-  if (ok) {
-    // ---- commit res_bus (vm_pu, va, p_mw, q_mvar), slack injection, res_line.pl_mw, sgen.q_mvar
-    const double* Ve = d.Ve + e; const double* Vf = d.Vf + e; const double* Vm = d.Vm + e; const double* Va = d.Va + e;
-    double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;    // I_root = sum_j Y_rj V_j  (V_root = vroot + 0j)
-    for (int k = 0; k < d.n; ++k) {
-      const int bus = d.bus_of_pos[k];
-      const double vm = Vm[k * S];
-      d.vm[(size_t)bus * S + e] = vm;
-      d.va[(size_t)bus * S + e] = Va[k * S];
-      double P = 0.0, Q = 0.0;
-      for (int i = d.load_ptr[k]; i < d.load_ptr[k + 1]; ++i) { const size_t o = (size_t)d.load_idx[i] * S + e; P += d.cur_pl[o]; Q += d.cur_ql[o]; }
-      for (int i = d.sgen_ptr[k]; i < d.sgen_ptr[k + 1]; ++i) { const size_t o = (size_t)d.sgen_idx[i] * S + e; P -= d.cur_pv[o]; Q -= d.q_new[o]; }
-      P += d.shunt_p[k] * vm * vm; Q += d.shunt_q[k] * vm * vm;
-      d.res_p[(size_t)bus * S + e] = P; d.res_q[(size_t)bus * S + e] = Q;
-      if (d.flags[k] & F_PARENT_ROOT) {
-        const double g = d.yc[6 * k + 4], b = d.yc[6 * k + 5], ek = Ve[k * S], fk = Vf[k * S];
-        ir += g * ek - b * fk; ii += g * fk + b * ek;
-      }
-    }
-    {  // slack bus: res_bus = -(V conj(I)) * sn  (+ shunt), consumer sign
-      const int bus = d.bus_of_pos[d.n];
-      const double sre = d.vroot * ir, sim = -d.vroot * ii;
-      d.vm[(size_t)bus * S + e] = d.vroot; d.va[(size_t)bus * S + e] = 0.0;
-      d.res_p[(size_t)bus * S + e] = -sre * d.sn + d.shunt_p[d.n] * d.vroot * d.vroot;
-      d.res_q[(size_t)bus * S + e] = -sim * d.sn + d.shunt_q[d.n] * d.vroot * d.vroot;
-    }
-    double loss = 0.0;
-    for (int l = 0; l < d.n_line; ++l) {
-      const LineFlow L = d.lines[l];
-      double pl = 0.0;
-      if (L.fpos >= 0) {
-        double ef, ff, et, ft;
-        if (L.fpos == d.n) { ef = d.vroot; ff = 0.0; } else { ef = Ve[L.fpos * S]; ff = Vf[L.fpos * S]; }
-        if (L.tpos == d.n) { et = d.vroot; ft = 0.0; } else { et = Ve[L.tpos * S]; ft = Vf[L.tpos * S]; }
-        // Sf = Vf conj(yff Vf + yft Vt),  St = Vt conj(ytf Vf + ytt Vt);  pl = Re(Sf + St) * sn
-        const double ifr = L.yff[0] * ef - L.yff[1] * ff + L.yft[0] * et - L.yft[1] * ft;
-        const double ifi = L.yff[0] * ff + L.yff[1] * ef + L.yft[0] * ft + L.yft[1] * et;
-        const double itr = L.ytf[0] * ef - L.ytf[1] * ff + L.ytt[0] * et - L.ytt[1] * ft;
-        const double iti = L.ytf[0] * ff + L.ytf[1] * ef + L.ytt[0] * ft + L.ytt[1] * et;
-        pl = ((ef * ifr + ff * ifi) + (et * itr + ft * iti)) * d.sn;
-      }
-      d.pl[(size_t)l * S + e] = pl;
-      loss += pl;
-    }
-    d.line_loss[e] = loss;
-    for (int j = 0; j < d.ns; ++j) d.cur_q[(size_t)j * S + e] = d.q_new[(size_t)j * S + e];
-  } else if (mode == MODE_STEP) {
-    for (int j = 0; j < d.ns; ++j) q_fail += fabs(d.q_new[(size_t)j * S + e]);     // :189
-    q_fail /= (double)d.ns;
-  }
-  if (mode == MODE_RESET) {
-    if (ok) { d.pending[e] = 0; d.done[e] = 0; }
-    return;
-  }
-  // ---- _calc_reward on the committed (or rolled-back == previous) state
   const double vlo = d.v_lower, vhi = d.v_upper, vref = 0.5 * (vlo + vhi);
   int n_lo = 0, n_hi = 0;
   double dev = 0.0, vsum = 0.0, mdrop = 0.0, mrise = 0.0, bar = 0.0;
+#pragma unroll 4
   for (int b = 0; b < d.nb; ++b) {
     const double v = d.vm[(size_t)b * S + e];
     n_lo += (v < vlo); n_hi += (v > vhi);
@@ -362,12 +503,17 @@ k_commit_reward(Dev d, int mode, int add_noise, double* __restrict__ reward, uin
     mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
     bar += barrier(d.barrier_type, v);
   }
+  double line_loss = 0.0;
+#pragma unroll 8
+  for (int l = 0; l < d.n_line; ++l) line_loss += d.pl[(size_t)l * S + e];
+  double q_loss = 0.0, q_fail = 0.0;
+  for (int j = 0; j < d.ns; ++j) {
+    q_loss += fabs(d.cur_q[(size_t)j * S + e]);
+    q_fail += fabs(d.q_new[(size_t)j * S + e]);                                // :189
+  }
+  q_loss /= (double)d.ns; q_fail /= (double)d.ns;
   const double inv_nb = 1.0 / (double)d.nb;
   const double out = (double)(n_lo + n_hi) / (double)d.nb;
-  double q_loss = 0.0;
-  for (int j = 0; j < d.ns; ++j) q_loss += fabs(d.cur_q[(size_t)j * S + e]);
-  q_loss /= (double)d.ns;
-  const double line_loss = d.line_loss[e];
   const double v_loss = bar * inv_nb * d.voltage_weight;
   double loss;
   if (d.use_line_weight) loss = line_loss / (double)d.n_line * d.line_weight + v_loss;   // :612-613
@@ -389,7 +535,6 @@ k_commit_reward(Dev d, int mode, int add_noise, double* __restrict__ reward, uin
   const bool term = (st + 1 >= d.episode_limit) || !ok;                                   // :204
   d.done[e] = term ? 1 : 0;
   reward[e] = rew; terminated[e] = term ? 1 : 0;
-  (void)add_noise;
 }
 
 // =================================================================================================
@@ -522,9 +667,6 @@ k_to_envminor(const double* __restrict__ src, double* __restrict__ dst, int n, i
 __global__ void k_copy_i32(const int32_t* s, int32_t* dd, int B) { int e = blockIdx.x * blockDim.x + threadIdx.x; if (e < B) dd[e] = s[e]; }
 __global__ void k_copy_u8(const uint8_t* s, uint8_t* dd, int B) { int e = blockIdx.x * blockDim.x + threadIdx.x; if (e < B) dd[e] = s[e]; }
 
-// identity descriptors for plain transposes
-__global__ void k_iota(int32_t* kind, int32_t* idx, int n, int k) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) { kind[i] = k; idx[i] = i; } }
-
 // stats: pending count, iteration sum / max over active envs (single block)
 __global__ void __launch_bounds__(256) k_stats(Dev d, long long* out) {
   __shared__ long long s_pend[256], s_sum[256], s_cnt[256];
@@ -559,10 +701,33 @@ void launch_sbus(const Dev& d, const double* pl, const double* ql, const double*
   hipLaunchKernelGGL(k_sbus, grid_env(d, d.n), dim3(256), 0, st, d, pl, ql, pv, q);
 }
 void launch_nr(const Dev& d, hipStream_t st) {
-  hipLaunchKernelGGL(k_nr_tree, dim3(d.Bp / 64), dim3(64), 0, st, d);
+  const dim3 grid(d.Bp / d.nr_lanes);
+  const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.nr_cslots, d.nr_xslots);
+  switch (d.nr_waves) {
+    case 1: hipLaunchKernelGGL(k_nr_wtree<1>, grid, dim3(64), lds, st, d); break;
+    case 2: hipLaunchKernelGGL(k_nr_wtree<2>, grid, dim3(128), lds, st, d); break;
+    case 4: hipLaunchKernelGGL(k_nr_wtree<4>, grid, dim3(256), lds, st, d); break;
+    case 8: hipLaunchKernelGGL(k_nr_wtree<8>, grid, dim3(512), lds, st, d); break;
+    default: hipLaunchKernelGGL(k_nr_wtree<16>, grid, dim3(1024), lds, st, d); break;
+  }
 }
-void launch_commit_reward(const Dev& d, int mode, int add_noise, double* reward, uint8_t* term, double* info, hipStream_t st) {
-  hipLaunchKernelGGL(k_commit_reward, dim3(d.Bp / 64), dim3(64), 0, st, d, mode, add_noise, reward, term, info);
+int nr_set_lds_limit(int waves, size_t bytes) {
+  hipError_t e = hipSuccess;
+  switch (waves) {
+    case 1: e = hipFuncSetAttribute((const void*)k_nr_wtree<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); break;
+    case 2: e = hipFuncSetAttribute((const void*)k_nr_wtree<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); break;
+    case 4: e = hipFuncSetAttribute((const void*)k_nr_wtree<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); break;
+    case 8: e = hipFuncSetAttribute((const void*)k_nr_wtree<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); break;
+    case 16: e = hipFuncSetAttribute((const void*)k_nr_wtree<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); break;
+    default: break;
+  }
+  return e == hipSuccess ? 0 : -1;
+}
+void launch_commit(const Dev& d, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_commit, dim3((d.B + 255) / 256, d.nb + d.n_line + d.ns), dim3(256), 0, st, d, mode);
+}
+void launch_reward(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
+  hipLaunchKernelGGL(k_reward, dim3(d.Bp / 64), dim3(64), 0, st, d, mode, reward, term, info);
 }
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st) {
   hipLaunchKernelGGL(k_reset_begin, dim3((d.B + 255) / 256), dim3(256), 0, st, d, start_rows, first_try);
@@ -584,7 +749,6 @@ void launch_to_envminor(const Dev& d, const double* src, double* dst, int n, hip
 }
 void launch_copy_i32(const int32_t* s, int32_t* dd, int B, hipStream_t st) { hipLaunchKernelGGL(k_copy_i32, dim3((B + 255) / 256), dim3(256), 0, st, s, dd, B); }
 void launch_copy_u8(const uint8_t* s, uint8_t* dd, int B, hipStream_t st) { hipLaunchKernelGGL(k_copy_u8, dim3((B + 255) / 256), dim3(256), 0, st, s, dd, B); }
-void launch_iota(int32_t* kind, int32_t* idx, int n, int k, hipStream_t st) { hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, st, kind, idx, n, k); }
 void launch_stats(const Dev& d, long long* out, hipStream_t st) { hipLaunchKernelGGL(k_stats, dim3(1), dim3(256), 0, st, d, out); }
 
 }  // namespace mapdn

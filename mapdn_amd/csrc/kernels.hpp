@@ -10,6 +10,11 @@ namespace mapdn {
 enum { MODE_STEP = 0, MODE_RESET = 1 };
 enum { STREAM_PV = 0, STREAM_LOAD_P = 1, STREAM_LOAD_Q = 2, STREAM_ACTION = 3, STREAM_START = 4 };
 
+// Fields of one NR operand block.  Every (wave, row) step of the elimination schedule owns one
+// block of NRF rows (a "row" = Bp doubles, env-minor), so all global accesses of a step are
+// block_base + field: the addresses of step r+1 do not depend on anything loaded in step r.
+enum { NF_EK = 0, NF_FK, NF_EP, NF_FP, NF_SR, NF_SI, NF_VA, NF_VM, NF_H0, NF_H1, NF_G0, NF_G1, NF_G2, NF_G3, NRF };
+
 // Everything a kernel needs, passed by value (kernarg segment -> scalar loads).
 // Layout rule: per-env arrays are env-minor, X[item][Bp]; Bp = B rounded up to 64.
 struct Dev {
@@ -17,11 +22,12 @@ struct Dev {
   double vroot, sn, tol;
   int32_t max_it;
   // ---- topology plan (shared by all envs; wave-uniform reads)
-  const int32_t* par; const uint32_t* flags; const double* yc; double yrr0, yrr1;
   const int32_t* bus_of_pos;
   const int32_t *load_ptr, *load_idx, *sgen_ptr, *sgen_idx;
   const double *shunt_p, *shunt_q;
   const LineFlow* lines;
+  const int32_t* root_children; const double* root_y; int32_t n_root_children;   // children of the slack: position, Y_root,k
+  double yrr0, yrr1;
   // ---- profile tables: [T][ncol], columns = pv | load_p | load_q
   const double* table; const double* stdv; const double* smax;
   int64_t T; int32_t n_start_days, per_hour, per_day;
@@ -34,14 +40,17 @@ struct Dev {
   double *vm, *va, *res_p, *res_q;                    // [nb][Bp] by bus id; va in rad
   double *pb, *qb;                                    // [nb][Bp] res_bus p/q with PV add-back
   double *pl;                                         // [n_line][Bp] res_line.pl_mw
-  double *line_loss, *sum_rewards;                    // [Bp]
+  double *sum_rewards;                                // [Bp]
   int32_t* steps; int64_t* start_row; uint32_t* draw;
   uint8_t *done, *pending, *active;
   int64_t* adv_row; uint32_t* adv_draw;
-  // ---- NR scratch, elimination-position order
-  double *Sr, *Si, *Ve, *Vf, *Vm, *Va;                // [n][Bp]
-  double *G, *H, *accS, *accD, *accR, *X;             // [4n|2n][Bp]
+  // ---- NR scratch: operand blocks [nblk+1][NRF][Bp] (block nblk = the slack bus), see NF_*
+  double* nrbuf; uint32_t nrbuf_bytes;
+  const int32_t* blk_of_pos;                          // [n+1] elimination position -> block
   int32_t* iters; uint8_t* conv;
+  // ---- NR schedule (k_nr_wtree): W waves per env group, L envs per wave, R rows
+  int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots;
+  const StepRec* sched; const int32_t* clist;
 };
 
 struct GatherSrc {
@@ -52,7 +61,13 @@ struct GatherSrc {
 void launch_qnew(const Dev& d, const void* actions, int dtype, int mode, hipStream_t st);
 void launch_sbus(const Dev& d, const double* pl, const double* ql, const double* pv, const double* q, hipStream_t st);
 void launch_nr(const Dev& d, hipStream_t st);
-void launch_commit_reward(const Dev& d, int mode, int add_noise, double* reward, uint8_t* term, double* info, hipStream_t st);
+int nr_set_lds_limit(int waves, size_t bytes);
+// dynamic LDS of k_nr_wtree: contribution slots (8 doubles/env), x slots (4 doubles/env), verdict bytes
+static inline size_t nr_lds_bytes(int W, int L, int cslots, int xslots) {
+  return ((size_t)cslots * 8 + (size_t)xslots * 4) * (size_t)L * sizeof(double) + (size_t)W * 64;
+}
+void launch_commit(const Dev& d, int mode, hipStream_t st);
+void launch_reward(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);
 void launch_advance(const Dev& d, int add_noise, hipStream_t st);
 void launch_addback(const Dev& d, hipStream_t st);
@@ -60,7 +75,6 @@ void launch_gather(const Dev& d, const GatherSrc& g, const int32_t* kind, const 
 void launch_to_envminor(const Dev& d, const double* src, double* dst, int n, hipStream_t st);
 void launch_copy_i32(const int32_t* s, int32_t* dd, int B, hipStream_t st);
 void launch_copy_u8(const uint8_t* s, uint8_t* dd, int B, hipStream_t st);
-void launch_iota(int32_t* kind, int32_t* idx, int n, int k, hipStream_t st);
 void launch_stats(const Dev& d, long long* out, hipStream_t st);
 
 }  // namespace mapdn

@@ -166,6 +166,9 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
     }
   }
   P.yrr[0] = Y(P.root_bus, P.root_bus).real(); P.yrr[1] = Y(P.root_bus, P.root_bus).imag();
+  P.root_children.clear(); P.root_y.clear();
+  for (int k = 0; k < P.n; ++k)
+    if (P.par[k] == P.n) { P.root_children.push_back(k); P.root_y.push_back(P.yc[(size_t)k * 6 + 4]); P.root_y.push_back(P.yc[(size_t)k * 6 + 5]); }
 
   // ---- res_line flows ---------------------------------------------------------------------------
   P.lines.resize(net.n_line);
@@ -229,6 +232,125 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   if (ss & MAPDN_SS_VA_DEGREE) for (int b = 0; b < nb; ++b) sput(G_VA_DEG, b);
   P.state_size = (int32_t)P.state_kind.size();
   return MAPDN_OK;
+}
+
+void build_schedule(const Plan& P, int W, Schedule& S) {
+  const int n = P.n;
+  S.W = W; S.steps.clear(); S.clist.clear();
+  std::vector<std::vector<int>> children(n + 1);
+  for (int k = 0; k < n; ++k) children[P.par[k]].push_back(k);     // ascending k
+  std::vector<int> depth(n + 1, 0);
+  for (int k = n - 1; k >= 0; --k) depth[k] = depth[P.par[k]] + 1;  // parents have larger positions
+  auto chain_child = [&](int k) { return (k > 0 && (P.flags[k - 1] & F_PARENT_NEXT)) ? k - 1 : -1; };
+  std::vector<int> pending(n, 0), row_of(n, -1), wave_of(n, -1);
+  for (int k = 0; k < n; ++k) pending[k] = (int)children[k].size();
+  std::vector<int> ready;
+  for (int k = 0; k < n; ++k) if (!pending[k]) ready.push_back(k);
+  std::vector<std::vector<int>> rows;   // rows[r][w] = node or -1
+  int scheduled = 0;
+  if (W == 1) {   // one worker: the plan's own order keeps the feeder chains contiguous
+    for (int k = 0; k < n; ++k) { rows.push_back({k}); row_of[k] = k; wave_of[k] = 0; }
+    scheduled = n;
+  }
+  while (scheduled < n) {
+    const int r = (int)rows.size();
+    // highest level first; among equals prefer nodes that continue a chain from the previous row
+    auto continues = [&](int k) { int c = chain_child(k); return c >= 0 && row_of[c] == r - 1; };
+    std::stable_sort(ready.begin(), ready.end(), [&](int a, int b) {
+      if (depth[a] != depth[b]) return depth[a] > depth[b];
+      bool ca = continues(a), cb = continues(b);
+      if (ca != cb) return ca;
+      return a < b;
+    });
+    const int take = std::min<int>(W, (int)ready.size());
+    std::vector<int> row(W, -1), chosen(ready.begin(), ready.begin() + take);
+    ready.erase(ready.begin(), ready.begin() + take);
+    std::vector<int> rest;
+    for (int k : chosen) {            // chain affinity first
+      int c = chain_child(k);
+      if (c >= 0 && row_of[c] == r - 1 && row[wave_of[c]] < 0) row[wave_of[c]] = k; else rest.push_back(k);
+    }
+    // a wave whose previous-row node's parent is NOT placed on it may take any remaining node
+    int w = 0;
+    for (int k : rest) { while (row[w] >= 0) ++w; row[w] = k; }
+    for (int ww = 0; ww < W; ++ww) if (row[ww] >= 0) { row_of[row[ww]] = r; wave_of[row[ww]] = ww; ++scheduled; }
+    rows.push_back(row);
+    for (int ww = 0; ww < W; ++ww) {
+      int k = row[ww];
+      if (k < 0) continue;
+      int p = P.par[k];
+      if (p < n && --pending[p] == 0) ready.push_back(p);
+    }
+  }
+  const int R = (int)rows.size();
+  S.R = R;
+  S.steps.assign((size_t)W * R, StepRec{});
+  std::vector<char> carry_out(n, 0);
+  for (int k = 0; k < n; ++k) {
+    int p = P.par[k];
+    if (p < n && chain_child(p) == k && row_of[p] == row_of[k] + 1 && wave_of[p] == wave_of[k]) carry_out[k] = 1;
+  }
+  // ---- LDS slot allocation by interval colouring.
+  // contribution slot of child c: written in forward row row_of[c], read in row row_of[par]; it may
+  // be rewritten only in a row AFTER the read (rows are separated by barriers, a row is not).
+  std::vector<int> oslot(n, -1), xslot(n, -1);
+  {
+    std::vector<std::vector<int>> writers(R), release(R + 1);
+    for (int k = 0; k < n; ++k) if (P.par[k] < n && !carry_out[k]) writers[row_of[k]].push_back(k);
+    std::vector<int> freelist; int next = 0;
+    for (int r = 0; r < R; ++r) {
+      for (int sl : release[r]) freelist.push_back(sl);
+      std::sort(freelist.begin(), freelist.end(), std::greater<int>());
+      for (int k : writers[r]) {
+        int sl; if (!freelist.empty()) { sl = freelist.back(); freelist.pop_back(); } else sl = next++;
+        oslot[k] = sl;
+        release[row_of[P.par[k]] + 1].push_back(sl);
+      }
+    }
+    S.n_cslots = std::max(next, 1);
+  }
+  // x slot of parent p: written in backward row row_of[p], read by its non-carried children at
+  // rows < row_of[p]; reusable by writers at rows strictly below the lowest reader row.
+  {
+    std::vector<int> low(n, -1);   // lowest reader row
+    for (int k = 0; k < n; ++k) { int p = P.par[k]; if (p < n && !carry_out[k]) low[p] = (low[p] < 0) ? row_of[k] : std::min(low[p], row_of[k]); }
+    std::vector<std::vector<int>> writers(R), release(R + 1);
+    for (int k = 0; k < n; ++k) if (low[k] >= 0) writers[row_of[k]].push_back(k);
+    std::vector<int> freelist; int next = 0;
+    for (int r = R - 1; r >= 0; --r) {
+      for (int sl : release[r]) freelist.push_back(sl);      // released for writers at row r: readers all at rows > r
+      std::sort(freelist.begin(), freelist.end(), std::greater<int>());
+      for (int k : writers[r]) {
+        int sl; if (!freelist.empty()) { sl = freelist.back(); freelist.pop_back(); } else sl = next++;
+        xslot[k] = sl;
+        if (low[k] - 1 >= 0) release[low[k] - 1].push_back(sl);
+      }
+    }
+    S.n_xslots = std::max(next, 1);
+  }
+  for (int w = 0; w < W; ++w)
+    for (int r = 0; r < R; ++r) {
+      StepRec& T = S.steps[(size_t)w * R + r];
+      const int k = rows[r][w];
+      T = StepRec{};
+      T.k = k;
+      if (k < 0) continue;
+      const double* c = &P.yc[(size_t)k * 6];
+      T.ykk[0] = c[0]; T.ykk[1] = c[1]; T.ykp[0] = c[2]; T.ykp[1] = c[3]; T.ypk[0] = c[4]; T.ypk[1] = c[5];
+      T.p = P.par[k];
+      uint32_t f = 0;
+      if (T.p == n) f |= S_PARENT_ROOT;
+      else if (carry_out[k]) f |= S_CARRY_OUT;
+      else { f |= S_SCRATCH_OUT; T.oslot = oslot[k]; T.pxslot = xslot[T.p]; }
+      T.cptr = (int32_t)S.clist.size();
+      uint32_t cnt = 0;
+      const int cc = chain_child(k);
+      if (cc >= 0) { if (carry_out[cc]) f |= S_CARRY_IN; else { S.clist.push_back(oslot[cc]); ++cnt; } }
+      for (int ch : children[k]) if (ch != cc) { S.clist.push_back(oslot[ch]); ++cnt; }
+      if (xslot[k] >= 0) { f |= S_X_OUT; T.xslot = xslot[k]; }
+      T.flags = f | (cnt << 16);
+    }
+  if (S.clist.empty()) S.clist.push_back(0);
 }
 
 }  // namespace mapdn

@@ -32,6 +32,36 @@ enum : int32_t {
   G_P = 7, G_Q = 8, G_VA_DEG = 9, G_NKIND = 10
 };
 
+// One step of one wave of the NR kernel (80 bytes, wave-uniform, prefetched one row ahead).
+// flags: S_* in the low 16 bits, number of LDS-slot children to gather in the high 16 bits.
+struct StepRec {
+  double ykk[2], ykp[2], ypk[2];
+  int32_t k;        // node position, -1 = idle step
+  int32_t p;        // parent position (n == root)
+  uint32_t flags;
+  int32_t cptr;     // first entry of this node's children-slot list
+  int32_t oslot;    // LDS contribution slot this node writes (S_SCRATCH_OUT)
+  int32_t xslot;    // LDS x slot this node writes in the backward sweep (S_X_OUT)
+  int32_t pxslot;   // LDS x slot of the parent (read when the parent's x is not carried)
+  int32_t pad;
+};
+
+// schedule-step flags (wave-uniform control flow in the NR kernel)
+enum : uint32_t {
+  S_PARENT_ROOT = 1u,    // parent is the slack bus: no off-diagonal Jacobian block
+  S_CARRY_OUT = 2u,      // the same wave processes the parent in the next row: contribution stays in registers
+  S_CARRY_IN = 4u,       // the chain child's contribution arrives in registers
+  S_SCRATCH_OUT = 8u,    // write own contribution to scratch slot[k] (parent gathers it)
+  S_X_OUT = 16u,         // backward sweep: store x_k to scratch (some child reads it from memory)
+};
+
+struct Schedule {
+  int32_t W = 1, R = 0;             // waves per env group, rows
+  std::vector<StepRec> steps;       // [W][R]
+  std::vector<int32_t> clist;       // LDS slots of the children to gather (canonical order: chain child first, then ascending)
+  int32_t n_cslots = 0, n_xslots = 0;  // LDS slots (reused by interval colouring): 8 resp. 2 doubles per env each
+};
+
 struct LineFlow {      // pi-model admittances of one net.line row for res_line.pl_mw
   int32_t fpos, tpos;  // elimination positions (n == root); -1 if out of service
   double yff[2], yft[2], ytf[2], ytt[2];
@@ -49,6 +79,8 @@ struct Plan {
   std::vector<uint32_t> flags;                  // [n]
   std::vector<double> yc;                       // [n*6] ykk, ykp, ypk (re, im)
   double yrr[2] = {0, 0};
+  std::vector<int32_t> root_children;           // positions whose parent is the slack
+  std::vector<double> root_y;                   // [2*len] Y[slack, child] (re, im)
   std::vector<cplx> ybus;                       // dense [nb*nb], debug export only
 
   std::vector<LineFlow> lines;                  // [n_line]
@@ -65,5 +97,11 @@ struct Plan {
 
 // returns MAPDN_OK or an error code, filling `err`
 int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& out, std::string& err);
+
+// Hu's level algorithm (optimal for unit-time in-trees) on W workers, with chain affinity so that a
+// parent scheduled right after its canonical chain child (node k-1 -> k when F_PARENT_NEXT) runs on
+// the same wave and receives the contribution through registers.  The sum order of children is
+// canonical (chain child first, then ascending position) and therefore independent of W.
+void build_schedule(const Plan& P, int W, Schedule& out);
 
 }  // namespace mapdn

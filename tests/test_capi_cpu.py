@@ -132,3 +132,38 @@ def test_no_gpu_fails_loudly(lib):
     from mapdn_amd.env import VoltageControlBatch
     with pytest.raises(Exception):
         VoltageControlBatch(net, make_case("case33")[1], ARGS, n_envs=2, device="cpu")
+
+
+@pytest.mark.parametrize("case", ["case33", "case141", "case322"])
+@pytest.mark.parametrize("W", [1, 2, 4, 8, 16])
+def test_nr_schedule_is_a_valid_tree_elimination(lib, case, W):
+    """Hu schedule: every node exactly once, children strictly before their parent, one node per
+    (wave,row), rows bounded below by tree depth and n/W and above by n."""
+    net, _ = make_case(case)
+    rc, h = host_handle(lib, net)
+    assert rc == 0
+    n = net.n_bus - 1
+    R = C.c_int32()
+    assert lib.mapdn_get_schedule(h, W, C.byref(R), None, None) == 0
+    R = R.value
+    rows = np.zeros(W * R, np.int32)
+    par = np.zeros(n, np.int32)
+    assert lib.mapdn_get_schedule(h, W, C.byref(C.c_int32()), _lib._p(rows, _lib._pi), _lib._p(par, _lib._pi)) == 0
+    rows = rows.reshape(W, R)
+    nodes = rows[rows >= 0]
+    assert sorted(nodes.tolist()) == list(range(n))
+    row_of = np.zeros(n, int)
+    for w in range(W):
+        for r in range(R):
+            if rows[w, r] >= 0:
+                row_of[rows[w, r]] = r
+    depth = np.zeros(n + 1, int)
+    for k in range(n - 1, -1, -1):
+        assert par[k] > k                      # parents are eliminated after their children
+        depth[k] = depth[par[k]] + 1
+        if par[k] < n:
+            assert row_of[par[k]] > row_of[k]
+    assert max(depth.max(), -(-n // W)) <= R <= n
+    if W == 1:
+        assert R == n
+    lib.mapdn_destroy(h)
