@@ -22,8 +22,8 @@ struct mapdn_handle {
   std::string err;
   std::vector<void*> allocs;
   bool have_profiles = false, was_reset = false, host_only = false;
-  int32_t *obs_kind = nullptr, *obs_idx = nullptr, *state_kind = nullptr, *state_idx = nullptr;
-  int32_t *zero_kind = nullptr, *iota_idx = nullptr, *vm_row = nullptr, *va_row = nullptr;
+  int32_t *obs_rows = nullptr, *state_rows = nullptr, *iota_idx = nullptr, *vm_row = nullptr, *va_row = nullptr;
+  double *obs_scale = nullptr, *state_scale = nullptr;
   double *t_pl = nullptr, *t_ql = nullptr, *t_pv = nullptr, *t_q = nullptr;
   double* table = nullptr; double* stdv = nullptr; double* smax = nullptr;
   long long* stats_dev = nullptr;
@@ -120,8 +120,14 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   UP(shunt_p, P.shunt_p); UP(shunt_q, P.shunt_q); UP(lines, P.lines);
   const size_t Bp = d.Bp;
 #define AL(field, rows) do { rc = dalloc(h, &d.field, (size_t)(rows) * Bp); if (rc) return rc; } while (0)
-  AL(cur_pv, d.ns); AL(cur_q, d.ns); AL(q_new, d.ns); AL(cur_pl, d.nl); AL(cur_ql, d.nl);
-  AL(vm, d.nb); AL(va, d.nb); AL(res_p, d.nb); AL(res_q, d.nb); AL(pb, d.nb); AL(qb, d.nb); AL(pl, d.n_line);
+  AL(q_new, d.ns); AL(cur_pl, d.nl); AL(cur_ql, d.nl); AL(pl, d.n_line);
+  // gatherable state block: pb qb [nb] | cur_pv cur_q [ns] | vm va res_p res_q [nb]
+  const int r_pb = 0, r_qb = d.nb, r_pv = 2 * d.nb, r_q = r_pv + d.ns, r_vm = r_q + d.ns, r_va = r_vm + d.nb,
+            r_rp = r_va + d.nb, r_rq = r_rp + d.nb, g_rows = r_rq + d.nb;
+  rc = dalloc(h, &d.gbuf, (size_t)g_rows * Bp); if (rc) return rc;
+  d.pb = d.gbuf + (size_t)r_pb * Bp; d.qb = d.gbuf + (size_t)r_qb * Bp; d.cur_pv = d.gbuf + (size_t)r_pv * Bp;
+  d.cur_q = d.gbuf + (size_t)r_q * Bp; d.vm = d.gbuf + (size_t)r_vm * Bp; d.va = d.gbuf + (size_t)r_va * Bp;
+  d.res_p = d.gbuf + (size_t)r_rp * Bp; d.res_q = d.gbuf + (size_t)r_rq * Bp;
   AL(sum_rewards, 1); AL(steps, 1); AL(start_row, 1); AL(draw, 1); AL(done, 1); AL(pending, 1);
   AL(active, 1); AL(adv_row, 1); AL(adv_draw, 1); AL(iters, 1); AL(conv, 1);
   {
@@ -129,14 +135,35 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     HIPCHK(h, hipMemcpy(d.done, ones.data(), Bp, hipMemcpyHostToDevice));   // nothing is steppable before reset
   }
   const int32_t* tmp;
-  rc = dupload(h, &tmp, P.obs_kind); if (rc) return rc; h->obs_kind = (int32_t*)tmp;
-  rc = dupload(h, &tmp, P.obs_idx); if (rc) return rc; h->obs_idx = (int32_t*)tmp;
-  rc = dupload(h, &tmp, P.state_kind); if (rc) return rc; h->state_kind = (int32_t*)tmp;
-  rc = dupload(h, &tmp, P.state_idx); if (rc) return rc; h->state_idx = (int32_t*)tmp;
+  {  // obs / state columns -> (source row of gbuf, scale); -1 = zero padding
+    auto tables = [&](const std::vector<int32_t>& kind, const std::vector<int32_t>& idx, std::vector<int32_t>& rows, std::vector<double>& scale) {
+      rows.resize(kind.size()); scale.assign(kind.size(), 1.0);
+      for (size_t c = 0; c < kind.size(); ++c) {
+        switch (kind[c]) {
+          case G_P_ADDBACK: rows[c] = r_pb + idx[c]; break;
+          case G_Q_ADDBACK: rows[c] = r_qb + idx[c]; break;
+          case G_SGEN_P: rows[c] = r_pv + idx[c]; break;
+          case G_SGEN_Q: rows[c] = r_q + idx[c]; break;
+          case G_VM: rows[c] = r_vm + idx[c]; break;
+          case G_VA_RAD: rows[c] = r_va + idx[c]; break;
+          case G_P: rows[c] = r_rp + idx[c]; break;
+          case G_Q: rows[c] = r_rq + idx[c]; break;
+          case G_VA_DEG: rows[c] = r_va + idx[c]; scale[c] = 180.0 / M_PI; break;
+          default: rows[c] = -1; break;
+        }
+      }
+    };
+    std::vector<int32_t> rows; std::vector<double> scale; const double* dt;
+    tables(P.obs_kind, P.obs_idx, rows, scale);
+    rc = dupload(h, &tmp, rows); if (rc) return rc; h->obs_rows = (int32_t*)tmp;
+    rc = dupload(h, &dt, scale); if (rc) return rc; h->obs_scale = (double*)dt;
+    tables(P.state_kind, P.state_idx, rows, scale);
+    rc = dupload(h, &tmp, rows); if (rc) return rc; h->state_rows = (int32_t*)tmp;
+    rc = dupload(h, &dt, scale); if (rc) return rc; h->state_scale = (double*)dt;
+  }
   const int maxn = std::max(std::max(d.nb, d.n_line), std::max(d.nl, d.ns));
-  std::vector<int32_t> zk(maxn, 0), io(maxn);
+  std::vector<int32_t> io(maxn);
   for (int i = 0; i < maxn; ++i) io[i] = i;
-  rc = dupload(h, &tmp, zk); if (rc) return rc; h->zero_kind = (int32_t*)tmp;
   rc = dupload(h, &tmp, io); if (rc) return rc; h->iota_idx = (int32_t*)tmp;
   rc = dalloc(h, &h->t_pl, (size_t)d.nl * Bp); if (rc) return rc;
   rc = dalloc(h, &h->t_ql, (size_t)d.nl * Bp); if (rc) return rc;
@@ -153,13 +180,15 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   if (!(W == 1 || W == 2 || W == 4 || W == 8 || W == 16) || !(L == 64 || L == 32 || L == 16)) {
     h->err = "MAPDN_NR_WAVES must be 1/2/4/8/16 and MAPDN_NR_LANES 64/32/16"; return MAPDN_E_INVALID; }
   build_schedule(P, W, h->sched);
+  if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
   // LDS budget (160 KB per CU on gfx950): halve the envs per wave until the slots fit
-  while (L > 16 && nr_lds_bytes(W, L, h->sched.n_cslots, h->sched.n_xslots) > 160 * 1024) L /= 2;
-  if (nr_lds_bytes(W, L, h->sched.n_cslots, h->sched.n_xslots) > 160 * 1024) {
-    h->err = "NR schedule needs more LDS than one CU has; lower MAPDN_NR_WAVES"; return MAPDN_E_INVALID; }
+  const int ncl = (int)h->sched.clist.size();
+  auto lds_need = [&](int l) { return nr_lds_bytes(W, l, h->sched.n_cslots, h->sched.n_xslots, h->sched.R, ncl); };
+  while (L > 16 && lds_need(L) > 160 * 1024) L /= 2;
+  if (lds_need(L) > 160 * 1024) { h->err = "NR schedule needs more LDS than one CU has; lower MAPDN_NR_WAVES"; return MAPDN_E_INVALID; }
   d.nr_waves = W; d.nr_lanes = L;
-  d.nr_rows = h->sched.R; d.nr_cslots = h->sched.n_cslots; d.nr_xslots = h->sched.n_xslots;
-  if (nr_set_lds_limit(W, nr_lds_bytes(W, L, d.nr_cslots, d.nr_xslots)) != 0) {
+  d.nr_rows = h->sched.R; d.nr_cslots = h->sched.n_cslots; d.nr_xslots = h->sched.n_xslots; d.nr_nclist = ncl;
+  if (nr_set_lds_limit(W, lds_need(L)) != 0) {
     h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return MAPDN_E_HIP; }
   UP(sched, h->sched.steps); UP(clist, h->sched.clist);
   {  // operand blocks: one per (wave,row) step + one for the slack bus; a single buffer resource addresses them
@@ -289,8 +318,7 @@ int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, i
   for (int t = 0; t < max_tries; ++t) {
     launch_reset_begin(d, start_rows, t == 0, st);
     launch_advance(d, add_noise, st);
-    launch_qnew(d, nullptr, MAPDN_F64, MODE_RESET, st);
-    launch_sbus(d, d.cur_pl, d.cur_ql, d.cur_pv, d.q_new, st);
+    launch_inject(d, MODE_RESET, nullptr, MAPDN_F64, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, st);
     nr_launch(h, st);
     launch_commit(d, MODE_RESET, st);
     launch_reward(d, MODE_RESET, nullptr, nullptr, nullptr, st);
@@ -310,23 +338,13 @@ int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int3
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   const Dev& d = h->d;
-  launch_qnew(d, actions, actions_dtype, MODE_STEP, st);
-  launch_sbus(d, d.cur_pl, d.cur_ql, d.cur_pv, d.q_new, st);
+  launch_inject(d, MODE_STEP, actions, actions_dtype, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, st);
   nr_launch(h, st);
   launch_commit(d, MODE_STEP, st);
   launch_reward(d, MODE_STEP, reward, terminated, info, st);
   launch_advance(d, add_noise, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
-}
-
-static GatherSrc obs_sources(const Dev& d) {
-  GatherSrc g;
-  for (int k = 0; k < G_NKIND; ++k) { g.base[k] = nullptr; g.scale[k] = 1.0; }
-  g.base[G_P_ADDBACK] = d.pb; g.base[G_Q_ADDBACK] = d.qb; g.base[G_SGEN_P] = d.cur_pv; g.base[G_SGEN_Q] = d.cur_q;
-  g.base[G_VM] = d.vm; g.base[G_VA_RAD] = d.va; g.base[G_P] = d.res_p; g.base[G_Q] = d.res_q;
-  g.base[G_VA_DEG] = d.va; g.scale[G_VA_DEG] = 180.0 / M_PI;
-  return g;
 }
 
 int mapdn_get_obs(mapdn_handle* h, void* obs, int32_t dtype, void* stream) {
@@ -336,7 +354,7 @@ int mapdn_get_obs(mapdn_handle* h, void* obs, int32_t dtype, void* stream) {
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   launch_addback(h->d, st);
-  launch_gather(h->d, obs_sources(h->d), h->obs_kind, h->obs_idx, obs, dtype, h->plan.n_agents * h->plan.obs_size, st);
+  launch_gather(h->d, h->d.gbuf, h->obs_rows, h->obs_scale, 1.0, obs, dtype, h->plan.n_agents * h->plan.obs_size, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
 }
@@ -347,16 +365,13 @@ int mapdn_get_state(mapdn_handle* h, void* state, int32_t dtype, void* stream) {
   NEEDDEV(h);
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
-  launch_gather(h->d, obs_sources(h->d), h->state_kind, h->state_idx, state, dtype, h->plan.state_size, st);
+  launch_gather(h->d, h->d.gbuf, h->state_rows, h->state_scale, 1.0, state, dtype, h->plan.state_size, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
 }
 
-static void transpose_out(mapdn_handle* h, const double* src, double scale, const int32_t* idx, double* out, int n, hipStream_t st) {
-  GatherSrc g;
-  for (int k = 0; k < G_NKIND; ++k) { g.base[k] = nullptr; g.scale[k] = 1.0; }
-  g.base[0] = src; g.scale[0] = scale;
-  launch_gather(h->d, g, h->zero_kind, idx, out, MAPDN_F64, n, st);
+static void transpose_out(mapdn_handle* h, const double* src, double scale, const int32_t* rows, double* out, int n, hipStream_t st) {
+  launch_gather(h->d, src, rows, nullptr, scale, out, MAPDN_F64, n, st);
 }
 
 int mapdn_get_results(mapdn_handle* h, double* vm_pu, double* va_degree, double* p_mw, double* q_mvar, double* pl_mw,
@@ -411,7 +426,7 @@ int mapdn_solve_only(mapdn_handle* h, const double* p_load, const double* q_load
   launch_to_envminor(d, q_sgen, h->t_q, d.ns, st);
   HIPCHK(h, hipMemsetAsync(d.active, 1, d.B, st));
   if (d.Bp > d.B) HIPCHK(h, hipMemsetAsync(d.active + d.B, 0, d.Bp - d.B, st));
-  launch_sbus(d, h->t_pl, h->t_ql, h->t_pv, h->t_q, st);
+  launch_inject(d, MODE_SOLVE, nullptr, MAPDN_F64, h->t_pl, h->t_ql, h->t_pv, h->t_q, st);
   nr_launch(h, st);
   if (vm_pu) transpose_out(h, d.nrbuf, 1.0, h->vm_row, vm_pu, d.nb, st);
   if (va_degree) transpose_out(h, d.nrbuf, 180.0 / M_PI, h->va_row, va_degree, d.nb, st);

@@ -40,63 +40,58 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
 }
 
 // =================================================================================================
-// K1a  q_new — _clip_reactive_power (voltage_control_env.py:568-572) for step(), or the random
-//      initial action of reset() (:120-122, get_action :337).  thread = (sgen j, env e).
+// K1  inject — _clip_reactive_power (voltage_control_env.py:568-572) for step(), or the random
+//     initial action of reset() (:120-122, get_action :337), fused with pandapower
+//     build_bus._calc_pq_elements_and_add_on_ppc + makeSbus: Sbus[k] = -(sum load - sum sgen)/sn_mva
+//     by element->bus CSR (no atomics).  thread = (position k, env e); the thread of a bus computes
+//     the q of the sgens on that bus, so q_new is written exactly once.  MODE_SOLVE takes all four
+//     element-power arrays as given (mapdn_solve_only).
 // =================================================================================================
 template <typename AT>
-__global__ void __launch_bounds__(256) k_qnew(Dev d, const AT* __restrict__ actions, int mode) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
-  if (e >= d.Bp) return;
-  bool act;
-  if (e >= d.B) act = false;
-  else if (mode == MODE_STEP) act = !d.done[e];
-  else act = d.pending[e] != 0;
-  if (j == 0) d.active[e] = act ? 1 : 0;
-  if (!act) return;
-  const size_t o = (size_t)j * d.Bp + e;
-  const double p = d.cur_pv[o];
-  const double sm = d.smax[j];
-  const double lim = sqrt(sm * sm - p * p);
-  double a;
-  if (mode == MODE_STEP) {
-    a = (double)actions[(size_t)e * d.ns + j];
-  } else if (d.reset_action) {
-    uint32_t x[4];
-    philox4x32_10((uint32_t)(d.env_id_offset + e), d.adv_draw[e], STREAM_ACTION, (uint32_t)(j >> 1),
-                  d.seed_lo, d.seed_hi, x);
-    const double u = ((j & 1) ? u53(x[2], x[3]) : u53(x[0], x[1])) * (1.0 / 9007199254740992.0);
-    a = d.action_low + (d.action_high - d.action_low) * u;
-  } else {
-    d.q_new[o] = 0.0;   // base-net q_mvar (deepcopy of base_powergrid, :106)
-    return;
-  }
-  d.q_new[o] = lim * a;
-}
-
-// =================================================================================================
-// K1b  Sbus — pandapower build_bus._calc_pq_elements_and_add_on_ppc + makeSbus:
-//      Sbus[k] = -(sum load - sum sgen)/sn_mva, by element->bus CSR (no atomics).
-//      thread = (position k, env e); writes into the NR operand block of node k.
-// =================================================================================================
 __global__ void __launch_bounds__(256)
-k_sbus(Dev d, const double* __restrict__ pl, const double* __restrict__ ql, const double* __restrict__ pv,
-       const double* __restrict__ q) {
+k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restrict__ pl, const double* __restrict__ ql,
+         const double* __restrict__ pv, const double* __restrict__ qin) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
+  const int k = blockIdx.y;                      // 0..n (n == slack: only its sgens' q, no Sbus row)
   if (e >= d.Bp) return;
+  bool act = true;
+  if (mode != MODE_SOLVE) {
+    if (e >= d.B) act = false;
+    else if (mode == MODE_STEP) act = !d.done[e];
+    else act = d.pending[e] != 0;
+    if (k == 0) d.active[e] = act ? 1 : 0;
+  }
   double P = 0.0, Q = 0.0;
   for (int i = d.load_ptr[k]; i < d.load_ptr[k + 1]; ++i) {
     const size_t o = (size_t)d.load_idx[i] * d.Bp + e;
     P += pl[o]; Q += ql[o];
   }
   for (int i = d.sgen_ptr[k]; i < d.sgen_ptr[k + 1]; ++i) {
-    const size_t o = (size_t)d.sgen_idx[i] * d.Bp + e;
-    P -= pv[o]; Q -= q[o];
+    const int j = d.sgen_idx[i];
+    const size_t o = (size_t)j * d.Bp + e;
+    const double p = pv[o];
+    double q;
+    if (mode == MODE_SOLVE) q = qin[o];
+    else if (!act) q = d.q_new[o];
+    else {
+      const double sm = d.smax[j];
+      const double lim = sqrt(sm * sm - p * p);
+      if (mode == MODE_STEP) q = lim * (double)actions[(size_t)e * d.ns + j];
+      else if (d.reset_action) {
+        uint32_t x[4];
+        philox4x32_10((uint32_t)(d.env_id_offset + e), d.adv_draw[e], STREAM_ACTION, (uint32_t)(j >> 1), d.seed_lo, d.seed_hi, x);
+        const double u = ((j & 1) ? u53(x[2], x[3]) : u53(x[0], x[1])) * (1.0 / 9007199254740992.0);
+        q = lim * (d.action_low + (d.action_high - d.action_low) * u);
+      } else q = 0.0;                            // base-net q_mvar (deepcopy of base_powergrid, :106)
+      d.q_new[o] = q;
+    }
+    P -= p; Q -= q;
   }
-  double* blk = d.nrbuf + (size_t)d.blk_of_pos[k] * NRF * d.Bp + e;
-  blk[(size_t)NF_SR * d.Bp] = -P / d.sn;
-  blk[(size_t)NF_SI * d.Bp] = -Q / d.sn;
+  if (k < d.n) {
+    double* blk = d.nrbuf + (size_t)d.blk_of_pos[k] * NRF * d.Bp + e;
+    blk[(size_t)NF_SR * d.Bp] = -P / d.sn;
+    blk[(size_t)NF_SI * d.Bp] = -Q / d.sn;
+  }
 }
 
 // =================================================================================================
@@ -195,20 +190,6 @@ __global__ void __launch_bounds__(64 * W) k_nr_wtree(Dev d) {
   const unsigned e = blockIdx.x * L + lane;
   const int R = d.nr_rows;
   const double vroot = d.vroot, tol = d.tol;
-  // schedule data through the CONSTANT address space: wave-uniform s_load (scalar cache), never
-  // vector memory — so record fetches neither occupy vmcnt nor serialise with the operand loads
-  typedef const __attribute__((address_space(4))) StepRec* crec_t;
-  typedef const __attribute__((address_space(4))) int32_t* cint_t;
-  const crec_t seq_c = (crec_t)(unsigned long long)(d.sched + (size_t)w * R);
-  const cint_t clist = (cint_t)(unsigned long long)d.clist;
-  auto rec = [&](int r) {                        // field-wise copy out of the constant address space
-    StepRec T;
-    T.ykk[0] = seq_c[r].ykk[0]; T.ykk[1] = seq_c[r].ykk[1]; T.ykp[0] = seq_c[r].ykp[0]; T.ykp[1] = seq_c[r].ykp[1];
-    T.ypk[0] = seq_c[r].ypk[0]; T.ypk[1] = seq_c[r].ypk[1];
-    T.k = seq_c[r].k; T.p = 0; T.flags = seq_c[r].flags; T.cptr = seq_c[r].cptr;
-    T.oslot = seq_c[r].oslot; T.xslot = seq_c[r].xslot; T.pxslot = seq_c[r].pxslot; T.pad = 0;
-    return T;
-  };
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d.nrbuf, 0, d.nrbuf_bytes, 0x00020000);
   const unsigned rb = (unsigned)d.Bp * 8u;       // bytes per row
   const unsigned bb = (unsigned)NRF * rb;        // bytes per operand block
@@ -216,9 +197,22 @@ __global__ void __launch_bounds__(64 * W) k_nr_wtree(Dev d) {
   unsigned vo[NRF];                              // lane + field offsets (loop-invariant VGPRs)
 #pragma unroll
   for (int f = 0; f < NRF; ++f) vo[f] = e * 8u + (unsigned)f * rb;
-  double* cs = lds + lane;                                  // contribution slots: cs[(slot*8 + item)*L]
-  double* xs = lds + (size_t)d.nr_cslots * 8 * L + lane;    // x/V slots:          xs[(slot*4 + item)*L]
+  // LDS map: [contribution slots 8/env][x slots 4/env][verdict bytes W*64][schedule W*R*80 B][overflow child list]
+  double* cs = lds + lane;                                  // cs[(slot*8 + item)*L]
+  double* xs = lds + (size_t)d.nr_cslots * 8 * L + lane;    // xs[(slot*4 + item)*L]
   uint8_t* s_ok = (uint8_t*)(lds + ((size_t)d.nr_cslots * 8 + (size_t)d.nr_xslots * 4) * L);   // [W][64]
+  StepRec* s_sched = (StepRec*)(s_ok + W * 64);             // 16-byte aligned: all sizes above are multiples of 64
+  int32_t* s_clist = (int32_t*)(s_sched + (size_t)W * R);
+  {  // stage this wave's step records (and the overflow child list) in LDS: LDS reads return in order
+     // with the other LGKM traffic, so records can be prefetched a row ahead (scalar loads cannot:
+     // every lgkmcnt(0) would drain them)
+    const uint4* src = (const uint4*)(d.sched + (size_t)w * R);
+    uint4* dst = (uint4*)(s_sched + (size_t)w * R);
+    for (unsigned i = lane; i < 5u * (unsigned)R; i += L) dst[i] = src[i];
+    if (w == 0) for (unsigned i = lane; i < (unsigned)d.nr_nclist; i += L) s_clist[i] = d.clist[i];
+  }
+  const StepRec* seq = s_sched + (size_t)w * R;
+  if (W > 1) __syncthreads();
 
   bool done = d.active[e] == 0;
   bool conv = false;
@@ -228,7 +222,7 @@ __global__ void __launch_bounds__(64 * W) k_nr_wtree(Dev d) {
     return;
   }
   for (int r = 0; r < R; ++r) {                  // flat start (runpp init="auto"): every bus at the slack set-point
-    if (seq_c[r].k < 0) continue;
+    if (seq[r].k < 0) continue;
     const unsigned sb = sb0 + (unsigned)r * bb;
     bst(vroot, rs, vo[NF_EK], sb); bst(0.0, rs, vo[NF_FK], sb); bst(vroot, rs, vo[NF_EP], sb); bst(0.0, rs, vo[NF_FP], sb);
     bst(0.0, rs, vo[NF_VA], sb); bst(vroot, rs, vo[NF_VM], sb);
@@ -249,107 +243,133 @@ __global__ void __launch_bounds__(64 * W) k_nr_wtree(Dev d) {
     o.e = bld(rs, vo[NF_EK], sb); o.f = bld(rs, vo[NF_FK], sb); o.va = bld(rs, vo[NF_VA], sb); o.vm = bld(rs, vo[NF_VM], sb);
   };
 
+  // NOTE on VMEM accounting: every step issues EXACTLY the same vector-memory instructions (fwd: 6
+  // loads + 6 stores, bwd: 10 loads + 6 stores) regardless of flags / idle steps (idle steps write
+  // don't-care values to their dummy block).  vmcnt is one in-order counter for loads AND stores on
+  // gfx9: only with a path-independent count can the compiler wait for "the loads issued two rows
+  // ago" (vmcnt(24)) without also draining the stores issued a few cycles earlier.
   auto fwd_step = [&](const StepRec& T, unsigned sb, const FwdOps& o) {
-    if (T.k < 0) return;
-    const uint32_t fl = T.flags;
-    const double gkk = T.ykk[0], bkk = T.ykk[1], gkp = T.ykp[0], bkp = T.ykp[1], gpk = T.ypk[0], bpk = T.ypk[1];
-    const double ek = o.ek, fk = o.fk, ep = o.ep, fp = o.fp;
-    // A_kp = V_k conj(Y_kp V_p),  A_pk = V_p conj(Y_pk V_k),  A_kk = |V_k|^2 conj(Y_kk)
-    const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
-    const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
-    const double ur = gpk * ek - bpk * fk, ui = gpk * fk + bpk * ek;
-    const double apk_r = ep * ur + fp * ui, apk_i = fp * ur - ep * ui;
-    const double v2 = ek * ek + fk * fk;
-    const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
-    double aS0 = 0, aS1 = 0, aD0 = 0, aD1 = 0, aD2 = 0, aD3 = 0, aR0 = 0, aR1 = 0;
-    if (fl & S_CARRY_IN) { aS0 = cS0; aS1 = cS1; aD0 = cD0; aD1 = cD1; aD2 = cD2; aD3 = cD3; aR0 = cR0; aR1 = cR1; }
-    const int nch = (int)(fl >> 16);
-    for (int j = 0; j < nch; ++j) {
-      const double* c = cs + (size_t)clist[T.cptr + j] * 8 * L;
-      aS0 += c[0]; aS1 += c[L]; aD0 += c[2 * L]; aD1 += c[3 * L]; aD2 += c[4 * L]; aD3 += c[5 * L];
-      aR0 += c[6 * L]; aR1 += c[7 * L];
-    }
-    // S_k = V_k conj(sum_j Y_kj V_j), mismatch F_k = S_k - Sbus_k
-    const double sr = akk_r + akp_r + aS0, si = akk_i + akp_i + aS1;
-    const double Fp = sr - o.sr, Fq = si - o.si;
-    allok = allok && (fabs(Fp) < tol) && (fabs(Fq) < tol);
-    const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) - aD1;
-    const double D2 = (sr - akk_r) - aD2, D3 = (si + akk_i) - aD3;
-    const double r0 = Fp - aR0, r1 = Fq - aR1;
-    const double idet = rcp_nr(D0 * D3 - D1 * D2);
-    const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
-    const double h0 = I0 * r0 + I1 * r1, h1 = I2 * r0 + I3 * r1;
-    bst(h0, rs, vo[NF_H0], sb); bst(h1, rs, vo[NF_H1], sb);
-    if (!(fl & S_PARENT_ROOT)) {
-      // U = J'(k,p) = [[Im A_kp, Re A_kp], [-Re A_kp, Im A_kp]],  L = J'(p,k) likewise from A_pk
-      const double G0 = I0 * akp_i - I1 * akp_r, G1 = I0 * akp_r + I1 * akp_i;
-      const double G2 = I2 * akp_i - I3 * akp_r, G3 = I2 * akp_r + I3 * akp_i;
-      bst(G0, rs, vo[NF_G0], sb); bst(G1, rs, vo[NF_G1], sb); bst(G2, rs, vo[NF_G2], sb); bst(G3, rs, vo[NF_G3], sb);
-      const double s0 = apk_i * G0 + apk_r * G2, s1 = apk_i * G1 + apk_r * G3;
-      const double s2 = apk_i * G2 - apk_r * G0, s3 = apk_i * G3 - apk_r * G1;
-      const double t0 = apk_i * h0 + apk_r * h1, t1 = apk_i * h1 - apk_r * h0;
-      if (fl & S_CARRY_OUT) {
-        cS0 = apk_r; cS1 = apk_i; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
-      } else {
-        double* c = cs + (size_t)T.oslot * 8 * L;
-        c[0] = apk_r; c[L] = apk_i; c[2 * L] = s0; c[3 * L] = s1; c[4 * L] = s2; c[5 * L] = s3; c[6 * L] = t0; c[7 * L] = t1;
+    const uint32_t fl = __builtin_amdgcn_readfirstlane(T.flags);   // uniform value read through LDS -> SGPR
+    double h0 = 0, h1 = 0, G0 = 0, G1 = 0, G2 = 0, G3 = 0;
+    if (__builtin_amdgcn_readfirstlane(T.k) >= 0) {
+      const double gkk = T.ykk[0], bkk = T.ykk[1], gkp = T.ykp[0], bkp = T.ykp[1], gpk = T.ypk[0], bpk = T.ypk[1];
+      const double ek = o.ek, fk = o.fk, ep = o.ep, fp = o.fp;
+      // A_kp = V_k conj(Y_kp V_p),  A_pk = V_p conj(Y_pk V_k),  A_kk = |V_k|^2 conj(Y_kk)
+      const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
+      const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
+      const double ur = gpk * ek - bpk * fk, ui = gpk * fk + bpk * ek;
+      const double apk_r = ep * ur + fp * ui, apk_i = fp * ur - ep * ui;
+      const double v2 = ek * ek + fk * fk;
+      const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
+      double aS0 = 0, aS1 = 0, aD0 = 0, aD1 = 0, aD2 = 0, aD3 = 0, aR0 = 0, aR1 = 0;
+      if (fl & S_CARRY_IN) { aS0 = cS0; aS1 = cS1; aD0 = cD0; aD1 = cD1; aD2 = cD2; aD3 = cD3; aR0 = cR0; aR1 = cR1; }
+      const int nch = (int)(fl >> 16);
+      auto gather = [&](int slot) {
+        const double* c = cs + (size_t)slot * 8 * L;
+        aS0 += c[0]; aS1 += c[L]; aD0 += c[2 * L]; aD1 += c[3 * L]; aD2 += c[4 * L]; aD3 += c[5 * L];
+        aR0 += c[6 * L]; aR1 += c[7 * L];
+      };
+      if (nch > 0) gather(__builtin_amdgcn_readfirstlane(T.ch[0]));
+      if (nch > 1) gather(__builtin_amdgcn_readfirstlane(T.ch[1]));
+      if (nch > 2) gather(__builtin_amdgcn_readfirstlane(T.ch[2]));
+      if (nch > 3) {
+        const int cp = __builtin_amdgcn_readfirstlane(T.cptr);
+        for (int j = 3; j < nch; ++j) gather(__builtin_amdgcn_readfirstlane(s_clist[cp + j - 3]));
+      }
+      // S_k = V_k conj(sum_j Y_kj V_j), mismatch F_k = S_k - Sbus_k
+      const double sr = akk_r + akp_r + aS0, si = akk_i + akp_i + aS1;
+      const double Fp = sr - o.sr, Fq = si - o.si;
+      allok = allok && (fabs(Fp) < tol) && (fabs(Fq) < tol);
+      const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) - aD1;
+      const double D2 = (sr - akk_r) - aD2, D3 = (si + akk_i) - aD3;
+      const double r0 = Fp - aR0, r1 = Fq - aR1;
+      const double idet = rcp_nr(D0 * D3 - D1 * D2);
+      const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
+      h0 = I0 * r0 + I1 * r1; h1 = I2 * r0 + I3 * r1;
+      if (!(fl & S_PARENT_ROOT)) {
+        // U = J'(k,p) = [[Im A_kp, Re A_kp], [-Re A_kp, Im A_kp]],  L = J'(p,k) likewise from A_pk
+        G0 = I0 * akp_i - I1 * akp_r; G1 = I0 * akp_r + I1 * akp_i;
+        G2 = I2 * akp_i - I3 * akp_r; G3 = I2 * akp_r + I3 * akp_i;
+        const double s0 = apk_i * G0 + apk_r * G2, s1 = apk_i * G1 + apk_r * G3;
+        const double s2 = apk_i * G2 - apk_r * G0, s3 = apk_i * G3 - apk_r * G1;
+        const double t0 = apk_i * h0 + apk_r * h1, t1 = apk_i * h1 - apk_r * h0;
+        if (fl & S_CARRY_OUT) {
+          cS0 = apk_r; cS1 = apk_i; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
+        } else {
+          double* c = cs + (size_t)(__builtin_amdgcn_readfirstlane(T.slots) & 1023u) * 8 * L;
+          c[0] = apk_r; c[L] = apk_i; c[2 * L] = s0; c[3 * L] = s1; c[4 * L] = s2; c[5 * L] = s3; c[6 * L] = t0; c[7 * L] = t1;
+        }
       }
     }
+    bst(h0, rs, vo[NF_H0], sb); bst(h1, rs, vo[NF_H1], sb);
+    bst(G0, rs, vo[NF_G0], sb); bst(G1, rs, vo[NF_G1], sb); bst(G2, rs, vo[NF_G2], sb); bst(G3, rs, vo[NF_G3], sb);
   };
   auto bwd_step = [&](const StepRec& T, unsigned sb, const BwdOps& o) {
-    if (T.k < 0) return;
-    const uint32_t fl = T.flags;
-    double y0 = o.h0, y1 = o.h1, pe = 0.0, pf = 0.0;
-    if (!(fl & S_PARENT_ROOT)) {
-      double p0, p1;
-      if (fl & S_CARRY_OUT) { p0 = x0; p1 = x1; pe = xe; pf = xf; }
-      else { const double* xp = xs + (size_t)T.pxslot * 4 * L; p0 = xp[0]; p1 = xp[L]; pe = xp[2 * L]; pf = xp[3 * L]; }
-      y0 -= o.g0 * p0 + o.g1 * p1;
-      y1 -= o.g2 * p0 + o.g3 * p1;
+    const uint32_t fl = __builtin_amdgcn_readfirstlane(T.flags);
+    const uint32_t slots = __builtin_amdgcn_readfirstlane(T.slots);
+    // defaults = "write back what was loaded" (idle steps, converged lanes)
+    double va = o.va, vm = o.vm, en = o.e, fn = o.f, pe = vroot, pf = 0.0;
+    if (__builtin_amdgcn_readfirstlane(T.k) >= 0) {
+      double y0 = o.h0, y1 = o.h1;
+      if (!(fl & S_PARENT_ROOT)) {
+        double p0, p1;
+        if (fl & S_CARRY_OUT) { p0 = x0; p1 = x1; pe = xe; pf = xf; }
+        else { const double* xp = xs + (size_t)(slots >> 20) * 4 * L; p0 = xp[0]; p1 = xp[L]; pe = xp[2 * L]; pf = xp[3 * L]; }
+        y0 -= o.g0 * p0 + o.g1 * p1;
+        y1 -= o.g2 * p0 + o.g3 * p1;
+      }
+      // newtonpf update: Va += dx_a, Vm += dx_m, V = Vm e^{jVa}, Vm = |V|, Va = angle(V), with
+      // dx_a = -y0, dx_m = -|V| y1  =>  V <- V (1 - y1) e^{-j y0}   (rotation by the small step)
+      double s, c;
+      const double dth = -y0;
+      if (__any(!(fabs(dth) <= 0.5))) sincos(dth, &s, &c);       // wave-uniform, only when diverging
+      else sincos_small(dth, &s, &c);
+      const double sc = 1.0 - y1;
+      const double e2 = sc * (o.e * c - o.f * s), f2 = sc * (o.e * s + o.f * c);
+      double va2 = o.va + dth;
+      double vm2 = o.vm * sc;
+      if (vm2 < 0.0) { vm2 = -vm2; va2 += M_PI; }
+      if (va2 > M_PI) va2 -= 2.0 * M_PI;
+      else if (va2 <= -M_PI) va2 += 2.0 * M_PI;
+      if (!done) { va = va2; vm = vm2; en = e2; fn = f2; }
+      // children receive x and this node's voltage AS STORED (a converged lane keeps its old one)
+      x0 = y0; x1 = y1; xe = en; xf = fn;
+      if (fl & S_X_OUT) { double* xo = xs + (size_t)((slots >> 10) & 1023u) * 4 * L; xo[0] = y0; xo[L] = y1; xo[2 * L] = en; xo[3 * L] = fn; }
     }
-    // newtonpf update: Va += dx_a, Vm += dx_m, V = Vm e^{jVa}, Vm = |V|, Va = angle(V), with
-    // dx_a = -y0, dx_m = -|V| y1  =>  V <- V (1 - y1) e^{-j y0}   (rotation by the small step)
-    double s, c;
-    const double dth = -y0;
-    if (__any(!(fabs(dth) <= 0.5))) sincos(dth, &s, &c);       // wave-uniform, only when diverging
-    else sincos_small(dth, &s, &c);
-    const double sc = 1.0 - y1;
-    const double en = sc * (o.e * c - o.f * s), fn = sc * (o.e * s + o.f * c);
-    x0 = y0; x1 = y1; xe = en; xf = fn;
-    if (fl & S_X_OUT) { double* xo = xs + (size_t)T.xslot * 4 * L; xo[0] = y0; xo[L] = y1; xo[2 * L] = en; xo[3 * L] = fn; }
-    double va = o.va + dth;
-    double vm = o.vm * sc;
-    if (vm < 0.0) { vm = -vm; va += M_PI; }
-    if (va > M_PI) va -= 2.0 * M_PI;
-    else if (va <= -M_PI) va += 2.0 * M_PI;
-    if (!done) {
-      bst(va, rs, vo[NF_VA], sb); bst(vm, rs, vo[NF_VM], sb); bst(en, rs, vo[NF_EK], sb); bst(fn, rs, vo[NF_FK], sb);
-      if (!(fl & S_PARENT_ROOT)) { bst(pe, rs, vo[NF_EP], sb); bst(pf, rs, vo[NF_FP], sb); }
-    }
+    // a converged lane must keep its state: its block is rewritten with the values it already holds
+    // (ep/fp of a converged lane equal the parent's committed voltage, which pe/pf then still carry)
+    bst(va, rs, vo[NF_VA], sb); bst(vm, rs, vo[NF_VM], sb); bst(en, rs, vo[NF_EK], sb); bst(fn, rs, vo[NF_FK], sb);
+    bst(pe, rs, vo[NF_EP], sb); bst(pf, rs, vo[NF_FP], sb);
   };
 
   for (;;) {
     // ------------------------------------------------------------------ forward sweep
-    // rows are processed in pairs with ping-pong operand sets (A/B): the loads of row r+1 are in
-    // flight while row r computes, without register copies.
+    // software pipeline of depth 2: while row r computes, the operand loads of rows r+1 and r+2 are
+    // in flight (three rotating operand/record sets, loop unrolled by 3 so the rotation is static);
+    // the operand blocks live beyond L2 (Infinity Cache / HBM latency > one row of compute).
     allok = true;
     cS0 = cS1 = cD0 = cD1 = cD2 = cD3 = cR0 = cR1 = 0.0;
     {
-      StepRec TA = rec(0), TB;
-      FwdOps oA = {}, oB = {};
+      StepRec T0 = seq[0], T1 = seq[R > 1 ? 1 : 0], T2;
+      FwdOps o0 = {}, o1 = {}, o2 = {};
       unsigned sb = sb0;
-      load_fwd(sb, oA);
+      load_fwd(sb, o0);
+      if (R > 1) load_fwd(sb + bb, o1);
       int r = 0;
-      for (; r + 1 < R; r += 2) {
-        TB = rec(r + 1); load_fwd(sb + bb, oB);
-        fwd_step(TA, sb, oA);
+      for (; r + 2 < R; r += 3) {
+        T2 = seq[r + 2]; load_fwd(sb + 2 * bb, o2);
+        fwd_step(T0, sb, o0);
         if (W > 1) lds_barrier();
-        if (r + 2 < R) { TA = rec(r + 2); load_fwd(sb + 2 * bb, oA); }
-        fwd_step(TB, sb + bb, oB);
+        if (r + 3 < R) { T0 = seq[r + 3]; load_fwd(sb + 3 * bb, o0); }
+        fwd_step(T1, sb + bb, o1);
         if (W > 1) lds_barrier();
-        sb += 2 * bb;
+        if (r + 4 < R) { T1 = seq[r + 4]; load_fwd(sb + 4 * bb, o1); }
+        fwd_step(T2, sb + 2 * bb, o2);
+        if (W > 1) lds_barrier();
+        sb += 3 * bb;
       }
-      if (r < R) { fwd_step(TA, sb, oA); if (W > 1) lds_barrier(); }
+      if (r < R) { fwd_step(T0, sb, o0); if (W > 1) lds_barrier(); }
+      if (r + 1 < R) { fwd_step(T1, sb + bb, o1); if (W > 1) lds_barrier(); }
     }
     if (W > 1) {                                 // AND of the per-wave verdicts, per env
       s_ok[w * 64 + lane] = allok ? 1 : 0;
@@ -365,21 +385,26 @@ __global__ void __launch_bounds__(64 * W) k_nr_wtree(Dev d) {
     // ------------------------------------------------------------------ backward sweep + update
     x0 = x1 = xe = xf = 0.0;
     {
-      StepRec TA = rec(R - 1), TB;
-      BwdOps oA = {}, oB = {};
+      StepRec T0 = seq[R - 1], T1 = seq[R > 1 ? R - 2 : 0], T2;
+      BwdOps o0 = {}, o1 = {}, o2 = {};
       unsigned sb = sb0 + (unsigned)(R - 1) * bb;
-      load_bwd(sb, oA);
+      load_bwd(sb, o0);
+      if (R > 1) load_bwd(sb - bb, o1);
       int r = R - 1;
-      for (; r - 1 >= 0; r -= 2) {
-        TB = rec(r - 1); load_bwd(sb - bb, oB);
-        bwd_step(TA, sb, oA);
+      for (; r - 2 >= 0; r -= 3) {
+        T2 = seq[r - 2]; load_bwd(sb - 2 * bb, o2);
+        bwd_step(T0, sb, o0);
         if (W > 1) lds_barrier();
-        if (r - 2 >= 0) { TA = rec(r - 2); load_bwd(sb - 2 * bb, oA); }
-        bwd_step(TB, sb - bb, oB);
+        if (r - 3 >= 0) { T0 = seq[r - 3]; load_bwd(sb - 3 * bb, o0); }
+        bwd_step(T1, sb - bb, o1);
         if (W > 1) lds_barrier();
-        sb -= 2 * bb;
+        if (r - 4 >= 0) { T1 = seq[r - 4]; load_bwd(sb - 4 * bb, o1); }
+        bwd_step(T2, sb - 2 * bb, o2);
+        if (W > 1) lds_barrier();
+        sb -= 3 * bb;
       }
-      if (r >= 0) { bwd_step(TA, sb, oA); if (W > 1) lds_barrier(); }
+      if (r >= 0) { bwd_step(T0, sb, o0); if (W > 1) lds_barrier(); }
+      if (r - 1 >= 0) { bwd_step(T1, sb - bb, o1); if (W > 1) lds_barrier(); }
     }
     if (!done) ++it;
   }
@@ -450,7 +475,8 @@ __global__ void __launch_bounds__(256) k_commit(Dev d, int mode) {
 // =================================================================================================
 // K7  reward — VoltageControl._calc_reward (voltage_control_env.py:574-623) on the committed (or,
 //     if the solve failed, rolled-back == previous) state, the unsolvable branch (:188-196) and
-//     step() bookkeeping (:199-209).  thread = env; the loops are independent coalesced loads.
+//     step() bookkeeping (:199-209).  A 64-env group is served by RWJ waves that each reduce a
+//     strided share of the buses / lines; partials are combined through LDS in a fixed order.
 // =================================================================================================
 __device__ __forceinline__ double barrier(int type, double v) {
   switch (type) {
@@ -475,52 +501,68 @@ __device__ __forceinline__ double barrier(int type, double v) {
   }
 }
 
-__global__ void __launch_bounds__(64)
+#define RWJ 8   // waves (bus partitions) per 64-env group in k_reward
+__global__ void __launch_bounds__(64 * RWJ)
 k_reward(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ terminated, double* __restrict__ info) {
-  const int e = blockIdx.x * 64 + threadIdx.x;
-  if (e >= d.B) return;
+  __shared__ double sm[8][RWJ][64];
+  const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  const bool valid = e < d.B;
   const size_t S = (size_t)d.Bp;
-  d.adv_row[e] = -1;
   if (mode == MODE_RESET) {
-    if (d.pending[e] && d.conv[e]) { d.pending[e] = 0; d.done[e] = 0; }
+    if (j == 0 && valid) {
+      d.adv_row[e] = -1;
+      if (d.pending[e] && d.conv[e]) { d.pending[e] = 0; d.done[e] = 0; }
+    }
     return;
   }
-  if (d.done[e]) {                                 // frozen env
+  const bool frozen = valid && d.done[e] != 0;
+  const double vlo = d.v_lower, vhi = d.v_upper, vref = 0.5 * (vlo + vhi);
+  // ---- partial statistics of this wave's share of the buses / lines (strided, coalesced over envs)
+  double n_lo = 0, n_hi = 0, dev = 0.0, vsum = 0.0, mdrop = 0.0, mrise = 0.0, bar = 0.0, line_loss = 0.0;
+  if (valid && !frozen) {
+    for (int b = j; b < d.nb; b += RWJ) {
+      const double v = d.vm[(size_t)b * S + e];
+      n_lo += (v < vlo) ? 1.0 : 0.0; n_hi += (v > vhi) ? 1.0 : 0.0;
+      dev += fabs(v - vref); vsum += v;
+      mdrop = fmax(mdrop, (v < vlo) ? (vlo - v) : 0.0);
+      mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
+      bar += barrier(d.barrier_type, v);
+    }
+    for (int l = j; l < d.n_line; l += RWJ) line_loss += d.pl[(size_t)l * S + e];
+  }
+  sm[0][j][lane] = n_lo; sm[1][j][lane] = n_hi; sm[2][j][lane] = dev; sm[3][j][lane] = vsum;
+  sm[4][j][lane] = mdrop; sm[5][j][lane] = mrise; sm[6][j][lane] = bar; sm[7][j][lane] = line_loss;
+  __syncthreads();
+  if (j != 0 || !valid) return;
+  d.adv_row[e] = -1;
+  if (frozen) {                                  // frozen env
     reward[e] = 0.0; terminated[e] = 1;
     for (int c = 0; c < MAPDN_N_INFO; ++c) info[(size_t)e * MAPDN_N_INFO + c] = 0.0;
     return;
   }
-  const bool ok = d.conv[e] != 0;
-  const double vlo = d.v_lower, vhi = d.v_upper, vref = 0.5 * (vlo + vhi);
-  int n_lo = 0, n_hi = 0;
-  double dev = 0.0, vsum = 0.0, mdrop = 0.0, mrise = 0.0, bar = 0.0;
-#pragma unroll 4
-  for (int b = 0; b < d.nb; ++b) {
-    const double v = d.vm[(size_t)b * S + e];
-    n_lo += (v < vlo); n_hi += (v > vhi);
-    dev += fabs(v - vref); vsum += v;
-    mdrop = fmax(mdrop, (v < vlo) ? (vlo - v) : 0.0);
-    mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
-    bar += barrier(d.barrier_type, v);
+#pragma unroll
+  for (int w = 1; w < RWJ; ++w) {                // fixed combination order: deterministic
+    n_lo += sm[0][w][lane]; n_hi += sm[1][w][lane]; dev += sm[2][w][lane]; vsum += sm[3][w][lane];
+    mdrop = fmax(mdrop, sm[4][w][lane]); mrise = fmax(mrise, sm[5][w][lane]); bar += sm[6][w][lane];
+    line_loss += sm[7][w][lane];
   }
-  double line_loss = 0.0;
-#pragma unroll 8
-  for (int l = 0; l < d.n_line; ++l) line_loss += d.pl[(size_t)l * S + e];
+  const bool ok = d.conv[e] != 0;
   double q_loss = 0.0, q_fail = 0.0;
-  for (int j = 0; j < d.ns; ++j) {
-    q_loss += fabs(d.cur_q[(size_t)j * S + e]);
-    q_fail += fabs(d.q_new[(size_t)j * S + e]);                                // :189
+  for (int jj = 0; jj < d.ns; ++jj) {
+    q_loss += fabs(d.cur_q[(size_t)jj * S + e]);
+    q_fail += fabs(d.q_new[(size_t)jj * S + e]);                               // :189
   }
   q_loss /= (double)d.ns; q_fail /= (double)d.ns;
   const double inv_nb = 1.0 / (double)d.nb;
-  const double out = (double)(n_lo + n_hi) / (double)d.nb;
+  const double out = (n_lo + n_hi) / (double)d.nb;
   const double v_loss = bar * inv_nb * d.voltage_weight;
   double loss;
   if (d.use_line_weight) loss = line_loss / (double)d.n_line * d.line_weight + v_loss;   // :612-613
   else loss = q_loss * d.q_weight + v_loss;                                              // :614-615
   double rew = -loss;
   double* inf = info + (size_t)e * MAPDN_N_INFO;
-  inf[0] = out; inf[1] = (double)n_lo / (double)d.nb; inf[2] = (double)n_hi / (double)d.nb;
+  inf[0] = out; inf[1] = n_lo / (double)d.nb; inf[2] = n_hi / (double)d.nb;
   inf[3] = (out > 1e-3) ? 0.0 : 1.0;
   inf[4] = dev * inv_nb; inf[5] = vsum * inv_nb; inf[6] = mdrop; inf[7] = mrise;
   inf[8] = line_loss; inf[9] = q_loss; inf[10] = 0.0;
@@ -605,7 +647,8 @@ __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise) {
 // =================================================================================================
 // K8  observe — get_obs (voltage_control_env.py:232-274) / get_state (:213-230).
 //     k_addback: effective PV add-back onto res_bus p/q at sgen buses (:238-244).
-//     k_gather : column descriptors (kind, index) -> env-major output through a 64x64 LDS tile so
+//     k_gather : per output column a precomputed source row of the state block (-1 = zero pad) and
+//                a scale -> env-major output through a 64x64 LDS tile so
 //                both the env-minor reads and the env-major writes are coalesced.
 // =================================================================================================
 __global__ void __launch_bounds__(256) k_addback(Dev d) {
@@ -624,21 +667,21 @@ __global__ void __launch_bounds__(256) k_addback(Dev d) {
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_gather(GatherSrc g, const int32_t* __restrict__ kind, const int32_t* __restrict__ idx, T* __restrict__ out,
-         int C, int B, int Bp) {
+k_gather(const double* __restrict__ base, const int32_t* __restrict__ rows, const double* __restrict__ scales,
+         double scale_all, T* __restrict__ out, int C, int B, int Bp) {
   __shared__ double tile[64][65];
   const int c0 = blockIdx.x * 64, e0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int r = ty; r < 64; r += 4) {
-    const int c = c0 + r;
-    double v = 0.0;
-    if (c < C) {
-      const int kd = kind[c];
-      const double* base = g.base[kd];
-      if (base) v = base[(size_t)idx[c] * Bp + e0 + tx] * g.scale[kd];
-    }
-    tile[r][tx] = v;
+  int rw[16]; double sc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {                 // all descriptor reads first (independent), then the data
+    const int c = c0 + ty + 4 * i;
+    rw[i] = (c < C) ? rows[c] : -1;
+    sc[i] = (scales && c < C) ? scales[c] : scale_all;
   }
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    tile[ty + 4 * i][tx] = (rw[i] >= 0) ? base[(size_t)rw[i] * Bp + e0 + tx] * sc[i] : 0.0;
   __syncthreads();
   for (int r = ty; r < 64; r += 4) {
     const int e = e0 + r, c = c0 + tx;
@@ -693,16 +736,15 @@ __global__ void __launch_bounds__(256) k_stats(Dev d, long long* out) {
 // =================================================================================================
 static inline dim3 grid_env(const Dev& d, int y) { return dim3((d.Bp + 255) / 256, y); }
 
-void launch_qnew(const Dev& d, const void* actions, int dtype, int mode, hipStream_t st) {
-  if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_qnew<float>, grid_env(d, d.ns), dim3(256), 0, st, d, (const float*)actions, mode);
-  else hipLaunchKernelGGL(k_qnew<double>, grid_env(d, d.ns), dim3(256), 0, st, d, (const double*)actions, mode);
-}
-void launch_sbus(const Dev& d, const double* pl, const double* ql, const double* pv, const double* q, hipStream_t st) {
-  hipLaunchKernelGGL(k_sbus, grid_env(d, d.n), dim3(256), 0, st, d, pl, ql, pv, q);
+void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,
+                   const double* pv, const double* q, hipStream_t st) {
+  const dim3 grid((d.Bp + 255) / 256, d.nb);
+  if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_inject<float>, grid, dim3(256), 0, st, d, mode, (const float*)actions, pl, ql, pv, q);
+  else hipLaunchKernelGGL(k_inject<double>, grid, dim3(256), 0, st, d, mode, (const double*)actions, pl, ql, pv, q);
 }
 void launch_nr(const Dev& d, hipStream_t st) {
   const dim3 grid(d.Bp / d.nr_lanes);
-  const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.nr_cslots, d.nr_xslots);
+  const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.nr_cslots, d.nr_xslots, d.nr_rows, d.nr_nclist);
   switch (d.nr_waves) {
     case 1: hipLaunchKernelGGL(k_nr_wtree<1>, grid, dim3(64), lds, st, d); break;
     case 2: hipLaunchKernelGGL(k_nr_wtree<2>, grid, dim3(128), lds, st, d); break;
@@ -727,7 +769,7 @@ void launch_commit(const Dev& d, int mode, hipStream_t st) {
   hipLaunchKernelGGL(k_commit, dim3((d.B + 255) / 256, d.nb + d.n_line + d.ns), dim3(256), 0, st, d, mode);
 }
 void launch_reward(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
-  hipLaunchKernelGGL(k_reward, dim3(d.Bp / 64), dim3(64), 0, st, d, mode, reward, term, info);
+  hipLaunchKernelGGL(k_reward, dim3(d.Bp / 64), dim3(64 * RWJ), 0, st, d, mode, reward, term, info);
 }
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st) {
   hipLaunchKernelGGL(k_reset_begin, dim3((d.B + 255) / 256), dim3(256), 0, st, d, start_rows, first_try);
@@ -739,10 +781,11 @@ void launch_advance(const Dev& d, int add_noise, hipStream_t st) {
 void launch_addback(const Dev& d, hipStream_t st) {
   hipLaunchKernelGGL(k_addback, grid_env(d, d.nb), dim3(256), 0, st, d);
 }
-void launch_gather(const Dev& d, const GatherSrc& g, const int32_t* kind, const int32_t* idx, void* out, int dtype, int C, hipStream_t st) {
+void launch_gather(const Dev& d, const double* base, const int32_t* rows, const double* scales, double scale_all,
+                   void* out, int dtype, int C, hipStream_t st) {
   dim3 grid((C + 63) / 64, d.Bp / 64);
-  if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_gather<float>, grid, dim3(256), 0, st, g, kind, idx, (float*)out, C, d.B, d.Bp);
-  else hipLaunchKernelGGL(k_gather<double>, grid, dim3(256), 0, st, g, kind, idx, (double*)out, C, d.B, d.Bp);
+  if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_gather<float>, grid, dim3(256), 0, st, base, rows, scales, scale_all, (float*)out, C, d.B, d.Bp);
+  else hipLaunchKernelGGL(k_gather<double>, grid, dim3(256), 0, st, base, rows, scales, scale_all, (double*)out, C, d.B, d.Bp);
 }
 void launch_to_envminor(const Dev& d, const double* src, double* dst, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_to_envminor, dim3((n + 63) / 64, d.Bp / 64), dim3(256), 0, st, src, dst, n, d.B, d.Bp);

@@ -7,7 +7,7 @@
 
 namespace mapdn {
 
-enum { MODE_STEP = 0, MODE_RESET = 1 };
+enum { MODE_STEP = 0, MODE_RESET = 1, MODE_SOLVE = 2 };
 enum { STREAM_PV = 0, STREAM_LOAD_P = 1, STREAM_LOAD_Q = 2, STREAM_ACTION = 3, STREAM_START = 4 };
 
 // Fields of one NR operand block.  Every (wave, row) step of the elimination schedule owns one
@@ -37,6 +37,9 @@ struct Dev {
   uint32_t seed_lo, seed_hi; int64_t env_id_offset;
   // ---- env state
   double *cur_pv, *cur_q, *cur_pl, *cur_ql, *q_new;   // [ns|nl][Bp]  MW / MVAr
+  // gatherable state lives in ONE block `gbuf` (rows of Bp doubles) so obs/state columns are plain row
+  // numbers: pb qb [nb] | cur_pv cur_q [ns] | vm va res_p res_q [nb]   (pointers below alias into it)
+  double* gbuf;
   double *vm, *va, *res_p, *res_q;                    // [nb][Bp] by bus id; va in rad
   double *pb, *qb;                                    // [nb][Bp] res_bus p/q with PV add-back
   double *pl;                                         // [n_line][Bp] res_line.pl_mw
@@ -49,29 +52,27 @@ struct Dev {
   const int32_t* blk_of_pos;                          // [n+1] elimination position -> block
   int32_t* iters; uint8_t* conv;
   // ---- NR schedule (k_nr_wtree): W waves per env group, L envs per wave, R rows
-  int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots;
+  int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots, nr_nclist;
   const StepRec* sched; const int32_t* clist;
 };
 
-struct GatherSrc {
-  const double* base[G_NKIND];
-  double scale[G_NKIND];
-};
-
-void launch_qnew(const Dev& d, const void* actions, int dtype, int mode, hipStream_t st);
-void launch_sbus(const Dev& d, const double* pl, const double* ql, const double* pv, const double* q, hipStream_t st);
+void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,
+                   const double* pv, const double* q, hipStream_t st);
 void launch_nr(const Dev& d, hipStream_t st);
 int nr_set_lds_limit(int waves, size_t bytes);
-// dynamic LDS of k_nr_wtree: contribution slots (8 doubles/env), x slots (4 doubles/env), verdict bytes
-static inline size_t nr_lds_bytes(int W, int L, int cslots, int xslots) {
-  return ((size_t)cslots * 8 + (size_t)xslots * 4) * (size_t)L * sizeof(double) + (size_t)W * 64;
+// dynamic LDS of k_nr_wtree: contribution slots (8 doubles/env), x slots (4 doubles/env), verdict
+// bytes, the W*R step records and the overflow child list
+static inline size_t nr_lds_bytes(int W, int L, int cslots, int xslots, int R, int nclist) {
+  return ((size_t)cslots * 8 + (size_t)xslots * 4) * (size_t)L * sizeof(double) + (size_t)W * 64 +
+         (size_t)W * R * sizeof(StepRec) + (size_t)nclist * sizeof(int32_t);
 }
 void launch_commit(const Dev& d, int mode, hipStream_t st);
 void launch_reward(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);
 void launch_advance(const Dev& d, int add_noise, hipStream_t st);
 void launch_addback(const Dev& d, hipStream_t st);
-void launch_gather(const Dev& d, const GatherSrc& g, const int32_t* kind, const int32_t* idx, void* out, int dtype, int C, hipStream_t st);
+void launch_gather(const Dev& d, const double* base, const int32_t* rows, const double* scales, double scale_all,
+                   void* out, int dtype, int C, hipStream_t st);
 void launch_to_envminor(const Dev& d, const double* src, double* dst, int n, hipStream_t st);
 void launch_copy_i32(const int32_t* s, int32_t* dd, int B, hipStream_t st);
 void launch_copy_u8(const uint8_t* s, uint8_t* dd, int B, hipStream_t st);

@@ -337,18 +337,21 @@ void build_schedule(const Plan& P, int W, Schedule& S) {
       if (k < 0) continue;
       const double* c = &P.yc[(size_t)k * 6];
       T.ykk[0] = c[0]; T.ykk[1] = c[1]; T.ykp[0] = c[2]; T.ykp[1] = c[3]; T.ypk[0] = c[4]; T.ypk[1] = c[5];
-      T.p = P.par[k];
-      uint32_t f = 0;
-      if (T.p == n) f |= S_PARENT_ROOT;
+      const int p = P.par[k];
+      uint32_t f = 0, os = 0, xsl = 0, pxs = 0;
+      if (p == n) f |= S_PARENT_ROOT;
       else if (carry_out[k]) f |= S_CARRY_OUT;
-      else { f |= S_SCRATCH_OUT; T.oslot = oslot[k]; T.pxslot = xslot[T.p]; }
-      T.cptr = (int32_t)S.clist.size();
-      uint32_t cnt = 0;
+      else { f |= S_SCRATCH_OUT; os = (uint32_t)oslot[k]; pxs = (uint32_t)xslot[p]; }
+      std::vector<int> kids;
       const int cc = chain_child(k);
-      if (cc >= 0) { if (carry_out[cc]) f |= S_CARRY_IN; else { S.clist.push_back(oslot[cc]); ++cnt; } }
-      for (int ch : children[k]) if (ch != cc) { S.clist.push_back(oslot[ch]); ++cnt; }
-      if (xslot[k] >= 0) { f |= S_X_OUT; T.xslot = xslot[k]; }
-      T.flags = f | (cnt << 16);
+      if (cc >= 0) { if (carry_out[cc]) f |= S_CARRY_IN; else kids.push_back(oslot[cc]); }
+      for (int ch : children[k]) if (ch != cc) kids.push_back(oslot[ch]);
+      for (size_t j = 0; j < kids.size() && j < 3; ++j) T.ch[j] = kids[j];
+      T.cptr = (int32_t)S.clist.size();
+      for (size_t j = 3; j < kids.size(); ++j) S.clist.push_back(kids[j]);
+      if (xslot[k] >= 0) { f |= S_X_OUT; xsl = (uint32_t)xslot[k]; }
+      T.slots = os | (xsl << 10) | (pxs << 20);
+      T.flags = f | ((uint32_t)kids.size() << 16);
     }
   if (S.clist.empty()) S.clist.push_back(0);
 }

@@ -32,19 +32,19 @@ enum : int32_t {
   G_P = 7, G_Q = 8, G_VA_DEG = 9, G_NKIND = 10
 };
 
-// One step of one wave of the NR kernel (80 bytes, wave-uniform, prefetched one row ahead).
+// One step of one wave of the NR kernel: 80 bytes, wave-uniform.  The kernel copies its wave's
+// records into LDS once and prefetches them a row ahead with ds_read (in-order LGKM returns).
 // flags: S_* in the low 16 bits, number of LDS-slot children to gather in the high 16 bits.
 struct StepRec {
   double ykk[2], ykp[2], ypk[2];
-  int32_t k;        // node position, -1 = idle step
-  int32_t p;        // parent position (n == root)
   uint32_t flags;
-  int32_t cptr;     // first entry of this node's children-slot list
-  int32_t oslot;    // LDS contribution slot this node writes (S_SCRATCH_OUT)
-  int32_t xslot;    // LDS x slot this node writes in the backward sweep (S_X_OUT)
-  int32_t pxslot;   // LDS x slot of the parent (read when the parent's x is not carried)
+  uint32_t slots;   // oslot | xslot << 10 | pxslot << 20 : LDS slots this node writes (contribution, x) / its parent's x slot
+  int32_t ch[3];    // contribution slots of the first three children to gather (canonical order)
+  int32_t cptr;     // overflow list (children 3..) in Schedule::clist
+  int32_t k;        // node position, -1 = idle step
   int32_t pad;
 };
+static_assert(sizeof(StepRec) == 80, "StepRec must be 80 bytes (5 x ds_read_b128)");
 
 // schedule-step flags (wave-uniform control flow in the NR kernel)
 enum : uint32_t {

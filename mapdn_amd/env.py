@@ -110,7 +110,7 @@ class VoltageControlBatch:
             p.n_rows, p.time_delta_min, p.days), self._h)
         B, dv = self.n_envs, self.device
         self._reward = torch.zeros(B, dtype=torch.float64, device=dv)
-        self._term = torch.zeros(B, dtype=torch.uint8, device=dv)
+        self._term = torch.zeros(B, dtype=torch.bool, device=dv)     # 1 byte per env, written as 0/1 by the kernel
         self._info = torch.zeros(B, N_INFO, dtype=torch.float64, device=dv)
         self._obs = {}
         self._state = {}
@@ -188,7 +188,7 @@ class VoltageControlBatch:
             _lib.check(self._lib.mapdn_step(self._h, a.data_ptr(), self._code(a.dtype), int(add_noise),
                                             self._reward.data_ptr(), self._term.data_ptr(), self._info.data_ptr(),
                                             self._stream()), self._h)
-        return self._out(self._reward), self._out(self._term).bool(), self._out(self._info)
+        return self._out(self._reward), self._out(self._term), self._out(self._info)
 
     def get_obs(self, dtype=None):
         dtype = dtype or self.obs_dtype
