@@ -68,15 +68,16 @@ static int dupload(mapdn_handle* h, const T** p, const std::vector<T>& v) {
   return MAPDN_OK;
 }
 
-// waves per env group / envs per wave for a padded batch of Bp envs (MI355X: 256 CUs x 4 SIMDs)
-static void choose_nr_geometry(int Bp, int& W, int& L) {
-  const int groups64 = Bp / 64;
-  if (groups64 >= 2048) { W = 1; L = 64; }
-  else if (groups64 >= 1024) { W = 2; L = 64; }
-  else if (groups64 >= 512) { W = 4; L = 64; }
-  else if (groups64 >= 128) { W = 8; L = 64; }
-  else if (groups64 >= 64) { W = 8; L = 32; }
-  else { W = 8; L = 16; }
+// NR launch geometry for a padded batch of Bp envs on a net with n non-slack buses (MI355X: 256 CUs
+// x 4 SIMDs).  Tuned on case33/141/322 (tools/sweep_nr.sh): ~8 workers per env is the knee of the
+// Hu schedule for feeders of 100-300 buses; keep >= ~512 workgroups while envs per workgroup <= 64.
+static void choose_nr_geometry(int Bp, int n, int& W, int& L) {
+  W = 1;
+  if (Bp >= 65536) L = 64;
+  else if (Bp >= 32768) L = 32;
+  else if (Bp >= 16384) L = 16;
+  else L = 8;
+  if (n < 48 && L < 16) L = 16;          // small feeders: 4 workers are enough
 }
 
 extern "C" {
@@ -170,42 +171,41 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   rc = dalloc(h, &h->t_pv, (size_t)d.ns * Bp); if (rc) return rc;
   rc = dalloc(h, &h->t_q, (size_t)d.ns * Bp); if (rc) return rc;
   rc = dalloc(h, &h->stats_dev, 4); if (rc) return rc;
-  // ---- NR launch geometry: W waves per env group x L envs per wave.  Small batches are spread
-  // over more wavefronts (idle SIMDs are free); big batches use full 64-env waves with one worker.
-  // Override with MAPDN_NR_WAVES / MAPDN_NR_LANES.
+  // ---- NR launch geometry: a workgroup = W waves serving L envs; each wave carries 64/L lane-group
+  // workers, so Wt = W*64/L workers eliminate independent subtrees of every env concurrently.
+  // Small batches get few envs per workgroup (many workgroups, all lanes busy with intra-env
+  // parallelism); big batches get L = 64 (pure env parallelism).  Override: MAPDN_NR_WAVES / MAPDN_NR_LANES.
   int W, L;
-  choose_nr_geometry(d.Bp, W, L);
+  choose_nr_geometry(d.Bp, P.n, W, L);
   if (const char* s = getenv("MAPDN_NR_WAVES")) W = atoi(s);
   if (const char* s = getenv("MAPDN_NR_LANES")) L = atoi(s);
-  if (!(W == 1 || W == 2 || W == 4 || W == 8 || W == 16) || !(L == 64 || L == 32 || L == 16)) {
-    h->err = "MAPDN_NR_WAVES must be 1/2/4/8/16 and MAPDN_NR_LANES 64/32/16"; return MAPDN_E_INVALID; }
-  build_schedule(P, W, h->sched);
+  if (!(W == 1 || W == 2 || W == 4 || W == 8 || W == 16) || !(L == 64 || L == 32 || L == 16 || L == 8 || L == 4)) {
+    h->err = "MAPDN_NR_WAVES must be 1/2/4/8/16 and MAPDN_NR_LANES 64/32/16/8/4"; return MAPDN_E_INVALID; }
+  const int Wt = W * (64 / L);
+  build_schedule(P, Wt, h->sched);
   if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
-  // LDS budget (160 KB per CU on gfx950): halve the envs per wave until the slots fit
   const int ncl = (int)h->sched.clist.size();
-  auto lds_need = [&](int l) { return nr_lds_bytes(W, l, h->sched.n_cslots, h->sched.n_xslots, h->sched.R, ncl); };
-  while (L > 16 && lds_need(L) > 160 * 1024) L /= 2;
-  if (lds_need(L) > 160 * 1024) { h->err = "NR schedule needs more LDS than one CU has; lower MAPDN_NR_WAVES"; return MAPDN_E_INVALID; }
+  const size_t lds_need = nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, h->sched.R, ncl);
+  if (lds_need > 160 * 1024) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
   d.nr_waves = W; d.nr_lanes = L;
   d.nr_rows = h->sched.R; d.nr_cslots = h->sched.n_cslots; d.nr_xslots = h->sched.n_xslots; d.nr_nclist = ncl;
-  if (nr_set_lds_limit(W, lds_need(L)) != 0) {
+  if (nr_set_lds_limit(W, lds_need) != 0) {
     h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return MAPDN_E_HIP; }
   UP(sched, h->sched.steps); UP(clist, h->sched.clist);
-  {  // operand blocks: one per (wave,row) step + one for the slack bus; a single buffer resource addresses them
-    const int nblk = W * h->sched.R;
-    std::vector<int32_t> blk(P.n + 1, nblk);
-    for (int i = 0; i < nblk; ++i) { const int k = h->sched.steps[i].k; if (k >= 0) blk[k] = i; }
-    UP(blk_of_pos, blk);
-    const size_t rows = (size_t)(nblk + 1) * NRF, bytes = rows * Bp * sizeof(double);
+  {  // NR scratch: factor blocks (one per (worker,row) step) | Sbus | Vout; a single buffer resource addresses it
+    const int nblk = Wt * h->sched.R;
+    d.r_sbus = (uint32_t)nblk * NBF;
+    d.r_vout = d.r_sbus + 2u * (uint32_t)P.n;
+    const size_t rows = (size_t)d.r_vout + (size_t)VOF * (P.n + 1), bytes = rows * Bp * sizeof(double);
     if (bytes >= (size_t)0xFFFFFFFFu) { h->err = "env batch too large: NR scratch exceeds the 4 GiB one buffer resource addresses; use fewer envs per handle"; return MAPDN_E_INVALID; }
     rc = dalloc(h, &d.nrbuf, rows * Bp); if (rc) return rc;
     d.nrbuf_bytes = (uint32_t)bytes;
-    std::vector<double> row(Bp, d.vroot);   // slack block: V = vroot + 0j (va = 0 from the memset)
-    double* rootblk = d.nrbuf + (size_t)nblk * NRF * Bp;
-    HIPCHK(h, hipMemcpy(rootblk + (size_t)NF_EK * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(rootblk + (size_t)NF_VM * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> row(Bp, d.vroot);   // slack entry of Vout: V = vroot + 0j (angle 0 from the memset)
+    double* rootv = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * P.n) * Bp;
+    HIPCHK(h, hipMemcpy(rootv + (size_t)VO_E * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(rootv + (size_t)VO_VM * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
     std::vector<int32_t> vmrow(P.nb), varow(P.nb);
-    for (int b = 0; b < P.nb; ++b) { const int bi = blk[P.pos_of_bus[b]]; vmrow[b] = bi * NRF + NF_VM; varow[b] = bi * NRF + NF_VA; }
+    for (int b = 0; b < P.nb; ++b) { const int k = P.pos_of_bus[b]; vmrow[b] = (int)d.r_vout + VOF * k + VO_VM; varow[b] = (int)d.r_vout + VOF * k + VO_VA; }
     rc = dupload(h, &tmp, vmrow); if (rc) return rc; h->vm_row = (int32_t*)tmp;
     rc = dupload(h, &tmp, varow); if (rc) return rc; h->va_row = (int32_t*)tmp;
   }

@@ -88,9 +88,9 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
     P -= p; Q -= q;
   }
   if (k < d.n) {
-    double* blk = d.nrbuf + (size_t)d.blk_of_pos[k] * NRF * d.Bp + e;
-    blk[(size_t)NF_SR * d.Bp] = -P / d.sn;
-    blk[(size_t)NF_SI * d.Bp] = -Q / d.sn;
+    double* sb = d.nrbuf + ((size_t)d.r_sbus + 2 * (size_t)k) * d.Bp + e;
+    sb[0] = -P / d.sn;
+    sb[d.Bp] = -Q / d.sn;
   }
 }
 
@@ -111,27 +111,29 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
 //  an independent subtree (or idles), so the critical path per sweep is ~tree depth instead of n.
 //  A wave may use only its first L lanes (64/32/16) so that small batches still cover many CUs.
 //
-//  Data movement:
-//   * every (wave,row) step owns one OPERAND BLOCK in global scratch, [ek fk ep fp sr si va vm h0 h1
-//     G0..G3][Bp] — own voltage, PARENT's voltage, Sbus, LU factors — addressed as
-//     block(w,r) + field through one buffer resource (scalar base, loop-invariant lane+field VGPR
-//     offsets).  Addresses of step r+1 depend on nothing loaded in step r, so its operands are
-//     prefetched while step r computes; blocks are private to their wave: no global ordering needed.
-//   * everything that crosses waves goes through LDS slots [slot][item][lane] allocated by the host
-//     with interval colouring: a child's S/Schur contribution to its parent (forward), and the
-//     parent's x AND new voltage pushed to its children (backward; the child stores it as ep/fp of
-//     its own block for the next forward sweep).  Values stay in registers instead when the same
-//     wave handles the parent in the adjacent row.  Rows are separated by an LDS-only barrier
-//     (s_waitcnt lgkmcnt(0); s_barrier): global loads/stores stay in flight across rows.
-//   * step constants (Y entries, flags, slot ids) are one 80-byte record, prefetched a row ahead.
+//  Data movement (the solve state is kept ON CHIP; HBM sees one Sbus read, one solution write and
+//  the LU factors):
+//   * node voltages (e,f) and Sbus are LDS-resident for the whole solve, [node][L envs] per
+//     workgroup; a child reads its parent's voltage straight from LDS.
+//   * everything that crosses workers inside a sweep — a child's S/Schur contribution to its parent
+//     (forward), a parent's x (backward) — goes through LDS slots [slot][item][env] allocated by the
+//     host with interval colouring; values stay in registers instead when the same worker handles
+//     the parent in the adjacent row.  Rows are separated by an LDS-only barrier when W > 1
+//     (s_waitcnt lgkmcnt(0); s_barrier) and by nothing at all when one wave holds all workers.
+//   * only the LU factors h, G (6 doubles per node) go to global scratch: every (worker,row) step
+//     owns one FACTOR BLOCK addressed as block(worker,row) + field through one buffer resource
+//     (scalar row offset, loop-invariant lane VGPR offsets); the backward sweep prefetches them two
+//     rows ahead.  Every step issues the same VMEM instructions, so vmcnt waits are exact.
+//   * step constants (Y entries, flags, slot ids) are 80-byte records staged once in LDS.
+//   * |V| and angle are formed once at the end (Vm = |V|, Va = angle(V) as newtonpf) and written
+//     with e,f to the Vout region for the commit kernel.
 //  The linear system is solved for z = [dtheta ; d|V|/|V|] (|V| columns scaled by |V_k|): the
 //  entries are j(S - A_kk), S + A_kk on the diagonal and -jA_ik, A_ik off it — no division by |V|;
 //  1/det uses v_rcp_f64 + two Newton steps; the update rotates V by the small step angle
 //  (polynomial sin/cos, full sincos only when a lane diverges).  Children are summed in a canonical
 //  order, so results are bit-identical for every W and L.
 // =================================================================================================
-struct FwdOps { double ek, fk, ep, fp, sr, si; };
-struct BwdOps { double h0, h1, g0, g1, g2, g3, e, f, va, vm; };
+struct BwdOps { double h0, h1, g0, g1, g2, g3; };
 
 __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -183,77 +185,77 @@ __device__ __forceinline__ void bst(double x, __amdgpu_buffer_rsrc_t r, unsigned
 template <int W>
 __global__ void __launch_bounds__(64 * W) k_nr_wtree(Dev d) {
   extern __shared__ double lds[];
+  // worker = (wave w, lane group s): S = 64/L sub-workers per wave, each serving the same L envs of
+  // this workgroup but eliminating a DIFFERENT node per row.  Per-lane step records + predication
+  // replace scalar branches, so one wave instruction does S nodes' worth of work.
   const unsigned lane = threadIdx.x & 63u;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const unsigned L = (unsigned)d.nr_lanes;
-  if (lane >= L) return;                         // the wave keeps running (and hitting barriers) with exec = L lanes
-  const unsigned e = blockIdx.x * L + lane;
+  const unsigned w = threadIdx.x >> 6;
+  const unsigned L = (unsigned)d.nr_lanes;       // envs per workgroup
+  const unsigned S = 64u / L;
+  const unsigned sw = lane / L, el = lane % L;
+  const unsigned t = w * S + sw;                 // worker id, 0 .. Wt-1
+  const unsigned Wt = (unsigned)W * S;
+  const unsigned e = blockIdx.x * L + el;
   const int R = d.nr_rows;
+  const unsigned n = (unsigned)d.n;
   const double vroot = d.vroot, tol = d.tol;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d.nrbuf, 0, d.nrbuf_bytes, 0x00020000);
   const unsigned rb = (unsigned)d.Bp * 8u;       // bytes per row
-  const unsigned bb = (unsigned)NRF * rb;        // bytes per operand block
-  const unsigned sb0 = (unsigned)(w * R) * bb;   // this wave's first block
-  unsigned vo[NRF];                              // lane + field offsets (loop-invariant VGPRs)
+  const unsigned bb = (unsigned)NBF * rb;        // bytes per factor block
+  unsigned vo[NBF];                              // env + field + worker offsets (loop-invariant VGPRs)
 #pragma unroll
-  for (int f = 0; f < NRF; ++f) vo[f] = e * 8u + (unsigned)f * rb;
-  // LDS map: [contribution slots 8/env][x slots 4/env][verdict bytes W*64][schedule W*R*80 B][overflow child list]
-  double* cs = lds + lane;                                  // cs[(slot*8 + item)*L]
-  double* xs = lds + (size_t)d.nr_cslots * 8 * L + lane;    // xs[(slot*4 + item)*L]
-  uint8_t* s_ok = (uint8_t*)(lds + ((size_t)d.nr_cslots * 8 + (size_t)d.nr_xslots * 4) * L);   // [W][64]
-  StepRec* s_sched = (StepRec*)(s_ok + W * 64);             // 16-byte aligned: all sizes above are multiples of 64
-  int32_t* s_clist = (int32_t*)(s_sched + (size_t)W * R);
-  {  // stage this wave's step records (and the overflow child list) in LDS: LDS reads return in order
-     // with the other LGKM traffic, so records can be prefetched a row ahead (scalar loads cannot:
-     // every lgkmcnt(0) would drain them)
-    const uint4* src = (const uint4*)(d.sched + (size_t)w * R);
-    uint4* dst = (uint4*)(s_sched + (size_t)w * R);
-    for (unsigned i = lane; i < 5u * (unsigned)R; i += L) dst[i] = src[i];
-    if (w == 0) for (unsigned i = lane; i < (unsigned)d.nr_nclist; i += L) s_clist[i] = d.clist[i];
+  for (int f = 0; f < NBF; ++f) vo[f] = e * 8u + (unsigned)f * rb + t * (unsigned)R * bb;
+  // LDS map: [V (n+1) x 2][Sbus n x 2][contribution slots x 8][x slots x 2]  (each x L envs, doubles)
+  //          [verdict bytes 64*W][schedule Wt*R*80 B][overflow child list]
+  double* sV = lds + el;                                    // sV[(2k + c)*L]
+  double* sS = sV + (size_t)2 * (n + 1) * L;                // sS[(2k + c)*L]
+  double* cs = sS + (size_t)2 * n * L;                      // cs[(slot*8 + item)*L]
+  double* xs = cs + (size_t)d.nr_cslots * 8 * L;            // xs[(slot*2 + item)*L]
+  uint8_t* s_ok = (uint8_t*)(xs - el + (size_t)d.nr_xslots * 2 * L);   // [Wt][L], Wt*L = 64*W
+  StepRec* s_sched = (StepRec*)(s_ok + 64 * W);             // 16-byte aligned: all sizes above are multiples of 64
+  int32_t* s_clist = (int32_t*)(s_sched + (size_t)Wt * R);
+  {  // stage the step records (and the overflow child list) in LDS
+    const uint4* src = (const uint4*)d.sched;
+    uint4* dst = (uint4*)s_sched;
+    for (unsigned i = threadIdx.x; i < 5u * Wt * (unsigned)R; i += 64u * W) dst[i] = src[i];
+    for (unsigned i = threadIdx.x; i < (unsigned)d.nr_nclist; i += 64u * W) s_clist[i] = d.clist[i];
+    // Sbus of this workgroup's envs -> LDS; flat start (runpp init="auto": every bus at the slack set-point)
+    const double* gS = d.nrbuf + (size_t)d.r_sbus * d.Bp + e;
+    for (unsigned i = t; i < 2u * n; i += Wt) sS[(size_t)i * L] = gS[(size_t)i * d.Bp];
+    for (unsigned k = t; k <= n; k += Wt) { sV[(size_t)(2 * k) * L] = vroot; sV[(size_t)(2 * k + 1) * L] = 0.0; }
   }
-  const StepRec* seq = s_sched + (size_t)w * R;
-  if (W > 1) __syncthreads();
+  __syncthreads();
+  const StepRec* seq = s_sched + (size_t)t * R;  // per lane: this worker's records
 
   bool done = d.active[e] == 0;
   bool conv = false;
   int it = 0;
-  if (__all(done)) {                             // identical in all W waves of the group
-    if (w == 0) { d.iters[e] = 0; d.conv[e] = 0; }
+  if (__all(done)) {                             // identical in all waves of the group
+    if (t == 0) { d.iters[e] = 0; d.conv[e] = 0; }
     return;
-  }
-  for (int r = 0; r < R; ++r) {                  // flat start (runpp init="auto"): every bus at the slack set-point
-    if (seq[r].k < 0) continue;
-    const unsigned sb = sb0 + (unsigned)r * bb;
-    bst(vroot, rs, vo[NF_EK], sb); bst(0.0, rs, vo[NF_FK], sb); bst(vroot, rs, vo[NF_EP], sb); bst(0.0, rs, vo[NF_FP], sb);
-    bst(0.0, rs, vo[NF_VA], sb); bst(vroot, rs, vo[NF_VM], sb);
   }
 
   bool allok;
-  double cS0, cS1, cD0, cD1, cD2, cD3, cR0, cR1;   // register carry child -> parent (same wave, next row)
-  double x0, x1, xe, xf;                           // register carry parent -> child in the backward sweep
+  double cS0, cS1, cD0, cD1, cD2, cD3, cR0, cR1;   // register carry child -> parent (same worker, next row)
+  double x0, x1;                                   // register carry parent -> child in the backward sweep
 
-  // operand loads are unconditional (idle steps own a dummy block): they depend on nothing but r
-  auto load_fwd = [&](unsigned sb, FwdOps& o) {
-    o.ek = bld(rs, vo[NF_EK], sb); o.fk = bld(rs, vo[NF_FK], sb); o.ep = bld(rs, vo[NF_EP], sb); o.fp = bld(rs, vo[NF_FP], sb);
-    o.sr = bld(rs, vo[NF_SR], sb); o.si = bld(rs, vo[NF_SI], sb);
-  };
   auto load_bwd = [&](unsigned sb, BwdOps& o) {
-    o.h0 = bld(rs, vo[NF_H0], sb); o.h1 = bld(rs, vo[NF_H1], sb);
-    o.g0 = bld(rs, vo[NF_G0], sb); o.g1 = bld(rs, vo[NF_G1], sb); o.g2 = bld(rs, vo[NF_G2], sb); o.g3 = bld(rs, vo[NF_G3], sb);
-    o.e = bld(rs, vo[NF_EK], sb); o.f = bld(rs, vo[NF_FK], sb); o.va = bld(rs, vo[NF_VA], sb); o.vm = bld(rs, vo[NF_VM], sb);
+    o.h0 = bld(rs, vo[NB_H0], sb); o.h1 = bld(rs, vo[NB_H1], sb);
+    o.g0 = bld(rs, vo[NB_G0], sb); o.g1 = bld(rs, vo[NB_G1], sb); o.g2 = bld(rs, vo[NB_G2], sb); o.g3 = bld(rs, vo[NB_G3], sb);
   };
 
   // NOTE on VMEM accounting: every step issues EXACTLY the same vector-memory instructions (fwd: 6
-  // loads + 6 stores, bwd: 10 loads + 6 stores) regardless of flags / idle steps (idle steps write
-  // don't-care values to their dummy block).  vmcnt is one in-order counter for loads AND stores on
-  // gfx9: only with a path-independent count can the compiler wait for "the loads issued two rows
-  // ago" (vmcnt(24)) without also draining the stores issued a few cycles earlier.
-  auto fwd_step = [&](const StepRec& T, unsigned sb, const FwdOps& o) {
-    const uint32_t fl = __builtin_amdgcn_readfirstlane(T.flags);   // uniform value read through LDS -> SGPR
+  // stores, bwd: 6 loads) regardless of flags / idle steps (idle steps write don't-care values to
+  // their dummy block): only with a path-independent count can the compiler's vmcnt waits be exact.
+  auto fwd_step = [&](const StepRec& T, unsigned sb) {
+    const uint32_t fl = T.flags;                 // per lane (differs between the sub-workers of a wave)
     double h0 = 0, h1 = 0, G0 = 0, G1 = 0, G2 = 0, G3 = 0;
-    if (__builtin_amdgcn_readfirstlane(T.k) >= 0) {
+    if (T.k >= 0) {
+      const unsigned k = (unsigned)T.k, p = (unsigned)T.p;
       const double gkk = T.ykk[0], bkk = T.ykk[1], gkp = T.ykp[0], bkp = T.ykp[1], gpk = T.ypk[0], bpk = T.ypk[1];
-      const double ek = o.ek, fk = o.fk, ep = o.ep, fp = o.fp;
+      const double ek = sV[(size_t)(2 * k) * L], fk = sV[(size_t)(2 * k + 1) * L];
+      const double ep = sV[(size_t)(2 * p) * L], fp = sV[(size_t)(2 * p + 1) * L];
+      const double osr = sS[(size_t)(2 * k) * L], osi = sS[(size_t)(2 * k + 1) * L];
       // A_kp = V_k conj(Y_kp V_p),  A_pk = V_p conj(Y_pk V_k),  A_kk = |V_k|^2 conj(Y_kk)
       const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
       const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
@@ -261,24 +263,22 @@ __global__ void __launch_bounds__(64 * W) k_nr_wtree(Dev d) {
       const double apk_r = ep * ur + fp * ui, apk_i = fp * ur - ep * ui;
       const double v2 = ek * ek + fk * fk;
       const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
-      double aS0 = 0, aS1 = 0, aD0 = 0, aD1 = 0, aD2 = 0, aD3 = 0, aR0 = 0, aR1 = 0;
-      if (fl & S_CARRY_IN) { aS0 = cS0; aS1 = cS1; aD0 = cD0; aD1 = cD1; aD2 = cD2; aD3 = cD3; aR0 = cR0; aR1 = cR1; }
+      const bool cin = (fl & S_CARRY_IN) != 0;
+      double aS0 = cin ? cS0 : 0.0, aS1 = cin ? cS1 : 0.0, aD0 = cin ? cD0 : 0.0, aD1 = cin ? cD1 : 0.0,
+             aD2 = cin ? cD2 : 0.0, aD3 = cin ? cD3 : 0.0, aR0 = cin ? cR0 : 0.0, aR1 = cin ? cR1 : 0.0;
       const int nch = (int)(fl >> 16);
       auto gather = [&](int slot) {
         const double* c = cs + (size_t)slot * 8 * L;
         aS0 += c[0]; aS1 += c[L]; aD0 += c[2 * L]; aD1 += c[3 * L]; aD2 += c[4 * L]; aD3 += c[5 * L];
         aR0 += c[6 * L]; aR1 += c[7 * L];
       };
-      if (nch > 0) gather(__builtin_amdgcn_readfirstlane(T.ch[0]));
-      if (nch > 1) gather(__builtin_amdgcn_readfirstlane(T.ch[1]));
-      if (nch > 2) gather(__builtin_amdgcn_readfirstlane(T.ch[2]));
-      if (nch > 3) {
-        const int cp = __builtin_amdgcn_readfirstlane(T.cptr);
-        for (int j = 3; j < nch; ++j) gather(__builtin_amdgcn_readfirstlane(s_clist[cp + j - 3]));
-      }
+      if (nch > 0) gather(T.ch[0]);
+      if (nch > 1) gather(T.ch[1]);
+      if (nch > 2) gather(T.ch[2]);
+      for (int j = 3; j < nch; ++j) gather(s_clist[T.cptr + j - 3]);
       // S_k = V_k conj(sum_j Y_kj V_j), mismatch F_k = S_k - Sbus_k
       const double sr = akk_r + akp_r + aS0, si = akk_i + akp_i + aS1;
-      const double Fp = sr - o.sr, Fq = si - o.si;
+      const double Fp = sr - osr, Fq = si - osi;
       allok = allok && (fabs(Fp) < tol) && (fabs(Fq) < tol);
       const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) - aD1;
       const double D2 = (sr - akk_r) - aD2, D3 = (si + akk_i) - aD3;
@@ -296,119 +296,114 @@ __global__ void __launch_bounds__(64 * W) k_nr_wtree(Dev d) {
         if (fl & S_CARRY_OUT) {
           cS0 = apk_r; cS1 = apk_i; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
         } else {
-          double* c = cs + (size_t)(__builtin_amdgcn_readfirstlane(T.slots) & 1023u) * 8 * L;
+          double* c = cs + (size_t)(T.slots & 1023u) * 8 * L;
           c[0] = apk_r; c[L] = apk_i; c[2 * L] = s0; c[3 * L] = s1; c[4 * L] = s2; c[5 * L] = s3; c[6 * L] = t0; c[7 * L] = t1;
         }
       }
     }
-    bst(h0, rs, vo[NF_H0], sb); bst(h1, rs, vo[NF_H1], sb);
-    bst(G0, rs, vo[NF_G0], sb); bst(G1, rs, vo[NF_G1], sb); bst(G2, rs, vo[NF_G2], sb); bst(G3, rs, vo[NF_G3], sb);
+    bst(h0, rs, vo[NB_H0], sb); bst(h1, rs, vo[NB_H1], sb);
+    bst(G0, rs, vo[NB_G0], sb); bst(G1, rs, vo[NB_G1], sb); bst(G2, rs, vo[NB_G2], sb); bst(G3, rs, vo[NB_G3], sb);
   };
-  auto bwd_step = [&](const StepRec& T, unsigned sb, const BwdOps& o) {
-    const uint32_t fl = __builtin_amdgcn_readfirstlane(T.flags);
-    const uint32_t slots = __builtin_amdgcn_readfirstlane(T.slots);
-    // defaults = "write back what was loaded" (idle steps, converged lanes)
-    double va = o.va, vm = o.vm, en = o.e, fn = o.f, pe = vroot, pf = 0.0;
-    if (__builtin_amdgcn_readfirstlane(T.k) >= 0) {
-      double y0 = o.h0, y1 = o.h1;
-      if (!(fl & S_PARENT_ROOT)) {
-        double p0, p1;
-        if (fl & S_CARRY_OUT) { p0 = x0; p1 = x1; pe = xe; pf = xf; }
-        else { const double* xp = xs + (size_t)(slots >> 20) * 4 * L; p0 = xp[0]; p1 = xp[L]; pe = xp[2 * L]; pf = xp[3 * L]; }
-        y0 -= o.g0 * p0 + o.g1 * p1;
-        y1 -= o.g2 * p0 + o.g3 * p1;
-      }
-      // newtonpf update: Va += dx_a, Vm += dx_m, V = Vm e^{jVa}, Vm = |V|, Va = angle(V), with
-      // dx_a = -y0, dx_m = -|V| y1  =>  V <- V (1 - y1) e^{-j y0}   (rotation by the small step)
-      double s, c;
-      const double dth = -y0;
-      if (__any(!(fabs(dth) <= 0.5))) sincos(dth, &s, &c);       // wave-uniform, only when diverging
-      else sincos_small(dth, &s, &c);
-      const double sc = 1.0 - y1;
-      const double e2 = sc * (o.e * c - o.f * s), f2 = sc * (o.e * s + o.f * c);
-      double va2 = o.va + dth;
-      double vm2 = o.vm * sc;
-      if (vm2 < 0.0) { vm2 = -vm2; va2 += M_PI; }
-      if (va2 > M_PI) va2 -= 2.0 * M_PI;
-      else if (va2 <= -M_PI) va2 += 2.0 * M_PI;
-      if (!done) { va = va2; vm = vm2; en = e2; fn = f2; }
-      // children receive x and this node's voltage AS STORED (a converged lane keeps its old one)
-      x0 = y0; x1 = y1; xe = en; xf = fn;
-      if (fl & S_X_OUT) { double* xo = xs + (size_t)((slots >> 10) & 1023u) * 4 * L; xo[0] = y0; xo[L] = y1; xo[2 * L] = en; xo[3 * L] = fn; }
+  auto bwd_step = [&](const StepRec& T, const BwdOps& o) {
+    const uint32_t fl = T.flags;
+    const uint32_t slots = T.slots;
+    const bool live = T.k >= 0;
+    double y0 = o.h0, y1 = o.h1;
+    if (live && !(fl & S_PARENT_ROOT)) {
+      double p0, p1;
+      if (fl & S_CARRY_OUT) { p0 = x0; p1 = x1; }
+      else { const double* xp = xs + (size_t)(slots >> 20) * 2 * L; p0 = xp[0]; p1 = xp[L]; }
+      y0 -= o.g0 * p0 + o.g1 * p1;
+      y1 -= o.g2 * p0 + o.g3 * p1;
     }
-    // a converged lane must keep its state: its block is rewritten with the values it already holds
-    // (ep/fp of a converged lane equal the parent's committed voltage, which pe/pf then still carry)
-    bst(va, rs, vo[NF_VA], sb); bst(vm, rs, vo[NF_VM], sb); bst(en, rs, vo[NF_EK], sb); bst(fn, rs, vo[NF_FK], sb);
-    bst(pe, rs, vo[NF_EP], sb); bst(pf, rs, vo[NF_FP], sb);
+    // newtonpf update: Va += dx_a, Vm += dx_m, V = Vm e^{jVa}, with dx_a = -y0, dx_m = -|V| y1
+    //   =>  V <- V (1 - y1) e^{-j y0}   (rotation by the small step; |V|, angle are formed at the end)
+    double s, c;
+    const double dth = -y0;
+    if (__any(live && !(fabs(dth) <= 0.5))) sincos(dth, &s, &c);   // wave-uniform, only when a lane diverges
+    else sincos_small(dth, &s, &c);
+    if (live) {
+      x0 = y0; x1 = y1;
+      if (fl & S_X_OUT) { double* xo = xs + (size_t)((slots >> 10) & 1023u) * 2 * L; xo[0] = y0; xo[L] = y1; }
+      if (!done) {
+        const unsigned k = (unsigned)T.k;
+        const double ek = sV[(size_t)(2 * k) * L], fk = sV[(size_t)(2 * k + 1) * L];
+        const double sc = 1.0 - y1;
+        sV[(size_t)(2 * k) * L] = sc * (ek * c - fk * s);
+        sV[(size_t)(2 * k + 1) * L] = sc * (ek * s + fk * c);
+      }
+    }
   };
 
   for (;;) {
     // ------------------------------------------------------------------ forward sweep
-    // software pipeline of depth 2: while row r computes, the operand loads of rows r+1 and r+2 are
-    // in flight (three rotating operand/record sets, loop unrolled by 3 so the rotation is static);
-    // the operand blocks live beyond L2 (Infinity Cache / HBM latency > one row of compute).
     allok = true;
     cS0 = cS1 = cD0 = cD1 = cD2 = cD3 = cR0 = cR1 = 0.0;
     {
-      StepRec T0 = seq[0], T1 = seq[R > 1 ? 1 : 0], T2;
-      FwdOps o0 = {}, o1 = {}, o2 = {};
-      unsigned sb = sb0;
-      load_fwd(sb, o0);
-      if (R > 1) load_fwd(sb + bb, o1);
+      StepRec T0 = seq[0], T1;
+      unsigned sb = 0;
       int r = 0;
-      for (; r + 2 < R; r += 3) {
-        T2 = seq[r + 2]; load_fwd(sb + 2 * bb, o2);
-        fwd_step(T0, sb, o0);
+      for (; r + 1 < R; r += 2) {                // records one row ahead (ping-pong, no copies)
+        T1 = seq[r + 1];
+        fwd_step(T0, sb);
         if (W > 1) lds_barrier();
-        if (r + 3 < R) { T0 = seq[r + 3]; load_fwd(sb + 3 * bb, o0); }
-        fwd_step(T1, sb + bb, o1);
+        if (r + 2 < R) T0 = seq[r + 2];
+        fwd_step(T1, sb + bb);
         if (W > 1) lds_barrier();
-        if (r + 4 < R) { T1 = seq[r + 4]; load_fwd(sb + 4 * bb, o1); }
-        fwd_step(T2, sb + 2 * bb, o2);
-        if (W > 1) lds_barrier();
-        sb += 3 * bb;
+        sb += 2 * bb;
       }
-      if (r < R) { fwd_step(T0, sb, o0); if (W > 1) lds_barrier(); }
-      if (r + 1 < R) { fwd_step(T1, sb + bb, o1); if (W > 1) lds_barrier(); }
+      if (r < R) { fwd_step(T0, sb); if (W > 1) lds_barrier(); }
     }
-    if (W > 1) {                                 // AND of the per-wave verdicts, per env
-      s_ok[w * 64 + lane] = allok ? 1 : 0;
-      lds_barrier();
-#pragma unroll
-      for (int ww = 0; ww < W; ++ww) allok = allok && (s_ok[ww * 64 + lane] != 0);
+    {                                            // AND of the workers' verdicts, per env
+      s_ok[t * L + el] = allok ? 1 : 0;
+      if (W > 1) lds_barrier();
+      for (unsigned tt = 0; tt < Wt; ++tt) allok = allok && (s_ok[tt * L + el] != 0);
     }
     if (!done) {
       conv = allok;
       if (conv || it == d.max_it) done = true;
     }
-    if (__all(done)) break;                      // same lanes, same values in every wave of the group
+    if (__all(done)) break;                      // same envs, same values in every wave of the group
     // ------------------------------------------------------------------ backward sweep + update
-    x0 = x1 = xe = xf = 0.0;
+    // software pipeline of depth 2 on the factor loads (three rotating sets, unrolled by 3)
+    x0 = x1 = 0.0;
     {
       StepRec T0 = seq[R - 1], T1 = seq[R > 1 ? R - 2 : 0], T2;
       BwdOps o0 = {}, o1 = {}, o2 = {};
-      unsigned sb = sb0 + (unsigned)(R - 1) * bb;
+      unsigned sb = (unsigned)(R - 1) * bb;
       load_bwd(sb, o0);
       if (R > 1) load_bwd(sb - bb, o1);
       int r = R - 1;
       for (; r - 2 >= 0; r -= 3) {
         T2 = seq[r - 2]; load_bwd(sb - 2 * bb, o2);
-        bwd_step(T0, sb, o0);
+        bwd_step(T0, o0);
         if (W > 1) lds_barrier();
         if (r - 3 >= 0) { T0 = seq[r - 3]; load_bwd(sb - 3 * bb, o0); }
-        bwd_step(T1, sb - bb, o1);
+        bwd_step(T1, o1);
         if (W > 1) lds_barrier();
         if (r - 4 >= 0) { T1 = seq[r - 4]; load_bwd(sb - 4 * bb, o1); }
-        bwd_step(T2, sb - 2 * bb, o2);
+        bwd_step(T2, o2);
         if (W > 1) lds_barrier();
         sb -= 3 * bb;
       }
-      if (r >= 0) { bwd_step(T0, sb, o0); if (W > 1) lds_barrier(); }
-      if (r - 1 >= 0) { bwd_step(T1, sb - bb, o1); if (W > 1) lds_barrier(); }
+      if (r >= 0) { bwd_step(T0, o0); if (W > 1) lds_barrier(); }
+      if (r - 1 >= 0) { bwd_step(T1, o1); if (W > 1) lds_barrier(); }
     }
     if (!done) ++it;
   }
-  if (w == 0) { d.iters[e] = it; d.conv[e] = conv ? 1 : 0; }
+  // ------------------------------------------------------------------ solution -> Vout (e, f, |V|, angle)
+  if (W > 1) __syncthreads();
+  {
+    double* gV = d.nrbuf + (size_t)d.r_vout * d.Bp + e;
+    for (unsigned k = t; k < n; k += Wt) {
+      const double ek = sV[(size_t)(2 * k) * L], fk = sV[(size_t)(2 * k + 1) * L];
+      double* o = gV + (size_t)(VOF * k) * d.Bp;
+      o[(size_t)VO_E * d.Bp] = ek; o[(size_t)VO_F * d.Bp] = fk;
+      o[(size_t)VO_VM * d.Bp] = sqrt(ek * ek + fk * fk);          // Vm = |V|
+      o[(size_t)VO_VA * d.Bp] = atan2(fk, ek);                     // Va = angle(V)
+    }
+  }
+  if (t == 0) { d.iters[e] = it; d.conv[e] = conv ? 1 : 0; }
 }
 
 // =================================================================================================
@@ -429,8 +424,8 @@ __global__ void __launch_bounds__(256) k_commit(Dev d, int mode) {
   int y = blockIdx.y;
   if (y < d.nb) {                                           // ---- bus at elimination position k (k == n: slack)
     const int k = y, bus = d.bus_of_pos[k];
-    const double* blk = d.nrbuf + (size_t)d.blk_of_pos[k] * NRF * S + e;
-    const double vm = blk[(size_t)NF_VM * S], va = blk[(size_t)NF_VA * S];
+    const double* vo = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * k) * S + e;
+    const double vm = vo[(size_t)VO_VM * S], va = vo[(size_t)VO_VA * S];
     d.vm[(size_t)bus * S + e] = vm;
     d.va[(size_t)bus * S + e] = va;
     double P = 0.0, Q = 0.0;
@@ -441,8 +436,8 @@ __global__ void __launch_bounds__(256) k_commit(Dev d, int mode) {
       // slack: res_bus = -(V conj(I)) * sn, I = Y_rr V_r + sum_children Y_rk V_k   (consumer sign)
       double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;
       for (int j = 0; j < d.n_root_children; ++j) {
-        const double* cb = d.nrbuf + (size_t)d.blk_of_pos[d.root_children[j]] * NRF * S + e;
-        const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ek = cb[(size_t)NF_EK * S], fk = cb[(size_t)NF_FK * S];
+        const double* cb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * d.root_children[j]) * S + e;
+        const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ek = cb[(size_t)VO_E * S], fk = cb[(size_t)VO_F * S];
         ir += g * ek - b * fk; ii += g * fk + b * ek;
       }
       P = -(d.vroot * ir) * d.sn; Q = (d.vroot * ii) * d.sn;
@@ -456,9 +451,9 @@ __global__ void __launch_bounds__(256) k_commit(Dev d, int mode) {
     const LineFlow Ln = d.lines[y];
     double pl = 0.0;
     if (Ln.fpos >= 0) {
-      const double* fb = d.nrbuf + (size_t)d.blk_of_pos[Ln.fpos] * NRF * S + e;
-      const double* tb = d.nrbuf + (size_t)d.blk_of_pos[Ln.tpos] * NRF * S + e;
-      const double ef = fb[(size_t)NF_EK * S], ff = fb[(size_t)NF_FK * S], et = tb[(size_t)NF_EK * S], ft = tb[(size_t)NF_FK * S];
+      const double* fb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * Ln.fpos) * S + e;
+      const double* tb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * Ln.tpos) * S + e;
+      const double ef = fb[(size_t)VO_E * S], ff = fb[(size_t)VO_F * S], et = tb[(size_t)VO_E * S], ft = tb[(size_t)VO_F * S];
       const double ifr = Ln.yff[0] * ef - Ln.yff[1] * ff + Ln.yft[0] * et - Ln.yft[1] * ft;
       const double ifi = Ln.yff[0] * ff + Ln.yff[1] * ef + Ln.yft[0] * ft + Ln.yft[1] * et;
       const double itr = Ln.ytf[0] * ef - Ln.ytf[1] * ff + Ln.ytt[0] * et - Ln.ytt[1] * ft;
@@ -744,7 +739,7 @@ void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const
 }
 void launch_nr(const Dev& d, hipStream_t st) {
   const dim3 grid(d.Bp / d.nr_lanes);
-  const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.nr_cslots, d.nr_xslots, d.nr_rows, d.nr_nclist);
+  const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.n, d.nr_cslots, d.nr_xslots, d.nr_rows, d.nr_nclist);
   switch (d.nr_waves) {
     case 1: hipLaunchKernelGGL(k_nr_wtree<1>, grid, dim3(64), lds, st, d); break;
     case 2: hipLaunchKernelGGL(k_nr_wtree<2>, grid, dim3(128), lds, st, d); break;

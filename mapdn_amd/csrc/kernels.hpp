@@ -10,10 +10,14 @@ namespace mapdn {
 enum { MODE_STEP = 0, MODE_RESET = 1, MODE_SOLVE = 2 };
 enum { STREAM_PV = 0, STREAM_LOAD_P = 1, STREAM_LOAD_Q = 2, STREAM_ACTION = 3, STREAM_START = 4 };
 
-// Fields of one NR operand block.  Every (wave, row) step of the elimination schedule owns one
-// block of NRF rows (a "row" = Bp doubles, env-minor), so all global accesses of a step are
-// block_base + field: the addresses of step r+1 do not depend on anything loaded in step r.
-enum { NF_EK = 0, NF_FK, NF_EP, NF_FP, NF_SR, NF_SI, NF_VA, NF_VM, NF_H0, NF_H1, NF_G0, NF_G1, NF_G2, NF_G3, NRF };
+// NR global scratch `nrbuf` ("rows" of Bp doubles, env-minor), three regions:
+//   factor blocks  [nblk][NBF]   one block per (worker,row) step: the LU factors h0 h1 G0..G3 written in
+//                                the forward sweep and read back in the backward sweep by the same worker
+//   Sbus           [n][2]        per elimination position: Re/Im of the scheduled injection (k_inject)
+//   Vout           [n+1][4]      per position (n == slack): e f |V| angle — the solution (k_nr_wtree)
+// Voltages, Sbus and everything that crosses workers live in LDS during the solve.
+enum { NB_H0 = 0, NB_H1, NB_G0, NB_G1, NB_G2, NB_G3, NBF };
+enum { VO_E = 0, VO_F, VO_VM, VO_VA, VOF };
 
 // Everything a kernel needs, passed by value (kernarg segment -> scalar loads).
 // Layout rule: per-env arrays are env-minor, X[item][Bp]; Bp = B rounded up to 64.
@@ -47,11 +51,10 @@ struct Dev {
   int32_t* steps; int64_t* start_row; uint32_t* draw;
   uint8_t *done, *pending, *active;
   int64_t* adv_row; uint32_t* adv_draw;
-  // ---- NR scratch: operand blocks [nblk+1][NRF][Bp] (block nblk = the slack bus), see NF_*
-  double* nrbuf; uint32_t nrbuf_bytes;
-  const int32_t* blk_of_pos;                          // [n+1] elimination position -> block
+  // ---- NR scratch (see NB_* / VO_*): row offsets of the Sbus and Vout regions
+  double* nrbuf; uint32_t nrbuf_bytes; uint32_t r_sbus, r_vout;
   int32_t* iters; uint8_t* conv;
-  // ---- NR schedule (k_nr_wtree): W waves per env group, L envs per wave, R rows
+  // ---- NR schedule (k_nr_wtree): W waves per workgroup, L envs per workgroup (64/L lane-group workers per wave), R rows
   int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots, nr_nclist;
   const StepRec* sched; const int32_t* clist;
 };
@@ -60,11 +63,13 @@ void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const
                    const double* pv, const double* q, hipStream_t st);
 void launch_nr(const Dev& d, hipStream_t st);
 int nr_set_lds_limit(int waves, size_t bytes);
-// dynamic LDS of k_nr_wtree: contribution slots (8 doubles/env), x slots (4 doubles/env), verdict
-// bytes, the W*R step records and the overflow child list
-static inline size_t nr_lds_bytes(int W, int L, int cslots, int xslots, int R, int nclist) {
-  return ((size_t)cslots * 8 + (size_t)xslots * 4) * (size_t)L * sizeof(double) + (size_t)W * 64 +
-         (size_t)W * R * sizeof(StepRec) + (size_t)nclist * sizeof(int32_t);
+// dynamic LDS of k_nr_wtree (W waves, L envs per workgroup => Wt = W*64/L workers): node voltages
+// (2 doubles x (n+1)) and Sbus (2 x n) per env, contribution slots (8 doubles/env), x slots (2 doubles/env),
+// verdict bytes, the Wt*R step records, overflow child list
+static inline size_t nr_lds_bytes(int W, int L, int n, int cslots, int xslots, int R, int nclist) {
+  const size_t Wt = (size_t)W * (64 / L);
+  return ((size_t)(2 * (n + 1) + 2 * n) + (size_t)cslots * 8 + (size_t)xslots * 2) * (size_t)L * sizeof(double) + (size_t)W * 64 +
+         Wt * R * sizeof(StepRec) + (size_t)nclist * sizeof(int32_t);
 }
 void launch_commit(const Dev& d, int mode, hipStream_t st);
 void launch_reward(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);

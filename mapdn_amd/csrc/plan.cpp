@@ -338,6 +338,7 @@ void build_schedule(const Plan& P, int W, Schedule& S) {
       const double* c = &P.yc[(size_t)k * 6];
       T.ykk[0] = c[0]; T.ykk[1] = c[1]; T.ykp[0] = c[2]; T.ykp[1] = c[3]; T.ypk[0] = c[4]; T.ypk[1] = c[5];
       const int p = P.par[k];
+      T.p = p;
       uint32_t f = 0, os = 0, xsl = 0, pxs = 0;
       if (p == n) f |= S_PARENT_ROOT;
       else if (carry_out[k]) f |= S_CARRY_OUT;

@@ -42,7 +42,7 @@ struct StepRec {
   int32_t ch[3];    // contribution slots of the first three children to gather (canonical order)
   int32_t cptr;     // overflow list (children 3..) in Schedule::clist
   int32_t k;        // node position, -1 = idle step
-  int32_t pad;
+  int32_t p;        // parent position (n == slack)
 };
 static_assert(sizeof(StepRec) == 80, "StepRec must be 80 bytes (5 x ds_read_b128)");
 
