@@ -98,7 +98,6 @@ def main():
     # (excluded) policy costs nothing inside it; a ring of `n_act` distinct action tensors
     n_act = min(a.steps + a.warmup + 60, 256)
     acts = torch.empty(n_act, B, env.n_sgen, dtype=torch.float32, device=dev).uniform_(-scale, scale, generator=gen)
-    ret = torch.zeros(B, dtype=torch.float64, device=dev)
     steps_in_ep = [0]
     step_no = [0]
 
@@ -107,7 +106,6 @@ def main():
         step_no[0] += 1
         r, term, info = env.step(act)
         env.get_obs()
-        ret.add_(r)
         steps_in_ep[0] += 1
         if steps_in_ep[0] >= env.episode_limit - 1:           # all envs terminate together (:204)
             env.reset()
@@ -127,7 +125,7 @@ def main():
     for _ in range(a.steps):
         one_step()
     if dist is not None:
-        gather_rollout(ret)                                   # end-of-rollout RCCL gather
+        gather_rollout(env.episode_returns())                 # end-of-rollout RCCL gather
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:

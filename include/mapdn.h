@@ -161,6 +161,9 @@ int mapdn_get_loads(mapdn_handle* h, double* load_p, double* load_q, void* strea
 /* `start` of voltage_control_env.py:445 for every env: device int64 [B] */
 int mapdn_get_start_rows(mapdn_handle* h, int64_t* start_rows, void* stream);
 
+/* sum_rewards of the running episode (voltage_control_env.py:203) for every env: device f64 [B] */
+int mapdn_get_returns(mapdn_handle* h, double* returns, void* stream);
+
 /* Pure power flow == pp.runpp(net) (voltage_control_env.py:557) on explicit element powers:
  * p_load, q_load f64 [B, nl]; p_sgen, q_sgen f64 [B, ns] (MW / MVAr) ->
  * vm_pu, va_degree f64 [B, nb]; iterations i32 [B]; converged u8 [B].  Does not touch env state. */

@@ -28,7 +28,7 @@ F32, F64 = 0, 1
 
 EXPORTS = (
     "mapdn_last_error", "mapdn_create", "mapdn_destroy", "mapdn_dims", "mapdn_set_profiles", "mapdn_reset",
-    "mapdn_step", "mapdn_get_start_rows", "mapdn_get_obs", "mapdn_get_state", "mapdn_get_results", "mapdn_get_loads",
+    "mapdn_step", "mapdn_get_start_rows", "mapdn_get_returns", "mapdn_get_obs", "mapdn_get_state", "mapdn_get_results", "mapdn_get_loads",
     "mapdn_solve_only", "mapdn_get_ybus_dense", "mapdn_get_obs_index", "mapdn_get_schedule", "mapdn_stats", "mapdn_nr_timing",
     "mapdn_nr_time_ms",
 )
@@ -104,6 +104,7 @@ def load():
     lib.mapdn_reset.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     lib.mapdn_step.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.mapdn_get_start_rows.argtypes = [vp, vp, vp]
+    lib.mapdn_get_returns.argtypes = [vp, vp, vp]
     lib.mapdn_get_obs.argtypes = [vp, vp, C.c_int32, vp]
     lib.mapdn_get_state.argtypes = [vp, vp, C.c_int32, vp]
     lib.mapdn_get_results.argtypes = [vp] + [vp] * 7 + [vp]

@@ -23,6 +23,7 @@ struct mapdn_handle {
   std::vector<void*> allocs;
   bool have_profiles = false, was_reset = false, host_only = false;
   int32_t *obs_rows = nullptr, *state_rows = nullptr, *iota_idx = nullptr, *vm_row = nullptr, *va_row = nullptr;
+  int32_t *obs_xptr = nullptr, *obs_xrow = nullptr;
   double *obs_scale = nullptr, *state_scale = nullptr;
   double *t_pl = nullptr, *t_ql = nullptr, *t_pv = nullptr, *t_q = nullptr;
   double* table = nullptr; double* stdv = nullptr; double* smax = nullptr;
@@ -72,12 +73,10 @@ static int dupload(mapdn_handle* h, const T** p, const std::vector<T>& v) {
 // x 4 SIMDs).  Tuned on case33/141/322 (tools/sweep_nr.sh): ~8 workers per env is the knee of the
 // Hu schedule for feeders of 100-300 buses; keep >= ~512 workgroups while envs per workgroup <= 64.
 static void choose_nr_geometry(int Bp, int n, int& W, int& L) {
-  W = 1;
-  if (Bp >= 65536) L = 64;
-  else if (Bp >= 32768) L = 32;
-  else if (Bp >= 16384) L = 16;
-  else L = 8;
-  if (n < 48 && L < 16) L = 16;          // small feeders: 4 workers are enough
+  (void)Bp;
+  if (n < 48) { W = 1; L = 16; }        // small feeders: 4 workers are enough
+  else if (n < 200) { W = 2; L = 16; }  // 8 workers
+  else { W = 2; L = 8; }                // 16 workers, LDS holds 8 envs of a ~320-bus feeder
 }
 
 extern "C" {
@@ -122,11 +121,11 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   const size_t Bp = d.Bp;
 #define AL(field, rows) do { rc = dalloc(h, &d.field, (size_t)(rows) * Bp); if (rc) return rc; } while (0)
   AL(q_new, d.ns); AL(cur_pl, d.nl); AL(cur_ql, d.nl); AL(pl, d.n_line);
-  // gatherable state block: pb qb [nb] | cur_pv cur_q [ns] | vm va res_p res_q [nb]
-  const int r_pb = 0, r_qb = d.nb, r_pv = 2 * d.nb, r_q = r_pv + d.ns, r_vm = r_q + d.ns, r_va = r_vm + d.nb,
+  // gatherable state block: cur_pv cur_q [ns] | vm va res_p res_q [nb]
+  const int r_pv = 0, r_q = r_pv + d.ns, r_vm = r_q + d.ns, r_va = r_vm + d.nb,
             r_rp = r_va + d.nb, r_rq = r_rp + d.nb, g_rows = r_rq + d.nb;
   rc = dalloc(h, &d.gbuf, (size_t)g_rows * Bp); if (rc) return rc;
-  d.pb = d.gbuf + (size_t)r_pb * Bp; d.qb = d.gbuf + (size_t)r_qb * Bp; d.cur_pv = d.gbuf + (size_t)r_pv * Bp;
+  d.cur_pv = d.gbuf + (size_t)r_pv * Bp;
   d.cur_q = d.gbuf + (size_t)r_q * Bp; d.vm = d.gbuf + (size_t)r_vm * Bp; d.va = d.gbuf + (size_t)r_va * Bp;
   d.res_p = d.gbuf + (size_t)r_rp * Bp; d.res_q = d.gbuf + (size_t)r_rq * Bp;
   AL(sum_rewards, 1); AL(steps, 1); AL(start_row, 1); AL(draw, 1); AL(done, 1); AL(pending, 1);
@@ -136,13 +135,18 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     HIPCHK(h, hipMemcpy(d.done, ones.data(), Bp, hipMemcpyHostToDevice));   // nothing is steppable before reset
   }
   const int32_t* tmp;
-  {  // obs / state columns -> (source row of gbuf, scale); -1 = zero padding
-    auto tables = [&](const std::vector<int32_t>& kind, const std::vector<int32_t>& idx, std::vector<int32_t>& rows, std::vector<double>& scale) {
-      rows.resize(kind.size()); scale.assign(kind.size(), 1.0);
+  {  // obs / state columns -> (source row of gbuf, scale, extra rows to add); -1 = zero padding.
+     // P/Q columns with the effective PV add-back (voltage_control_env.py:238-244) = res_bus row + the
+     // sgen.p_mw / q_mvar rows of the sgens on that bus.
+    std::vector<std::vector<int>> sgens_at(P.nb);
+    for (int j = 0; j < P.ns; ++j) sgens_at[P.sgen_bus[j]].push_back(j);
+    auto tables = [&](const std::vector<int32_t>& kind, const std::vector<int32_t>& idx, std::vector<int32_t>& rows,
+                      std::vector<double>& scale, std::vector<int32_t>& xptr, std::vector<int32_t>& xrow) {
+      rows.resize(kind.size()); scale.assign(kind.size(), 1.0); xptr.assign(kind.size() + 1, 0); xrow.clear();
       for (size_t c = 0; c < kind.size(); ++c) {
         switch (kind[c]) {
-          case G_P_ADDBACK: rows[c] = r_pb + idx[c]; break;
-          case G_Q_ADDBACK: rows[c] = r_qb + idx[c]; break;
+          case G_P_ADDBACK: rows[c] = r_rp + idx[c]; for (int j : sgens_at[idx[c]]) xrow.push_back(r_pv + j); break;
+          case G_Q_ADDBACK: rows[c] = r_rq + idx[c]; for (int j : sgens_at[idx[c]]) xrow.push_back(r_q + j); break;
           case G_SGEN_P: rows[c] = r_pv + idx[c]; break;
           case G_SGEN_Q: rows[c] = r_q + idx[c]; break;
           case G_VM: rows[c] = r_vm + idx[c]; break;
@@ -152,13 +156,18 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
           case G_VA_DEG: rows[c] = r_va + idx[c]; scale[c] = 180.0 / M_PI; break;
           default: rows[c] = -1; break;
         }
+        xptr[c + 1] = (int32_t)xrow.size();
+        if (xptr[c + 1] > xptr[c]) rows[c] |= 0x40000000;   // GATHER_HAS_EXTRA
       }
+      if (xrow.empty()) xrow.push_back(0);
     };
-    std::vector<int32_t> rows; std::vector<double> scale; const double* dt;
-    tables(P.obs_kind, P.obs_idx, rows, scale);
+    std::vector<int32_t> rows, xptr, xrow; std::vector<double> scale; const double* dt;
+    tables(P.obs_kind, P.obs_idx, rows, scale, xptr, xrow);
     rc = dupload(h, &tmp, rows); if (rc) return rc; h->obs_rows = (int32_t*)tmp;
     rc = dupload(h, &dt, scale); if (rc) return rc; h->obs_scale = (double*)dt;
-    tables(P.state_kind, P.state_idx, rows, scale);
+    rc = dupload(h, &tmp, xptr); if (rc) return rc; h->obs_xptr = (int32_t*)tmp;
+    rc = dupload(h, &tmp, xrow); if (rc) return rc; h->obs_xrow = (int32_t*)tmp;
+    tables(P.state_kind, P.state_idx, rows, scale, xptr, xrow);     // get_state has no add-back
     rc = dupload(h, &tmp, rows); if (rc) return rc; h->state_rows = (int32_t*)tmp;
     rc = dupload(h, &dt, scale); if (rc) return rc; h->state_scale = (double*)dt;
   }
@@ -179,9 +188,10 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   choose_nr_geometry(d.Bp, P.n, W, L);
   if (const char* s = getenv("MAPDN_NR_WAVES")) W = atoi(s);
   if (const char* s = getenv("MAPDN_NR_LANES")) L = atoi(s);
-  if (!(W == 1 || W == 2 || W == 4 || W == 8 || W == 16) || !(L == 64 || L == 32 || L == 16 || L == 8 || L == 4)) {
-    h->err = "MAPDN_NR_WAVES must be 1/2/4/8/16 and MAPDN_NR_LANES 64/32/16/8/4"; return MAPDN_E_INVALID; }
+  if (!(W == 1 || W == 2 || W == 4 || W == 8) || !(L == 32 || L == 16 || L == 8 || L == 4)) {
+    h->err = "MAPDN_NR_WAVES must be 1/2/4/8 and MAPDN_NR_LANES 32/16/8/4"; return MAPDN_E_INVALID; }
   const int Wt = W * (64 / L);
+  if (10 * Wt > 2 * (P.n + 2)) { h->err = "network too small for this many NR workers (epilogue scratch): raise MAPDN_NR_LANES or lower MAPDN_NR_WAVES"; return MAPDN_E_INVALID; }
   build_schedule(P, Wt, h->sched);
   if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
   const int ncl = (int)h->sched.clist.size();
@@ -189,8 +199,11 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   if (lds_need > 160 * 1024) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
   d.nr_waves = W; d.nr_lanes = L;
   d.nr_rows = h->sched.R; d.nr_cslots = h->sched.n_cslots; d.nr_xslots = h->sched.n_xslots; d.nr_nclist = ncl;
-  if (nr_set_lds_limit(W, lds_need) != 0) {
-    h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return MAPDN_E_HIP; }
+  {
+    const int lr = nr_set_lds_limit(W, L, lds_need);
+    if (lr == -2) { h->err = "this (MAPDN_NR_WAVES, MAPDN_NR_LANES) combination is not compiled in"; return MAPDN_E_INVALID; }
+    if (lr != 0) { h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return MAPDN_E_HIP; }
+  }
   UP(sched, h->sched.steps); UP(clist, h->sched.clist);
   {  // NR scratch: factor blocks (one per (worker,row) step) | Sbus | Vout; a single buffer resource addresses it
     const int nblk = Wt * h->sched.R;
@@ -289,8 +302,8 @@ int mapdn_set_profiles(mapdn_handle* h, const double* pv, const double* load_p, 
   return MAPDN_OK;
 }
 
-static void nr_launch(mapdn_handle* h, hipStream_t st) {
-  if (!h->timing) { launch_nr(h->d, st); return; }
+static void nr_launch(mapdn_handle* h, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
+  if (!h->timing) { launch_nr(h->d, mode, reward, term, info, st); return; }
   if (h->ev_used + 2 > h->ev.size()) {
     if (h->ev.size() >= 2 * 8192) {   // pool full: drain
       double ms; int64_t n; mapdn_nr_time_ms(h, &ms, &n); h->acc_ms = ms; h->acc_launches = n;
@@ -303,7 +316,7 @@ static void nr_launch(mapdn_handle* h, hipStream_t st) {
   hipEvent_t a = h->ev[h->ev_used], b = h->ev[h->ev_used + 1];
   h->ev_used += 2;
   (void)hipEventRecord(a, st);
-  launch_nr(h->d, st);
+  launch_nr(h->d, mode, reward, term, info, st);
   (void)hipEventRecord(b, st);
 }
 
@@ -319,9 +332,7 @@ int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, i
     launch_reset_begin(d, start_rows, t == 0, st);
     launch_advance(d, add_noise, st);
     launch_inject(d, MODE_RESET, nullptr, MAPDN_F64, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, st);
-    nr_launch(h, st);
-    launch_commit(d, MODE_RESET, st);
-    launch_reward(d, MODE_RESET, nullptr, nullptr, nullptr, st);
+    nr_launch(h, MODE_RESET, nullptr, nullptr, nullptr, st);
   }
   HIPCHK(h, hipGetLastError());
   h->was_reset = true;
@@ -339,9 +350,7 @@ int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int3
   hipStream_t st = (hipStream_t)stream;
   const Dev& d = h->d;
   launch_inject(d, MODE_STEP, actions, actions_dtype, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, st);
-  nr_launch(h, st);
-  launch_commit(d, MODE_STEP, st);
-  launch_reward(d, MODE_STEP, reward, terminated, info, st);
+  nr_launch(h, MODE_STEP, reward, terminated, info, st);
   launch_advance(d, add_noise, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
@@ -353,8 +362,8 @@ int mapdn_get_obs(mapdn_handle* h, void* obs, int32_t dtype, void* stream) {
   NEEDDEV(h);
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
-  launch_addback(h->d, st);
-  launch_gather(h->d, h->d.gbuf, h->obs_rows, h->obs_scale, 1.0, obs, dtype, h->plan.n_agents * h->plan.obs_size, st);
+  launch_gather(h->d, h->d.gbuf, h->obs_rows, h->obs_scale, 1.0, h->obs_xptr, h->obs_xrow, obs, dtype,
+                h->plan.n_agents * h->plan.obs_size, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
 }
@@ -365,13 +374,13 @@ int mapdn_get_state(mapdn_handle* h, void* state, int32_t dtype, void* stream) {
   NEEDDEV(h);
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
-  launch_gather(h->d, h->d.gbuf, h->state_rows, h->state_scale, 1.0, state, dtype, h->plan.state_size, st);
+  launch_gather(h->d, h->d.gbuf, h->state_rows, h->state_scale, 1.0, nullptr, nullptr, state, dtype, h->plan.state_size, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
 }
 
 static void transpose_out(mapdn_handle* h, const double* src, double scale, const int32_t* rows, double* out, int n, hipStream_t st) {
-  launch_gather(h->d, src, rows, nullptr, scale, out, MAPDN_F64, n, st);
+  launch_gather(h->d, src, rows, nullptr, scale, nullptr, nullptr, out, MAPDN_F64, n, st);
 }
 
 int mapdn_get_results(mapdn_handle* h, double* vm_pu, double* va_degree, double* p_mw, double* q_mvar, double* pl_mw,
@@ -412,6 +421,14 @@ int mapdn_get_start_rows(mapdn_handle* h, int64_t* start_rows, void* stream) {
   return MAPDN_OK;
 }
 
+int mapdn_get_returns(mapdn_handle* h, double* returns, void* stream) {
+  if (!h || !returns) return MAPDN_E_INVALID;
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(returns, h->d.sum_rewards, (size_t)h->d.B * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MAPDN_OK;
+}
+
 int mapdn_solve_only(mapdn_handle* h, const double* p_load, const double* q_load, const double* p_sgen, const double* q_sgen,
                      double* vm_pu, double* va_degree, int32_t* iterations, uint8_t* converged, void* stream) {
   if (!h) return MAPDN_E_INVALID;
@@ -427,7 +444,7 @@ int mapdn_solve_only(mapdn_handle* h, const double* p_load, const double* q_load
   HIPCHK(h, hipMemsetAsync(d.active, 1, d.B, st));
   if (d.Bp > d.B) HIPCHK(h, hipMemsetAsync(d.active + d.B, 0, d.Bp - d.B, st));
   launch_inject(d, MODE_SOLVE, nullptr, MAPDN_F64, h->t_pl, h->t_ql, h->t_pv, h->t_q, st);
-  nr_launch(h, st);
+  nr_launch(h, MODE_SOLVE, nullptr, nullptr, nullptr, st);
   if (vm_pu) transpose_out(h, d.nrbuf, 1.0, h->vm_row, vm_pu, d.nb, st);
   if (va_degree) transpose_out(h, d.nrbuf, 180.0 / M_PI, h->va_row, va_degree, d.nb, st);
   if (iterations) launch_copy_i32(d.iters, iterations, d.B, st);
@@ -455,7 +472,7 @@ int mapdn_get_schedule(const mapdn_handle* h, int32_t W, int32_t* n_rows, int32_
   Schedule S;
   build_schedule(h->plan, W, S);
   *n_rows = S.R;
-  if (rows) for (size_t i = 0; i < S.steps.size(); ++i) rows[i] = S.steps[i].k;
+  if (rows) for (size_t i = 0; i < S.steps.size(); ++i) rows[i] = (S.steps[i].flags & S_LIVE) ? S.steps[i].k : -1;
   if (parent) std::memcpy(parent, h->plan.par.data(), h->plan.par.size() * sizeof(int32_t));
   return MAPDN_OK;
 }

@@ -133,6 +133,30 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
 //  (polynomial sin/cos, full sincos only when a lane diverges).  Children are summed in a canonical
 //  order, so results are bit-identical for every W and L.
 // =================================================================================================
+__device__ __forceinline__ double barrier(int type, double v) {
+  switch (type) {
+    case MAPDN_BARRIER_L1: return fabs(v - 1.0);                               // l1.py:7
+    case MAPDN_BARRIER_L2: return 2.0 * (v - 1.0) * (v - 1.0);                 // l2.py:7
+    case MAPDN_BARRIER_COURANT_BELTRAMI: {                                     // courant_beltrami.py:7
+      const double a = fmax(0.0, v - 1.05), b = fmax(0.0, 0.95 - v);
+      return a * a + b * b;
+    }
+    case MAPDN_BARRIER_BOWL: {                                                 // bowl.py:6-12
+      const double dv = fabs(v - 1.0);
+      if (dv > 0.05) return 2.0 * dv - 0.095;
+      const double scale = 0.1;
+      const double nrm = 1.0 / sqrt(2.0 * M_PI * scale * scale) * exp(-0.5 * (v - 1.0) * (v - 1.0) / (scale * scale));
+      return -0.01 * nrm + 0.04;
+    }
+    default: {                                                                 // bump.py:6-12
+      if (fabs(v) < 1.0) return exp(-1.0 / (1.0 - v * v * v * v));
+      if (v > 1.0 && v < 3.0) { const double w = v - 2.0; return exp(-1.0 / (1.0 - w * w * w * w)); }
+      return 0.0;
+    }
+  }
+}
+
+struct FwdOps { double ek, fk, ep, fp, sr, si; };
 struct BwdOps { double h0, h1, g0, g1, g2, g3; };
 
 __device__ __forceinline__ void lds_barrier() {
@@ -182,19 +206,19 @@ __device__ __forceinline__ void bst(double x, __amdgpu_buffer_rsrc_t r, unsigned
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, voff, soff, 0);
 }
 
-template <int W>
-__global__ void __launch_bounds__(64 * W) k_nr_wtree(Dev d) {
+template <int W, int L>
+__global__ void __launch_bounds__(64 * W)
+k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ terminated, double* __restrict__ info) {
   extern __shared__ double lds[];
   // worker = (wave w, lane group s): S = 64/L sub-workers per wave, each serving the same L envs of
-  // this workgroup but eliminating a DIFFERENT node per row.  Per-lane step records + predication
-  // replace scalar branches, so one wave instruction does S nodes' worth of work.
+  // this workgroup but eliminating a DIFFERENT node per row.  Per-lane step records; the step body
+  // is branch-free (zero / trash slots instead of predicated LDS traffic), so one wave instruction
+  // does S nodes' worth of work and the compiler can issue every LDS read of a row up front.
+  constexpr unsigned S = 64u / L, Wt = (unsigned)W * S;
   const unsigned lane = threadIdx.x & 63u;
   const unsigned w = threadIdx.x >> 6;
-  const unsigned L = (unsigned)d.nr_lanes;       // envs per workgroup
-  const unsigned S = 64u / L;
   const unsigned sw = lane / L, el = lane % L;
   const unsigned t = w * S + sw;                 // worker id, 0 .. Wt-1
-  const unsigned Wt = (unsigned)W * S;
   const unsigned e = blockIdx.x * L + el;
   const int R = d.nr_rows;
   const unsigned n = (unsigned)d.n;
@@ -205,11 +229,11 @@ __global__ void __launch_bounds__(64 * W) k_nr_wtree(Dev d) {
   unsigned vo[NBF];                              // env + field + worker offsets (loop-invariant VGPRs)
 #pragma unroll
   for (int f = 0; f < NBF; ++f) vo[f] = e * 8u + (unsigned)f * rb + t * (unsigned)R * bb;
-  // LDS map: [V (n+1) x 2][Sbus n x 2][contribution slots x 8][x slots x 2]  (each x L envs, doubles)
-  //          [verdict bytes 64*W][schedule Wt*R*80 B][overflow child list]
+  // LDS map (doubles, each x L envs): [V (n+2) x 2][Sbus (n+2) x 2][contribution slots x 8][x slots x 2]
+  //          then [verdict bytes 64*W][schedule Wt*R*80 B][overflow child list]; node n = slack, n+1 = trash
   double* sV = lds + el;                                    // sV[(2k + c)*L]
-  double* sS = sV + (size_t)2 * (n + 1) * L;                // sS[(2k + c)*L]
-  double* cs = sS + (size_t)2 * n * L;                      // cs[(slot*8 + item)*L]
+  double* sS = sV + (size_t)2 * (n + 2) * L;                // sS[(2k + c)*L]
+  double* cs = sS + (size_t)2 * (n + 2) * L;                // cs[(slot*8 + item)*L]
   double* xs = cs + (size_t)d.nr_cslots * 8 * L;            // xs[(slot*2 + item)*L]
   uint8_t* s_ok = (uint8_t*)(xs - el + (size_t)d.nr_xslots * 2 * L);   // [Wt][L], Wt*L = 64*W
   StepRec* s_sched = (StepRec*)(s_ok + 64 * W);             // 16-byte aligned: all sizes above are multiples of 64
@@ -221,138 +245,155 @@ __global__ void __launch_bounds__(64 * W) k_nr_wtree(Dev d) {
     for (unsigned i = threadIdx.x; i < (unsigned)d.nr_nclist; i += 64u * W) s_clist[i] = d.clist[i];
     // Sbus of this workgroup's envs -> LDS; flat start (runpp init="auto": every bus at the slack set-point)
     const double* gS = d.nrbuf + (size_t)d.r_sbus * d.Bp + e;
-    for (unsigned i = t; i < 2u * n; i += Wt) sS[(size_t)i * L] = gS[(size_t)i * d.Bp];
-    for (unsigned k = t; k <= n; k += Wt) { sV[(size_t)(2 * k) * L] = vroot; sV[(size_t)(2 * k + 1) * L] = 0.0; }
+    for (unsigned i = t; i < 2u * (n + 2); i += Wt) sS[(size_t)i * L] = (i < 2u * n) ? gS[(size_t)i * d.Bp] : 0.0;
+    for (unsigned k = t; k < n + 2; k += Wt) { sV[(size_t)(2 * k) * L] = vroot; sV[(size_t)(2 * k + 1) * L] = 0.0; }
+    if (t == 0) {                                // the ZERO slots (second-to-last of each kind) read as 0 forever
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cs[((size_t)(d.nr_cslots - 2) * 8 + i) * L] = 0.0;
+      xs[((size_t)(d.nr_xslots - 2) * 2) * L] = 0.0; xs[((size_t)(d.nr_xslots - 2) * 2 + 1) * L] = 0.0;
+    }
   }
   __syncthreads();
   const StepRec* seq = s_sched + (size_t)t * R;  // per lane: this worker's records
 
-  bool done = d.active[e] == 0;
+  const bool act = d.active[e] != 0;              // this env takes part in the solve (same for all its workers)
+  bool done = !act;
   bool conv = false;
   int it = 0;
-  if (__all(done)) {                             // identical in all waves of the group
-    if (t == 0) { d.iters[e] = 0; d.conv[e] = 0; }
-    return;
-  }
+  const bool nothing_to_solve = __all(done);      // identical in all waves of the group
 
   bool allok;
   double cS0, cS1, cD0, cD1, cD2, cD3, cR0, cR1;   // register carry child -> parent (same worker, next row)
   double x0, x1;                                   // register carry parent -> child in the backward sweep
 
+  auto load_ops = [&](const StepRec& T, FwdOps& o) {     // LDS operand reads (V is constant during a forward sweep)
+    const unsigned k = (unsigned)T.k, p = (unsigned)T.p;
+    o.ek = sV[(size_t)(2 * k) * L]; o.fk = sV[(size_t)(2 * k + 1) * L];
+    o.ep = sV[(size_t)(2 * p) * L]; o.fp = sV[(size_t)(2 * p + 1) * L];
+    o.sr = sS[(size_t)(2 * k) * L]; o.si = sS[(size_t)(2 * k + 1) * L];
+  };
   auto load_bwd = [&](unsigned sb, BwdOps& o) {
     o.h0 = bld(rs, vo[NB_H0], sb); o.h1 = bld(rs, vo[NB_H1], sb);
     o.g0 = bld(rs, vo[NB_G0], sb); o.g1 = bld(rs, vo[NB_G1], sb); o.g2 = bld(rs, vo[NB_G2], sb); o.g3 = bld(rs, vo[NB_G3], sb);
   };
 
-  // NOTE on VMEM accounting: every step issues EXACTLY the same vector-memory instructions (fwd: 6
-  // stores, bwd: 6 loads) regardless of flags / idle steps (idle steps write don't-care values to
-  // their dummy block): only with a path-independent count can the compiler's vmcnt waits be exact.
-  auto fwd_step = [&](const StepRec& T, unsigned sb) {
-    const uint32_t fl = T.flags;                 // per lane (differs between the sub-workers of a wave)
-    double h0 = 0, h1 = 0, G0 = 0, G1 = 0, G2 = 0, G3 = 0;
-    if (T.k >= 0) {
-      const unsigned k = (unsigned)T.k, p = (unsigned)T.p;
-      const double gkk = T.ykk[0], bkk = T.ykk[1], gkp = T.ykp[0], bkp = T.ykp[1], gpk = T.ypk[0], bpk = T.ypk[1];
-      const double ek = sV[(size_t)(2 * k) * L], fk = sV[(size_t)(2 * k + 1) * L];
-      const double ep = sV[(size_t)(2 * p) * L], fp = sV[(size_t)(2 * p + 1) * L];
-      const double osr = sS[(size_t)(2 * k) * L], osi = sS[(size_t)(2 * k + 1) * L];
-      // A_kp = V_k conj(Y_kp V_p),  A_pk = V_p conj(Y_pk V_k),  A_kk = |V_k|^2 conj(Y_kk)
-      const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
-      const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
-      const double ur = gpk * ek - bpk * fk, ui = gpk * fk + bpk * ek;
-      const double apk_r = ep * ur + fp * ui, apk_i = fp * ur - ep * ui;
-      const double v2 = ek * ek + fk * fk;
-      const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
-      const bool cin = (fl & S_CARRY_IN) != 0;
-      double aS0 = cin ? cS0 : 0.0, aS1 = cin ? cS1 : 0.0, aD0 = cin ? cD0 : 0.0, aD1 = cin ? cD1 : 0.0,
-             aD2 = cin ? cD2 : 0.0, aD3 = cin ? cD3 : 0.0, aR0 = cin ? cR0 : 0.0, aR1 = cin ? cR1 : 0.0;
-      const int nch = (int)(fl >> 16);
-      auto gather = [&](int slot) {
-        const double* c = cs + (size_t)slot * 8 * L;
+  // Every step issues EXACTLY the same memory instructions whatever its flags (fwd: 16 gather reads,
+  // 8 contribution writes, 6 factor stores; bwd: 2 x reads, 2 x writes, 2 V writes, 6 factor loads):
+  // absent children / parents are the ZERO slot, unread outputs go to the TRASH slot / node.
+  auto fwd_step = [&](const StepRec& T, const FwdOps& o, unsigned sb) {
+    const uint32_t fl = T.flags;
+    // (1) the gathers first: they depend on the previous row's writes and head the critical path
+    const double* c0 = cs + (size_t)(T.chs & 1023u) * (8 * L);
+    const double* c1 = cs + (size_t)((T.chs >> 10) & 1023u) * (8 * L);
+    double g0[8], g1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { g0[i] = c0[i * L]; g1[i] = c1[i * L]; }
+    // (2) child-independent part: A_kp = V_k conj(Y_kp V_p), A_pk = V_p conj(Y_pk V_k), A_kk = |V_k|^2 conj(Y_kk)
+    const double gkk = T.ykk[0], bkk = T.ykk[1], gkp = T.ykp[0], bkp = T.ykp[1], gpk = T.ypk[0], bpk = T.ypk[1];
+    const double ek = o.ek, fk = o.fk, ep = o.ep, fp = o.fp;
+    const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
+    const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
+    const double ur = gpk * ek - bpk * fk, ui = gpk * fk + bpk * ek;
+    const double apk_r = ep * ur + fp * ui, apk_i = fp * ur - ep * ui;
+    const double v2 = ek * ek + fk * fk;
+    const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
+    // (3) children: register carry (same worker, previous row) + LDS slots, canonical order
+    const bool cin = (fl & S_CARRY_IN) != 0;
+    double aS0 = (cin ? cS0 : 0.0) + g0[0], aS1 = (cin ? cS1 : 0.0) + g0[1], aD0 = (cin ? cD0 : 0.0) + g0[2],
+           aD1 = (cin ? cD1 : 0.0) + g0[3], aD2 = (cin ? cD2 : 0.0) + g0[4], aD3 = (cin ? cD3 : 0.0) + g0[5],
+           aR0 = (cin ? cR0 : 0.0) + g0[6], aR1 = (cin ? cR1 : 0.0) + g0[7];
+    aS0 += g1[0]; aS1 += g1[1]; aD0 += g1[2]; aD1 += g1[3]; aD2 += g1[4]; aD3 += g1[5]; aR0 += g1[6]; aR1 += g1[7];
+    const int nch = (int)(fl >> 16);
+    if (nch > 2) {                               // rare: junctions with more than two slot children
+      auto gather = [&](unsigned slot) {
+        const double* c = cs + (size_t)slot * (8 * L);
         aS0 += c[0]; aS1 += c[L]; aD0 += c[2 * L]; aD1 += c[3 * L]; aD2 += c[4 * L]; aD3 += c[5 * L];
         aR0 += c[6 * L]; aR1 += c[7 * L];
       };
-      if (nch > 0) gather(T.ch[0]);
-      if (nch > 1) gather(T.ch[1]);
-      if (nch > 2) gather(T.ch[2]);
-      for (int j = 3; j < nch; ++j) gather(s_clist[T.cptr + j - 3]);
-      // S_k = V_k conj(sum_j Y_kj V_j), mismatch F_k = S_k - Sbus_k
-      const double sr = akk_r + akp_r + aS0, si = akk_i + akp_i + aS1;
-      const double Fp = sr - osr, Fq = si - osi;
-      allok = allok && (fabs(Fp) < tol) && (fabs(Fq) < tol);
-      const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) - aD1;
-      const double D2 = (sr - akk_r) - aD2, D3 = (si + akk_i) - aD3;
-      const double r0 = Fp - aR0, r1 = Fq - aR1;
-      const double idet = rcp_nr(D0 * D3 - D1 * D2);
-      const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
-      h0 = I0 * r0 + I1 * r1; h1 = I2 * r0 + I3 * r1;
-      if (!(fl & S_PARENT_ROOT)) {
-        // U = J'(k,p) = [[Im A_kp, Re A_kp], [-Re A_kp, Im A_kp]],  L = J'(p,k) likewise from A_pk
-        G0 = I0 * akp_i - I1 * akp_r; G1 = I0 * akp_r + I1 * akp_i;
-        G2 = I2 * akp_i - I3 * akp_r; G3 = I2 * akp_r + I3 * akp_i;
-        const double s0 = apk_i * G0 + apk_r * G2, s1 = apk_i * G1 + apk_r * G3;
-        const double s2 = apk_i * G2 - apk_r * G0, s3 = apk_i * G3 - apk_r * G1;
-        const double t0 = apk_i * h0 + apk_r * h1, t1 = apk_i * h1 - apk_r * h0;
-        if (fl & S_CARRY_OUT) {
-          cS0 = apk_r; cS1 = apk_i; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
-        } else {
-          double* c = cs + (size_t)(T.slots & 1023u) * 8 * L;
-          c[0] = apk_r; c[L] = apk_i; c[2 * L] = s0; c[3 * L] = s1; c[4 * L] = s2; c[5 * L] = s3; c[6 * L] = t0; c[7 * L] = t1;
-        }
-      }
+      gather((T.chs >> 20) & 1023u);
+      for (int j = 3; j < nch; ++j) gather((unsigned)s_clist[T.cptr + j - 3]);
     }
+    // S_k = V_k conj(sum_j Y_kj V_j), mismatch F_k = S_k - Sbus_k
+    const double sr = akk_r + akp_r + aS0, si = akk_i + akp_i + aS1;
+    const double Fp = sr - o.sr, Fq = si - o.si;
+    allok = allok && (!(fl & S_LIVE) || ((fabs(Fp) < tol) && (fabs(Fq) < tol)));
+    const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) - aD1;
+    const double D2 = (sr - akk_r) - aD2, D3 = (si + akk_i) - aD3;
+    const double r0 = Fp - aR0, r1 = Fq - aR1;
+    const double idet = rcp_nr(D0 * D3 - D1 * D2);
+    const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
+    const double h0 = I0 * r0 + I1 * r1, h1 = I2 * r0 + I3 * r1;
+    // U = J'(k,p) = [[Im A_kp, Re A_kp], [-Re A_kp, Im A_kp]],  L = J'(p,k) likewise from A_pk
+    const double G0 = I0 * akp_i - I1 * akp_r, G1 = I0 * akp_r + I1 * akp_i;
+    const double G2 = I2 * akp_i - I3 * akp_r, G3 = I2 * akp_r + I3 * akp_i;
+    const double s0 = apk_i * G0 + apk_r * G2, s1 = apk_i * G1 + apk_r * G3;
+    const double s2 = apk_i * G2 - apk_r * G0, s3 = apk_i * G3 - apk_r * G1;
+    const double t0 = apk_i * h0 + apk_r * h1, t1 = apk_i * h1 - apk_r * h0;
+    // contribution to the parent: registers (consumed only if the next step has S_CARRY_IN) and the
+    // LDS slot (TRASH unless S_SCRATCH_OUT)
+    cS0 = apk_r; cS1 = apk_i; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
+    double* c = cs + (size_t)(T.slots & 1023u) * (8 * L);
+    c[0] = apk_r; c[L] = apk_i; c[2 * L] = s0; c[3 * L] = s1; c[4 * L] = s2; c[5 * L] = s3; c[6 * L] = t0; c[7 * L] = t1;
     bst(h0, rs, vo[NB_H0], sb); bst(h1, rs, vo[NB_H1], sb);
     bst(G0, rs, vo[NB_G0], sb); bst(G1, rs, vo[NB_G1], sb); bst(G2, rs, vo[NB_G2], sb); bst(G3, rs, vo[NB_G3], sb);
   };
-  auto bwd_step = [&](const StepRec& T, const BwdOps& o) {
+  // ek/fk: this node's voltage, read from LDS one row ahead (only its own step ever writes it)
+  auto bwd_step = [&](const StepRec& T, const BwdOps& o, double ek, double fk) {
     const uint32_t fl = T.flags;
     const uint32_t slots = T.slots;
-    const bool live = T.k >= 0;
-    double y0 = o.h0, y1 = o.h1;
-    if (live && !(fl & S_PARENT_ROOT)) {
-      double p0, p1;
-      if (fl & S_CARRY_OUT) { p0 = x0; p1 = x1; }
-      else { const double* xp = xs + (size_t)(slots >> 20) * 2 * L; p0 = xp[0]; p1 = xp[L]; }
-      y0 -= o.g0 * p0 + o.g1 * p1;
-      y1 -= o.g2 * p0 + o.g3 * p1;
-    }
+    const double* xp = xs + (size_t)(slots >> 20) * (2 * L);       // parent's x slot (ZERO slot for slack parents)
+    const double q0 = xp[0], q1 = xp[L];
+    const bool cout = (fl & S_CARRY_OUT) != 0;
+    const double p0 = cout ? x0 : q0, p1 = cout ? x1 : q1;
+    const double y0 = o.h0 - (o.g0 * p0 + o.g1 * p1);
+    const double y1 = o.h1 - (o.g2 * p0 + o.g3 * p1);
+    x0 = y0; x1 = y1;
+    double* xo = xs + (size_t)((slots >> 10) & 1023u) * (2 * L);   // TRASH unless S_X_OUT
+    xo[0] = y0; xo[L] = y1;
     // newtonpf update: Va += dx_a, Vm += dx_m, V = Vm e^{jVa}, with dx_a = -y0, dx_m = -|V| y1
     //   =>  V <- V (1 - y1) e^{-j y0}   (rotation by the small step; |V|, angle are formed at the end)
     double s, c;
     const double dth = -y0;
-    if (__any(live && !(fabs(dth) <= 0.5))) sincos(dth, &s, &c);   // wave-uniform, only when a lane diverges
-    else sincos_small(dth, &s, &c);
-    if (live) {
-      x0 = y0; x1 = y1;
-      if (fl & S_X_OUT) { double* xo = xs + (size_t)((slots >> 10) & 1023u) * 2 * L; xo[0] = y0; xo[L] = y1; }
-      if (!done) {
-        const unsigned k = (unsigned)T.k;
-        const double ek = sV[(size_t)(2 * k) * L], fk = sV[(size_t)(2 * k + 1) * L];
-        const double sc = 1.0 - y1;
-        sV[(size_t)(2 * k) * L] = sc * (ek * c - fk * s);
-        sV[(size_t)(2 * k + 1) * L] = sc * (ek * s + fk * c);
-      }
-    }
+    sincos_small(dth, &s, &c);
+    if (__any((fl & S_LIVE) && !(fabs(dth) <= 0.5))) sincos(dth, &s, &c);   // wave-uniform, only when a lane diverges
+    const double sc = 1.0 - y1;
+    const double en = sc * (ek * c - fk * s), fn = sc * (ek * s + fk * c);
+    const unsigned k = (unsigned)T.k;
+    sV[(size_t)(2 * k) * L] = done ? ek : en;                        // converged envs keep their state; idle steps hit the trash node
+    sV[(size_t)(2 * k + 1) * L] = done ? fk : fn;
   };
 
-  for (;;) {
+  while (!nothing_to_solve) {
     // ------------------------------------------------------------------ forward sweep
+    // three rotating record / operand sets (loop unrolled by 3 so the rotation is static): while
+    // row r computes, record r+2 and the LDS operands of row r+1 are already on their way
     allok = true;
     cS0 = cS1 = cD0 = cD1 = cD2 = cD3 = cR0 = cR1 = 0.0;
     {
-      StepRec T0 = seq[0], T1;
+      StepRec T0 = seq[0], T1 = seq[R > 1 ? 1 : 0], T2;
+      FwdOps o0, o1, o2;
+      load_ops(T0, o0);
       unsigned sb = 0;
       int r = 0;
-      for (; r + 1 < R; r += 2) {                // records one row ahead (ping-pong, no copies)
-        T1 = seq[r + 1];
-        fwd_step(T0, sb);
+      for (; r + 2 < R; r += 3) {
+        T2 = seq[r + 2]; load_ops(T1, o1);
+        fwd_step(T0, o0, sb);
         if (W > 1) lds_barrier();
-        if (r + 2 < R) T0 = seq[r + 2];
-        fwd_step(T1, sb + bb);
+        if (r + 3 < R) T0 = seq[r + 3];
+        load_ops(T2, o2);
+        fwd_step(T1, o1, sb + bb);
         if (W > 1) lds_barrier();
-        sb += 2 * bb;
+        if (r + 4 < R) T1 = seq[r + 4];
+        if (r + 3 < R) load_ops(T0, o0);
+        fwd_step(T2, o2, sb + 2 * bb);
+        if (W > 1) lds_barrier();
+        sb += 3 * bb;
       }
-      if (r < R) { fwd_step(T0, sb); if (W > 1) lds_barrier(); }
+      if (r < R) {
+        if (r + 1 < R) load_ops(T1, o1);
+        fwd_step(T0, o0, sb); if (W > 1) lds_barrier();
+      }
+      if (r + 1 < R) { fwd_step(T1, o1, sb + bb); if (W > 1) lds_barrier(); }
     }
     {                                            // AND of the workers' verdicts, per env
       s_ok[t * L + el] = allok ? 1 : 0;
@@ -365,213 +406,208 @@ __global__ void __launch_bounds__(64 * W) k_nr_wtree(Dev d) {
     }
     if (__all(done)) break;                      // same envs, same values in every wave of the group
     // ------------------------------------------------------------------ backward sweep + update
-    // software pipeline of depth 2 on the factor loads (three rotating sets, unrolled by 3)
+    // factor loads (global scratch) two rows ahead, own voltage (LDS) one row ahead
     x0 = x1 = 0.0;
     {
       StepRec T0 = seq[R - 1], T1 = seq[R > 1 ? R - 2 : 0], T2;
       BwdOps o0 = {}, o1 = {}, o2 = {};
+      double e0, f0, e1, f1, e2, f2;
       unsigned sb = (unsigned)(R - 1) * bb;
       load_bwd(sb, o0);
       if (R > 1) load_bwd(sb - bb, o1);
+      e0 = sV[(size_t)(2 * (unsigned)T0.k) * L]; f0 = sV[(size_t)(2 * (unsigned)T0.k + 1) * L];
       int r = R - 1;
       for (; r - 2 >= 0; r -= 3) {
         T2 = seq[r - 2]; load_bwd(sb - 2 * bb, o2);
-        bwd_step(T0, o0);
+        e1 = sV[(size_t)(2 * (unsigned)T1.k) * L]; f1 = sV[(size_t)(2 * (unsigned)T1.k + 1) * L];
+        bwd_step(T0, o0, e0, f0);
         if (W > 1) lds_barrier();
         if (r - 3 >= 0) { T0 = seq[r - 3]; load_bwd(sb - 3 * bb, o0); }
-        bwd_step(T1, o1);
+        e2 = sV[(size_t)(2 * (unsigned)T2.k) * L]; f2 = sV[(size_t)(2 * (unsigned)T2.k + 1) * L];
+        bwd_step(T1, o1, e1, f1);
         if (W > 1) lds_barrier();
         if (r - 4 >= 0) { T1 = seq[r - 4]; load_bwd(sb - 4 * bb, o1); }
-        bwd_step(T2, o2);
+        if (r - 3 >= 0) { e0 = sV[(size_t)(2 * (unsigned)T0.k) * L]; f0 = sV[(size_t)(2 * (unsigned)T0.k + 1) * L]; }
+        bwd_step(T2, o2, e2, f2);
         if (W > 1) lds_barrier();
         sb -= 3 * bb;
       }
-      if (r >= 0) { bwd_step(T0, o0); if (W > 1) lds_barrier(); }
-      if (r - 1 >= 0) { bwd_step(T1, o1); if (W > 1) lds_barrier(); }
+      if (r >= 0) {
+        if (r - 1 >= 0) { e1 = sV[(size_t)(2 * (unsigned)T1.k) * L]; f1 = sV[(size_t)(2 * (unsigned)T1.k + 1) * L]; }
+        bwd_step(T0, o0, e0, f0); if (W > 1) lds_barrier();
+      }
+      if (r - 1 >= 0) { bwd_step(T1, o1, e1, f1); if (W > 1) lds_barrier(); }
     }
     if (!done) ++it;
   }
-  // ------------------------------------------------------------------ solution -> Vout (e, f, |V|, angle)
-  if (W > 1) __syncthreads();
-  {
-    double* gV = d.nrbuf + (size_t)d.r_vout * d.Bp + e;
+  if (t == 0) { d.iters[e] = it; d.conv[e] = conv ? 1 : 0; }
+  // =================================================================== fused epilogue
+  // The workgroup still holds the solution of its L envs in LDS, so the rest of the env step happens
+  // here, spread over the same Wt workers (strided over buses / lines / sgens):
+  //   K6  commit  — pandapower pfsoln/_extract_results: res_bus (vm_pu, va, p_mw, q_mvar incl. the slack
+  //                 injection), res_line.pl_mw, sgen.q_mvar, only for envs whose solve converged
+  //   K7  reward  — VoltageControl._calc_reward (voltage_control_env.py:574-623) on the committed (or, if
+  //                 the solve failed, rolled-back == previous) state, the unsolvable branch (:188-196) and
+  //                 step() bookkeeping (:199-209)
+  const size_t SB = (size_t)d.Bp;
+  if (mode == MODE_SOLVE) {                      // mapdn_solve_only: just the solution
+    double* gV = d.nrbuf + (size_t)d.r_vout * SB + e;
     for (unsigned k = t; k < n; k += Wt) {
       const double ek = sV[(size_t)(2 * k) * L], fk = sV[(size_t)(2 * k + 1) * L];
-      double* o = gV + (size_t)(VOF * k) * d.Bp;
-      o[(size_t)VO_E * d.Bp] = ek; o[(size_t)VO_F * d.Bp] = fk;
-      o[(size_t)VO_VM * d.Bp] = sqrt(ek * ek + fk * fk);          // Vm = |V|
-      o[(size_t)VO_VA * d.Bp] = atan2(fk, ek);                     // Va = angle(V)
-    }
-  }
-  if (t == 0) { d.iters[e] = it; d.conv[e] = conv ? 1 : 0; }
-}
-
-// =================================================================================================
-// K6  commit — pandapower pfsoln/_extract_results: res_bus (vm_pu, va, p_mw, q_mvar incl. the slack
-//     injection), res_line.pl_mw, sgen.q_mvar, for envs whose solve converged.  Fully parallel:
-//     thread = (item, env) with item in [buses | lines | sgens].  Does not touch done/pending.
-// =================================================================================================
-__device__ __forceinline__ bool commit_cond(const Dev& d, int mode, int e) {
-  if (!d.conv[e]) return false;
-  return mode == MODE_STEP ? (d.done[e] == 0) : (d.pending[e] != 0);
-}
-
-__global__ void __launch_bounds__(256) k_commit(Dev d, int mode) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= d.B) return;
-  if (!commit_cond(d, mode, e)) return;
-  const size_t S = (size_t)d.Bp;
-  int y = blockIdx.y;
-  if (y < d.nb) {                                           // ---- bus at elimination position k (k == n: slack)
-    const int k = y, bus = d.bus_of_pos[k];
-    const double* vo = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * k) * S + e;
-    const double vm = vo[(size_t)VO_VM * S], va = vo[(size_t)VO_VA * S];
-    d.vm[(size_t)bus * S + e] = vm;
-    d.va[(size_t)bus * S + e] = va;
-    double P = 0.0, Q = 0.0;
-    if (k < d.n) {
-      for (int i = d.load_ptr[k]; i < d.load_ptr[k + 1]; ++i) { const size_t o = (size_t)d.load_idx[i] * S + e; P += d.cur_pl[o]; Q += d.cur_ql[o]; }
-      for (int i = d.sgen_ptr[k]; i < d.sgen_ptr[k + 1]; ++i) { const size_t o = (size_t)d.sgen_idx[i] * S + e; P -= d.cur_pv[o]; Q -= d.q_new[o]; }
-    } else {
-      // slack: res_bus = -(V conj(I)) * sn, I = Y_rr V_r + sum_children Y_rk V_k   (consumer sign)
-      double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;
-      for (int j = 0; j < d.n_root_children; ++j) {
-        const double* cb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * d.root_children[j]) * S + e;
-        const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ek = cb[(size_t)VO_E * S], fk = cb[(size_t)VO_F * S];
-        ir += g * ek - b * fk; ii += g * fk + b * ek;
-      }
-      P = -(d.vroot * ir) * d.sn; Q = (d.vroot * ii) * d.sn;
-    }
-    P += d.shunt_p[k] * vm * vm; Q += d.shunt_q[k] * vm * vm;
-    d.res_p[(size_t)bus * S + e] = P; d.res_q[(size_t)bus * S + e] = Q;
-    return;
-  }
-  y -= d.nb;
-  if (y < d.n_line) {                                       // ---- res_line.pl_mw = Re(Sf + St) * sn
-    const LineFlow Ln = d.lines[y];
-    double pl = 0.0;
-    if (Ln.fpos >= 0) {
-      const double* fb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * Ln.fpos) * S + e;
-      const double* tb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * Ln.tpos) * S + e;
-      const double ef = fb[(size_t)VO_E * S], ff = fb[(size_t)VO_F * S], et = tb[(size_t)VO_E * S], ft = tb[(size_t)VO_F * S];
-      const double ifr = Ln.yff[0] * ef - Ln.yff[1] * ff + Ln.yft[0] * et - Ln.yft[1] * ft;
-      const double ifi = Ln.yff[0] * ff + Ln.yff[1] * ef + Ln.yft[0] * ft + Ln.yft[1] * et;
-      const double itr = Ln.ytf[0] * ef - Ln.ytf[1] * ff + Ln.ytt[0] * et - Ln.ytt[1] * ft;
-      const double iti = Ln.ytf[0] * ff + Ln.ytf[1] * ef + Ln.ytt[0] * ft + Ln.ytt[1] * et;
-      pl = ((ef * ifr + ff * ifi) + (et * itr + ft * iti)) * d.sn;
-    }
-    d.pl[(size_t)y * S + e] = pl;
-    return;
-  }
-  y -= d.n_line;
-  d.cur_q[(size_t)y * S + e] = d.q_new[(size_t)y * S + e];   // ---- sgen.q_mvar of the accepted solve
-}
-
-// =================================================================================================
-// K7  reward — VoltageControl._calc_reward (voltage_control_env.py:574-623) on the committed (or,
-//     if the solve failed, rolled-back == previous) state, the unsolvable branch (:188-196) and
-//     step() bookkeeping (:199-209).  A 64-env group is served by RWJ waves that each reduce a
-//     strided share of the buses / lines; partials are combined through LDS in a fixed order.
-// =================================================================================================
-__device__ __forceinline__ double barrier(int type, double v) {
-  switch (type) {
-    case MAPDN_BARRIER_L1: return fabs(v - 1.0);                               // l1.py:7
-    case MAPDN_BARRIER_L2: return 2.0 * (v - 1.0) * (v - 1.0);                 // l2.py:7
-    case MAPDN_BARRIER_COURANT_BELTRAMI: {                                     // courant_beltrami.py:7
-      const double a = fmax(0.0, v - 1.05), b = fmax(0.0, 0.95 - v);
-      return a * a + b * b;
-    }
-    case MAPDN_BARRIER_BOWL: {                                                 // bowl.py:6-12
-      const double dv = fabs(v - 1.0);
-      if (dv > 0.05) return 2.0 * dv - 0.095;
-      const double scale = 0.1;
-      const double nrm = 1.0 / sqrt(2.0 * M_PI * scale * scale) * exp(-0.5 * (v - 1.0) * (v - 1.0) / (scale * scale));
-      return -0.01 * nrm + 0.04;
-    }
-    default: {                                                                 // bump.py:6-12
-      if (fabs(v) < 1.0) return exp(-1.0 / (1.0 - v * v * v * v));
-      if (v > 1.0 && v < 3.0) { const double w = v - 2.0; return exp(-1.0 / (1.0 - w * w * w * w)); }
-      return 0.0;
-    }
-  }
-}
-
-#define RWJ 8   // waves (bus partitions) per 64-env group in k_reward
-__global__ void __launch_bounds__(64 * RWJ)
-k_reward(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ terminated, double* __restrict__ info) {
-  __shared__ double sm[8][RWJ][64];
-  const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + lane;
-  const bool valid = e < d.B;
-  const size_t S = (size_t)d.Bp;
-  if (mode == MODE_RESET) {
-    if (j == 0 && valid) {
-      d.adv_row[e] = -1;
-      if (d.pending[e] && d.conv[e]) { d.pending[e] = 0; d.done[e] = 0; }
+      double* o = gV + (size_t)(VOF * k) * SB;
+      o[(size_t)VO_E * SB] = ek; o[(size_t)VO_F * SB] = fk;
+      o[(size_t)VO_VM * SB] = sqrt(ek * ek + fk * fk);            // Vm = |V|
+      o[(size_t)VO_VA * SB] = atan2(fk, ek);                       // Va = angle(V)
     }
     return;
   }
-  const bool frozen = valid && d.done[e] != 0;
+  const bool commitf = act && conv;              // act: STEP -> not frozen, RESET -> pending
+  const bool valid = e < (unsigned)d.B;
   const double vlo = d.v_lower, vhi = d.v_upper, vref = 0.5 * (vlo + vhi);
-  // ---- partial statistics of this wave's share of the buses / lines (strided, coalesced over envs)
-  double n_lo = 0, n_hi = 0, dev = 0.0, vsum = 0.0, mdrop = 0.0, mrise = 0.0, bar = 0.0, line_loss = 0.0;
-  if (valid && !frozen) {
-    for (int b = j; b < d.nb; b += RWJ) {
-      const double v = d.vm[(size_t)b * S + e];
-      n_lo += (v < vlo) ? 1.0 : 0.0; n_hi += (v > vhi) ? 1.0 : 0.0;
-      dev += fabs(v - vref); vsum += v;
-      mdrop = fmax(mdrop, (v < vlo) ? (vlo - v) : 0.0);
-      mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
-      bar += barrier(d.barrier_type, v);
+  double n_lo = 0, n_hi = 0, dev = 0.0, vsum = 0.0, mdrop = 0.0, mrise = 0.0, bar = 0.0, line_loss = 0.0, q_loss = 0.0, q_fail = 0.0;
+  // Topology constants are read through the CONSTANT address space: the compiler then knows that no
+  // store of this kernel can alias them and batches the loads of the unrolled, branch-free loops
+  // (only the stores are predicated).  Envs whose solve failed (rare) take statistics from the
+  // rolled-back state in a separate slow path.
+  typedef const __attribute__((address_space(4))) int32_t* c_i32;
+  typedef const __attribute__((address_space(4))) double* c_f64;
+  const c_i32 bus_of_pos = (c_i32)(unsigned long long)d.bus_of_pos;
+  const c_f64 shunt_p = (c_f64)(unsigned long long)d.shunt_p, shunt_q = (c_f64)(unsigned long long)d.shunt_q;
+  const c_f64 linec = (c_f64)(unsigned long long)d.lines;          // LineFlow = {int32 fpos, tpos; double y[8]} = 9 x 8 bytes
+  // ---- buses (elimination positions 0..n-1; the slack follows)
+#pragma unroll 4
+  for (unsigned k = t; k < n; k += Wt) {
+    const size_t o = (size_t)bus_of_pos[k] * SB + e;
+    const double ek = sV[(size_t)(2 * k) * L], fk = sV[(size_t)(2 * k + 1) * L];
+    const double v = sqrt(ek * ek + fk * fk);                        // res_bus.vm_pu = |V|
+    if (commitf) {
+      d.vm[o] = v;
+      d.va[o] = atan2(fk, ek);                                       // res_bus.va (rad here) = angle(V)
+      d.res_p[o] = -sS[(size_t)(2 * k) * L] * d.sn + shunt_p[k] * v * v;      // bus demand = -Sbus * sn_mva (+ shunt)
+      d.res_q[o] = -sS[(size_t)(2 * k + 1) * L] * d.sn + shunt_q[k] * v * v;
     }
-    for (int l = j; l < d.n_line; l += RWJ) line_loss += d.pl[(size_t)l * S + e];
+    n_lo += (v < vlo) ? 1.0 : 0.0; n_hi += (v > vhi) ? 1.0 : 0.0;
+    dev += fabs(v - vref); vsum += v;
+    mdrop = fmax(mdrop, (v < vlo) ? (vlo - v) : 0.0);
+    mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
+    bar += barrier(d.barrier_type, v);
   }
-  sm[0][j][lane] = n_lo; sm[1][j][lane] = n_hi; sm[2][j][lane] = dev; sm[3][j][lane] = vsum;
-  sm[4][j][lane] = mdrop; sm[5][j][lane] = mrise; sm[6][j][lane] = bar; sm[7][j][lane] = line_loss;
+  if (t == n % Wt) {                              // the slack bus (position n)
+    const size_t o = (size_t)bus_of_pos[n] * SB + e;
+    const double v = vroot;                       // committed slack voltage never changes
+    if (commitf) {
+      // res_bus = -(V conj(I)) * sn, I = Y_rr V_r + sum_children Y_rk V_k   (consumer sign)
+      double ir = d.yrr0 * vroot, ii = d.yrr1 * vroot;
+      for (int j = 0; j < d.n_root_children; ++j) {
+        const unsigned c = (unsigned)d.root_children[j];
+        const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ec = sV[(size_t)(2 * c) * L], fc = sV[(size_t)(2 * c + 1) * L];
+        ir += g * ec - b * fc; ii += g * fc + b * ec;
+      }
+      d.vm[o] = vroot; d.va[o] = 0.0;
+      d.res_p[o] = -(vroot * ir) * d.sn + shunt_p[n] * vroot * vroot;
+      d.res_q[o] = (vroot * ii) * d.sn + shunt_q[n] * vroot * vroot;
+    }
+    n_lo += (v < vlo) ? 1.0 : 0.0; n_hi += (v > vhi) ? 1.0 : 0.0;
+    dev += fabs(v - vref); vsum += v;
+    mdrop = fmax(mdrop, (v < vlo) ? (vlo - v) : 0.0);
+    mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
+    bar += barrier(d.barrier_type, v);
+  }
+  // ---- res_line.pl_mw = Re(Sf + St) * sn   (out-of-service rows: fpos = tpos = slack, all-zero admittances)
+#pragma unroll 4
+  for (unsigned l = t; l < (unsigned)d.n_line; l += Wt) {
+    const c_f64 Lc = linec + (size_t)l * 9;
+    const c_i32 Li = (c_i32)Lc;
+    const unsigned a = (unsigned)Li[0], b = (unsigned)Li[1];
+    const double yffr = Lc[1], yffi = Lc[2], yftr = Lc[3], yfti = Lc[4], ytfr = Lc[5], ytfi = Lc[6], yttr = Lc[7], ytti = Lc[8];
+    const double ef = sV[(size_t)(2 * a) * L], ff = sV[(size_t)(2 * a + 1) * L], et = sV[(size_t)(2 * b) * L], ft = sV[(size_t)(2 * b + 1) * L];
+    const double ifr = yffr * ef - yffi * ff + yftr * et - yfti * ft;
+    const double ifi = yffr * ff + yffi * ef + yftr * ft + yfti * et;
+    const double itr = ytfr * ef - ytfi * ff + yttr * et - ytti * ft;
+    const double iti = ytfr * ff + ytfi * ef + yttr * ft + ytti * et;
+    const double pl = ((ef * ifr + ff * ifi) + (et * itr + ft * iti)) * d.sn;
+    if (commitf) d.pl[(size_t)l * SB + e] = pl;
+    line_loss += pl;
+  }
+  // ---- sgen.q_mvar of the accepted solve; q statistics
+#pragma unroll 3
+  for (unsigned j = t; j < (unsigned)d.ns; j += Wt) {
+    const size_t o = (size_t)j * SB + e;
+    const double qn = d.q_new[o];
+    if (commitf) d.cur_q[o] = qn;
+    q_loss += fabs(qn); q_fail += fabs(qn);                          // :604-606, :189
+  }
+  // ---- slow path (wave-uniform, rare): an env of this wave is active but did not converge -> its
+  // statistics come from the PREVIOUS committed state (voltage_control_env.py:190 restores last_powergrid)
+  if (mode == MODE_STEP && __any(act && !conv)) {
+    double a_lo = 0, a_hi = 0, a_dev = 0, a_sum = 0, a_drop = 0, a_rise = 0, a_bar = 0, a_ll = 0, a_ql = 0;
+    for (unsigned k = t; k <= n; k += Wt) {
+      const double v = valid ? d.vm[(size_t)bus_of_pos[k] * SB + e] : 1.0;
+      a_lo += (v < vlo) ? 1.0 : 0.0; a_hi += (v > vhi) ? 1.0 : 0.0;
+      a_dev += fabs(v - vref); a_sum += v;
+      a_drop = fmax(a_drop, (v < vlo) ? (vlo - v) : 0.0);
+      a_rise = fmax(a_rise, (v > vhi) ? (v - vhi) : 0.0);
+      a_bar += barrier(d.barrier_type, v);
+    }
+    for (unsigned l = t; l < (unsigned)d.n_line; l += Wt) a_ll += valid ? d.pl[(size_t)l * SB + e] : 0.0;
+    for (unsigned j = t; j < (unsigned)d.ns; j += Wt) a_ql += fabs(d.cur_q[(size_t)j * SB + e]);
+    if (!commitf) { n_lo = a_lo; n_hi = a_hi; dev = a_dev; vsum = a_sum; mdrop = a_drop; mrise = a_rise; bar = a_bar; line_loss = a_ll; q_loss = a_ql; }
+  }
+  if (mode == MODE_RESET) {
+    if (t == 0 && valid) {
+      d.adv_row[e] = -1;
+      if (act && conv) { d.pending[e] = 0; d.done[e] = 0; }
+    }
+    return;
+  }
+  // ---- combine the workers' partials through LDS (the Sbus region is free now), fixed order
   __syncthreads();
-  if (j != 0 || !valid) return;
+  double* sm = sS;                                // sm[(q*Wt + worker)*L]
+  const double part[10] = {n_lo, n_hi, dev, vsum, mdrop, mrise, bar, line_loss, q_loss, q_fail};
+#pragma unroll
+  for (int q = 0; q < 10; ++q) sm[(size_t)(q * Wt + t) * L] = part[q];
+  __syncthreads();
+  if (t != 0 || !valid) return;
   d.adv_row[e] = -1;
-  if (frozen) {                                  // frozen env
+  if (!act) {                                     // frozen env: terminated earlier in this episode
     reward[e] = 0.0; terminated[e] = 1;
     for (int c = 0; c < MAPDN_N_INFO; ++c) info[(size_t)e * MAPDN_N_INFO + c] = 0.0;
     return;
   }
+  double tot[10];
 #pragma unroll
-  for (int w = 1; w < RWJ; ++w) {                // fixed combination order: deterministic
-    n_lo += sm[0][w][lane]; n_hi += sm[1][w][lane]; dev += sm[2][w][lane]; vsum += sm[3][w][lane];
-    mdrop = fmax(mdrop, sm[4][w][lane]); mrise = fmax(mrise, sm[5][w][lane]); bar += sm[6][w][lane];
-    line_loss += sm[7][w][lane];
+  for (int q = 0; q < 10; ++q) {
+    double a = sm[(size_t)(q * Wt) * L];
+    for (unsigned ww = 1; ww < Wt; ++ww) { const double b = sm[(size_t)(q * Wt + ww) * L]; a = (q == 4 || q == 5) ? fmax(a, b) : a + b; }
+    tot[q] = a;
   }
-  const bool ok = d.conv[e] != 0;
-  double q_loss = 0.0, q_fail = 0.0;
-  for (int jj = 0; jj < d.ns; ++jj) {
-    q_loss += fabs(d.cur_q[(size_t)jj * S + e]);
-    q_fail += fabs(d.q_new[(size_t)jj * S + e]);                               // :189
+  {
+    const bool ok = conv;
+    const double inv_nb = 1.0 / (double)d.nb;
+    const double out = (tot[0] + tot[1]) * inv_nb;
+    const double ql = tot[8] / (double)d.ns, qf = tot[9] / (double)d.ns;
+    const double v_loss = tot[6] * inv_nb * d.voltage_weight;
+    double loss;
+    if (d.use_line_weight) loss = tot[7] / (double)d.n_line * d.line_weight + v_loss;   // :612-613
+    else loss = ql * d.q_weight + v_loss;                                                // :614-615
+    double rew = -loss;
+    double* inf = info + (size_t)e * MAPDN_N_INFO;
+    inf[0] = out; inf[1] = tot[0] * inv_nb; inf[2] = tot[1] * inv_nb;
+    inf[3] = (out > 1e-3) ? 0.0 : 1.0;
+    inf[4] = tot[2] * inv_nb; inf[5] = tot[3] * inv_nb; inf[6] = tot[4]; inf[7] = tot[5];
+    inf[8] = tot[7]; inf[9] = ql; inf[10] = 0.0;
+    if (!ok) { rew -= 200.0; inf[10] = 1.0; inf[3] = 0.0; inf[9] = qf; }                 // :192-196
+    // ---- bookkeeping: next profile row uses t = steps BEFORE the increment (:199 vs :202)
+    const int st = d.steps[e];
+    d.adv_row[e] = d.start_row[e] + st;
+    d.adv_draw[e] = d.draw[e];
+    d.draw[e] += 1;
+    d.steps[e] = st + 1;
+    d.sum_rewards[e] += rew;
+    const bool term = (st + 1 >= d.episode_limit) || !ok;                                 // :204
+    d.done[e] = term ? 1 : 0;
+    reward[e] = rew; terminated[e] = term ? 1 : 0;
   }
-  q_loss /= (double)d.ns; q_fail /= (double)d.ns;
-  const double inv_nb = 1.0 / (double)d.nb;
-  const double out = (n_lo + n_hi) / (double)d.nb;
-  const double v_loss = bar * inv_nb * d.voltage_weight;
-  double loss;
-  if (d.use_line_weight) loss = line_loss / (double)d.n_line * d.line_weight + v_loss;   // :612-613
-  else loss = q_loss * d.q_weight + v_loss;                                              // :614-615
-  double rew = -loss;
-  double* inf = info + (size_t)e * MAPDN_N_INFO;
-  inf[0] = out; inf[1] = n_lo / (double)d.nb; inf[2] = n_hi / (double)d.nb;
-  inf[3] = (out > 1e-3) ? 0.0 : 1.0;
-  inf[4] = dev * inv_nb; inf[5] = vsum * inv_nb; inf[6] = mdrop; inf[7] = mrise;
-  inf[8] = line_loss; inf[9] = q_loss; inf[10] = 0.0;
-  if (!ok) { rew -= 200.0; inf[10] = 1.0; inf[3] = 0.0; inf[9] = q_fail; }              // :192-196
-  // ---- bookkeeping: next profile row uses t = steps BEFORE the increment (:199 vs :202)
-  const int st = d.steps[e];
-  d.adv_row[e] = d.start_row[e] + st;
-  d.adv_draw[e] = d.draw[e];
-  d.draw[e] += 1;
-  d.steps[e] = st + 1;
-  d.sum_rewards[e] += rew;
-  const bool term = (st + 1 >= d.episode_limit) || !ok;                                   // :204
-  d.done[e] = term ? 1 : 0;
-  reward[e] = rew; terminated[e] = term ? 1 : 0;
 }
 
 // =================================================================================================
@@ -641,46 +677,62 @@ __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise) {
 
 // =================================================================================================
 // K8  observe — get_obs (voltage_control_env.py:232-274) / get_state (:213-230).
-//     k_addback: effective PV add-back onto res_bus p/q at sgen buses (:238-244).
+//     The effective PV add-back onto res_bus p/q at sgen buses (:238-244) is a per-column list of
+//     extra rows to add (x_ptr/x_row): only columns of PV buses have any.
 //     k_gather : per output column a precomputed source row of the state block (-1 = zero pad) and
 //                a scale -> env-major output through a 64x64 LDS tile so
 //                both the env-minor reads and the env-major writes are coalesced.
 // =================================================================================================
-__global__ void __launch_bounds__(256) k_addback(Dev d) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;   // position, 0..nb-1
-  if (e >= d.Bp) return;
-  const int bus = d.bus_of_pos[k];
-  const size_t o = (size_t)bus * d.Bp + e;
-  double P = d.res_p[o], Q = d.res_q[o];
-  for (int i = d.sgen_ptr[k]; i < d.sgen_ptr[k + 1]; ++i) {
-    const size_t s = (size_t)d.sgen_idx[i] * d.Bp + e;
-    P += d.cur_pv[s]; Q += d.cur_q[s];
-  }
-  d.pb[o] = P; d.qb[o] = Q;
-}
-
+#define GATHER_HAS_EXTRA 0x40000000   // flag bit in a row descriptor: the column has add-back rows (x_ptr/x_row)
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_gather(const double* __restrict__ base, const int32_t* __restrict__ rows, const double* __restrict__ scales,
-         double scale_all, T* __restrict__ out, int C, int B, int Bp) {
+k_gather(const double* __restrict__ base, const int32_t* rows_g, const double* scales_g,
+         double scale_all, const int32_t* x_ptr_g, const int32_t* x_row_g,
+         T* __restrict__ out, int C, int B, int Bp) {
   __shared__ double tile[64][65];
+  // descriptors are wave-uniform (a wave handles whole columns): read them through the constant
+  // address space -> s_load on the scalar unit, no VMEM round trip ahead of the data loads
+  typedef const __attribute__((address_space(4))) int32_t* c_i32;
+  typedef const __attribute__((address_space(4))) double* c_f64;
+  const c_i32 rows = (c_i32)(unsigned long long)rows_g, x_ptr = (c_i32)(unsigned long long)x_ptr_g, x_row = (c_i32)(unsigned long long)x_row_g;
+  const c_f64 scales = (c_f64)(unsigned long long)scales_g;
   const int c0 = blockIdx.x * 64, e0 = blockIdx.y * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int rw[16]; double sc[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {                 // all descriptor reads first (independent), then the data
+  for (int i = 0; i < 16; ++i) {                 // all descriptor reads first, then the data
     const int c = c0 + ty + 4 * i;
     rw[i] = (c < C) ? rows[c] : -1;
-    sc[i] = (scales && c < C) ? scales[c] : scale_all;
+    sc[i] = (scales_g && c < C) ? scales[c] : scale_all;
   }
+  double v[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i)
-    tile[ty + 4 * i][tx] = (rw[i] >= 0) ? base[(size_t)rw[i] * Bp + e0 + tx] * sc[i] : 0.0;
+    v[i] = (rw[i] >= 0) ? base[(size_t)(rw[i] & ~GATHER_HAS_EXTRA) * Bp + e0 + tx] * sc[i] : 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (rw[i] >= 0 && (rw[i] & GATHER_HAS_EXTRA)) {   // wave-uniform, only the PV-bus columns
+      const int c = c0 + ty + 4 * i;
+      for (int q = x_ptr[c]; q < x_ptr[c + 1]; ++q) v[i] += base[(size_t)x_row[q] * Bp + e0 + tx];
+    }
+    tile[ty + 4 * i][tx] = v[i];
+  }
   __syncthreads();
-  for (int r = ty; r < 64; r += 4) {
-    const int e = e0 + r, c = c0 + tx;
-    if (e < B && c < C) out[(size_t)e * C + c] = (T)tile[tx][r];
+  // write phase: 16 threads x 4 consecutive columns per env row -> 16-byte (f32) / 32-byte (f64) stores
+  const int q4 = (threadIdx.x & 15) * 4, er = threadIdx.x >> 4;
+  const bool vec = (C % 4) == 0;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = er + 16 * pass, e = e0 + r, c = c0 + q4;
+    if (e >= B || c >= C) continue;
+    T* o = out + (size_t)e * C + c;
+    if (vec) {                                   // C % 4 == 0 and c % 4 == 0: the 4 columns exist and are aligned
+      struct alignas(sizeof(T) * 4) V4 { T a, b, c, d; };
+      *reinterpret_cast<V4*>(o) = V4{(T)tile[q4][r], (T)tile[q4 + 1][r], (T)tile[q4 + 2][r], (T)tile[q4 + 3][r]};
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (c + u < C) o[u] = (T)tile[q4 + u][r];
+    }
   }
 }
 
@@ -729,7 +781,6 @@ __global__ void __launch_bounds__(256) k_stats(Dev d, long long* out) {
 // =================================================================================================
 // launchers (host)
 // =================================================================================================
-static inline dim3 grid_env(const Dev& d, int y) { return dim3((d.Bp + 255) / 256, y); }
 
 void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,
                    const double* pv, const double* q, hipStream_t st) {
@@ -737,34 +788,20 @@ void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const
   if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_inject<float>, grid, dim3(256), 0, st, d, mode, (const float*)actions, pl, ql, pv, q);
   else hipLaunchKernelGGL(k_inject<double>, grid, dim3(256), 0, st, d, mode, (const double*)actions, pl, ql, pv, q);
 }
-void launch_nr(const Dev& d, hipStream_t st) {
+// (W, L) instantiations of k_nr_wtree
+#define NR_FOR_EACH(X) X(1, 4) X(1, 8) X(1, 16) X(1, 32) X(2, 4) X(2, 8) X(2, 16) X(2, 32) X(4, 8) X(4, 16) X(4, 32) X(8, 16) X(8, 32)
+void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
   const dim3 grid(d.Bp / d.nr_lanes);
   const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.n, d.nr_cslots, d.nr_xslots, d.nr_rows, d.nr_nclist);
-  switch (d.nr_waves) {
-    case 1: hipLaunchKernelGGL(k_nr_wtree<1>, grid, dim3(64), lds, st, d); break;
-    case 2: hipLaunchKernelGGL(k_nr_wtree<2>, grid, dim3(128), lds, st, d); break;
-    case 4: hipLaunchKernelGGL(k_nr_wtree<4>, grid, dim3(256), lds, st, d); break;
-    case 8: hipLaunchKernelGGL(k_nr_wtree<8>, grid, dim3(512), lds, st, d); break;
-    default: hipLaunchKernelGGL(k_nr_wtree<16>, grid, dim3(1024), lds, st, d); break;
-  }
+#define X(w, l) if (d.nr_waves == w && d.nr_lanes == l) { hipLaunchKernelGGL((k_nr_wtree<w, l>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); return; }
+  NR_FOR_EACH(X)
+#undef X
 }
-int nr_set_lds_limit(int waves, size_t bytes) {
-  hipError_t e = hipSuccess;
-  switch (waves) {
-    case 1: e = hipFuncSetAttribute((const void*)k_nr_wtree<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); break;
-    case 2: e = hipFuncSetAttribute((const void*)k_nr_wtree<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); break;
-    case 4: e = hipFuncSetAttribute((const void*)k_nr_wtree<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); break;
-    case 8: e = hipFuncSetAttribute((const void*)k_nr_wtree<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); break;
-    case 16: e = hipFuncSetAttribute((const void*)k_nr_wtree<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); break;
-    default: break;
-  }
-  return e == hipSuccess ? 0 : -1;
-}
-void launch_commit(const Dev& d, int mode, hipStream_t st) {
-  hipLaunchKernelGGL(k_commit, dim3((d.B + 255) / 256, d.nb + d.n_line + d.ns), dim3(256), 0, st, d, mode);
-}
-void launch_reward(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
-  hipLaunchKernelGGL(k_reward, dim3(d.Bp / 64), dim3(64 * RWJ), 0, st, d, mode, reward, term, info);
+int nr_set_lds_limit(int waves, int lanes, size_t bytes) {
+#define X(w, l) if (waves == w && lanes == l) return hipFuncSetAttribute((const void*)k_nr_wtree<w, l>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
+  NR_FOR_EACH(X)
+#undef X
+  return -2;   // unsupported geometry
 }
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st) {
   hipLaunchKernelGGL(k_reset_begin, dim3((d.B + 255) / 256), dim3(256), 0, st, d, start_rows, first_try);
@@ -773,14 +810,11 @@ void launch_advance(const Dev& d, int add_noise, hipStream_t st) {
   const int pairs = ((d.ns + 1) >> 1) + 2 * ((d.nl + 1) >> 1);
   hipLaunchKernelGGL(k_advance, dim3((d.B + 255) / 256, pairs), dim3(256), 0, st, d, add_noise);
 }
-void launch_addback(const Dev& d, hipStream_t st) {
-  hipLaunchKernelGGL(k_addback, grid_env(d, d.nb), dim3(256), 0, st, d);
-}
 void launch_gather(const Dev& d, const double* base, const int32_t* rows, const double* scales, double scale_all,
-                   void* out, int dtype, int C, hipStream_t st) {
+                   const int32_t* x_ptr, const int32_t* x_row, void* out, int dtype, int C, hipStream_t st) {
   dim3 grid((C + 63) / 64, d.Bp / 64);
-  if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_gather<float>, grid, dim3(256), 0, st, base, rows, scales, scale_all, (float*)out, C, d.B, d.Bp);
-  else hipLaunchKernelGGL(k_gather<double>, grid, dim3(256), 0, st, base, rows, scales, scale_all, (double*)out, C, d.B, d.Bp);
+  if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_gather<float>, grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (float*)out, C, d.B, d.Bp);
+  else hipLaunchKernelGGL(k_gather<double>, grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (double*)out, C, d.B, d.Bp);
 }
 void launch_to_envminor(const Dev& d, const double* src, double* dst, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_to_envminor, dim3((n + 63) / 64, d.Bp / 64), dim3(256), 0, st, src, dst, n, d.B, d.Bp);

@@ -42,10 +42,9 @@ struct Dev {
   // ---- env state
   double *cur_pv, *cur_q, *cur_pl, *cur_ql, *q_new;   // [ns|nl][Bp]  MW / MVAr
   // gatherable state lives in ONE block `gbuf` (rows of Bp doubles) so obs/state columns are plain row
-  // numbers: pb qb [nb] | cur_pv cur_q [ns] | vm va res_p res_q [nb]   (pointers below alias into it)
+  // numbers: cur_pv cur_q [ns] | vm va res_p res_q [nb]   (pointers below alias into it)
   double* gbuf;
   double *vm, *va, *res_p, *res_q;                    // [nb][Bp] by bus id; va in rad
-  double *pb, *qb;                                    // [nb][Bp] res_bus p/q with PV add-back
   double *pl;                                         // [n_line][Bp] res_line.pl_mw
   double *sum_rewards;                                // [Bp]
   int32_t* steps; int64_t* start_row; uint32_t* draw;
@@ -61,23 +60,20 @@ struct Dev {
 
 void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,
                    const double* pv, const double* q, hipStream_t st);
-void launch_nr(const Dev& d, hipStream_t st);
-int nr_set_lds_limit(int waves, size_t bytes);
-// dynamic LDS of k_nr_wtree (W waves, L envs per workgroup => Wt = W*64/L workers): node voltages
-// (2 doubles x (n+1)) and Sbus (2 x n) per env, contribution slots (8 doubles/env), x slots (2 doubles/env),
+void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
+int nr_set_lds_limit(int waves, int lanes, size_t bytes);   // -2: (waves, lanes) not instantiated
+// dynamic LDS of k_nr_wtree (W waves, L envs per workgroup => Wt = W*64/L workers): node voltages and
+// Sbus (2 + 2 doubles x (n+2): nodes, slack, trash) per env, contribution slots (8 doubles/env), x slots (2 doubles/env),
 // verdict bytes, the Wt*R step records, overflow child list
 static inline size_t nr_lds_bytes(int W, int L, int n, int cslots, int xslots, int R, int nclist) {
   const size_t Wt = (size_t)W * (64 / L);
-  return ((size_t)(2 * (n + 1) + 2 * n) + (size_t)cslots * 8 + (size_t)xslots * 2) * (size_t)L * sizeof(double) + (size_t)W * 64 +
+  return ((size_t)(4 * (n + 2)) + (size_t)cslots * 8 + (size_t)xslots * 2) * (size_t)L * sizeof(double) + (size_t)W * 64 +
          Wt * R * sizeof(StepRec) + (size_t)nclist * sizeof(int32_t);
 }
-void launch_commit(const Dev& d, int mode, hipStream_t st);
-void launch_reward(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);
 void launch_advance(const Dev& d, int add_noise, hipStream_t st);
-void launch_addback(const Dev& d, hipStream_t st);
 void launch_gather(const Dev& d, const double* base, const int32_t* rows, const double* scales, double scale_all,
-                   void* out, int dtype, int C, hipStream_t st);
+                   const int32_t* x_ptr, const int32_t* x_row, void* out, int dtype, int C, hipStream_t st);
 void launch_to_envminor(const Dev& d, const double* src, double* dst, int n, hipStream_t st);
 void launch_copy_i32(const int32_t* s, int32_t* dd, int B, hipStream_t st);
 void launch_copy_u8(const uint8_t* s, uint8_t* dd, int B, hipStream_t st);

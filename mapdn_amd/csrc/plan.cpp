@@ -174,7 +174,7 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   P.lines.resize(net.n_line);
   for (int l = 0; l < net.n_line; ++l) {
     LineFlow& L = P.lines[l];
-    if (!net.line_in_service[l]) { L.fpos = L.tpos = -1; continue; }
+    if (!net.line_in_service[l]) { L = LineFlow{}; L.fpos = L.tpos = P.n; continue; }   // zero admittances at the slack: pl == 0
     const PiBranch& b = line_pi[l];
     L.fpos = P.pos_of_bus[b.f]; L.tpos = P.pos_of_bus[b.t];
     L.yff[0] = b.yff.real(); L.yff[1] = b.yff.imag(); L.yft[0] = b.yft.real(); L.yft[1] = b.yft.imag();
@@ -328,18 +328,23 @@ void build_schedule(const Plan& P, int W, Schedule& S) {
     }
     S.n_xslots = std::max(next, 1);
   }
+  // zero + trash slots
+  const uint32_t c_zero = (uint32_t)S.n_cslots, c_trash = c_zero + 1; S.n_cslots += 2;
+  const uint32_t x_zero = (uint32_t)S.n_xslots, x_trash = x_zero + 1; S.n_xslots += 2;
   for (int w = 0; w < W; ++w)
     for (int r = 0; r < R; ++r) {
       StepRec& T = S.steps[(size_t)w * R + r];
       const int k = rows[r][w];
       T = StepRec{};
-      T.k = k;
+      T.k = n + 1; T.p = n;                       // idle: trash node, slack parent
+      T.slots = c_trash | (x_trash << 10) | (x_zero << 20);
+      T.chs = c_zero | (c_zero << 10) | (c_zero << 20);
       if (k < 0) continue;
       const double* c = &P.yc[(size_t)k * 6];
       T.ykk[0] = c[0]; T.ykk[1] = c[1]; T.ykp[0] = c[2]; T.ykp[1] = c[3]; T.ypk[0] = c[4]; T.ypk[1] = c[5];
       const int p = P.par[k];
-      T.p = p;
-      uint32_t f = 0, os = 0, xsl = 0, pxs = 0;
+      T.k = k; T.p = p;
+      uint32_t f = S_LIVE, os = c_trash, xsl = x_trash, pxs = x_zero;
       if (p == n) f |= S_PARENT_ROOT;
       else if (carry_out[k]) f |= S_CARRY_OUT;
       else { f |= S_SCRATCH_OUT; os = (uint32_t)oslot[k]; pxs = (uint32_t)xslot[p]; }
@@ -347,7 +352,9 @@ void build_schedule(const Plan& P, int W, Schedule& S) {
       const int cc = chain_child(k);
       if (cc >= 0) { if (carry_out[cc]) f |= S_CARRY_IN; else kids.push_back(oslot[cc]); }
       for (int ch : children[k]) if (ch != cc) kids.push_back(oslot[ch]);
-      for (size_t j = 0; j < kids.size() && j < 3; ++j) T.ch[j] = kids[j];
+      uint32_t ch3[3] = {c_zero, c_zero, c_zero};
+      for (size_t j = 0; j < kids.size() && j < 3; ++j) ch3[j] = (uint32_t)kids[j];
+      T.chs = ch3[0] | (ch3[1] << 10) | (ch3[2] << 20);
       T.cptr = (int32_t)S.clist.size();
       for (size_t j = 3; j < kids.size(); ++j) S.clist.push_back(kids[j]);
       if (xslot[k] >= 0) { f |= S_X_OUT; xsl = (uint32_t)xslot[k]; }

@@ -32,38 +32,42 @@ enum : int32_t {
   G_P = 7, G_Q = 8, G_VA_DEG = 9, G_NKIND = 10
 };
 
-// One step of one wave of the NR kernel: 80 bytes, wave-uniform.  The kernel copies its wave's
-// records into LDS once and prefetches them a row ahead with ds_read (in-order LGKM returns).
-// flags: S_* in the low 16 bits, number of LDS-slot children to gather in the high 16 bits.
+// One step of one NR worker: 80 bytes, staged in LDS by the kernel and read per lane (5 x
+// ds_read_b128).  Every slot / node index is always valid: the host substitutes a ZERO slot for
+// absent children / parents and a TRASH slot or node for outputs nobody reads, so the kernel's
+// step body is branch-free.  flags: S_* in the low 16 bits, number of children in the high 16.
 struct StepRec {
   double ykk[2], ykp[2], ypk[2];
   uint32_t flags;
-  uint32_t slots;   // oslot | xslot << 10 | pxslot << 20 : LDS slots this node writes (contribution, x) / its parent's x slot
-  int32_t ch[3];    // contribution slots of the first three children to gather (canonical order)
+  uint32_t slots;   // oslot | xslot << 10 | pxslot << 20 : contribution / x slots this node writes, parent's x slot
+  uint32_t chs;     // ch0 | ch1 << 10 | ch2 << 20 : contribution slots of the first three children (canonical order)
   int32_t cptr;     // overflow list (children 3..) in Schedule::clist
-  int32_t k;        // node position, -1 = idle step
-  int32_t p;        // parent position (n == slack)
+  int32_t k, p;     // node / parent position (idle step: trash node n+1 / slack n)
+  int32_t pad[2];
 };
 static_assert(sizeof(StepRec) == 80, "StepRec must be 80 bytes (5 x ds_read_b128)");
 
-// schedule-step flags (wave-uniform control flow in the NR kernel)
+// schedule-step flags
 enum : uint32_t {
   S_PARENT_ROOT = 1u,    // parent is the slack bus: no off-diagonal Jacobian block
-  S_CARRY_OUT = 2u,      // the same wave processes the parent in the next row: contribution stays in registers
+  S_CARRY_OUT = 2u,      // the same worker processes the parent in the next row: contribution stays in registers
   S_CARRY_IN = 4u,       // the chain child's contribution arrives in registers
-  S_SCRATCH_OUT = 8u,    // write own contribution to scratch slot[k] (parent gathers it)
-  S_X_OUT = 16u,         // backward sweep: store x_k to scratch (some child reads it from memory)
+  S_SCRATCH_OUT = 8u,    // own contribution goes to a real LDS slot (parent gathers it)
+  S_X_OUT = 16u,         // backward sweep: x_k goes to a real LDS slot (some child reads it)
+  S_LIVE = 32u,          // not an idle step
 };
 
 struct Schedule {
   int32_t W = 1, R = 0;             // waves per env group, rows
   std::vector<StepRec> steps;       // [W][R]
   std::vector<int32_t> clist;       // LDS slots of the children to gather (canonical order: chain child first, then ascending)
-  int32_t n_cslots = 0, n_xslots = 0;  // LDS slots (reused by interval colouring): 8 resp. 2 doubles per env each
+  // LDS slots (reused by interval colouring): 8 resp. 2 doubles per env each; the last two of each kind
+  // are the ZERO slot (n-2) and the TRASH slot (n-1)
+  int32_t n_cslots = 0, n_xslots = 0;
 };
 
 struct LineFlow {      // pi-model admittances of one net.line row for res_line.pl_mw
-  int32_t fpos, tpos;  // elimination positions (n == root); -1 if out of service
+  int32_t fpos, tpos;  // elimination positions (n == root); out of service: both n with zero admittances
   double yff[2], yft[2], ytf[2], ytt[2];
 };
 

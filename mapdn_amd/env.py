@@ -151,6 +151,13 @@ class VoltageControlBatch:
             _lib.check(self._lib.mapdn_get_start_rows(self._h, out.data_ptr(), self._stream()), self._h)
         return out
 
+    def episode_returns(self):
+        """sum_rewards of the running episode (voltage_control_env.py:203), float64 [B]"""
+        out = torch.empty(self.n_envs, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.mapdn_get_returns(self._h, out.data_ptr(), self._stream()), self._h)
+        return out
+
     def reset(self, start_rows=None, add_noise=True, reset_time=True):
         """reset() (voltage_control_env.py:96-135).  start_rows: optional int64 [B] table rows;
         reset_time=False re-uses the previous episode's start (:110-113)."""
