@@ -35,6 +35,15 @@ def algorithmic_bytes_per_env_step(env):
     return 8 * (2 * nl + 2 * ns) + 8 * 2 * nb + 4 * env.n_agents * env.obs_size + (8 + 1 + 8 * 11)
 
 
+def measured_traffic(case, envs):
+    """HBM bytes per k_nr_wtree launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py;
+    FETCH_SIZE and WRITE_SIZE need separate passes, so bench.py cannot measure them live)."""
+    path = os.path.join(ROOT, "profiles", f"r01_traffic_{case}_b{envs}.json")
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path))["traffic_bytes_per_launch"]
+
+
 def cpu_baseline(case, seconds=12.0):
     """Restated pandapower-equivalent CPU path (oracle/, numpy+scipy, 1 env, 1 core): step()+get_obs().
     pandapower 2.7.0 itself is not installable offline, hence kind='port'."""
@@ -159,7 +168,8 @@ def main():
                        "parallelism": f"env-batch sharded x{n_gpus}, no data-path collective"},
             "nr_iterations": {"mean": stats["mean_nr_iters"], "max": stats["max_nr_iters"]},
             "roofline": {"bound": "hbm", "kernel": "k_nr_wtree", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.case, B),
+                         "algorithmic_bytes_per_launch": bytes_step * B,
                          "algorithmic_bytes_per_env_step": bytes_step, "envs_per_launch": B,
                          "kernel_avg_ms": nr_avg_s * 1e3, "kernel_launches_timed": nr_launches},
         }

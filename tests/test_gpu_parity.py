@@ -321,3 +321,93 @@ def test_golden_episode(case):
         assert np.abs(env.get_obs().cpu().numpy() - g["obs"][t + 1]).max() < 1e-9
         assert np.abs(env.get_state().cpu().numpy() - g["state"][t + 1]).max() < 1e-7
     env.close()
+
+
+# ---- generic network features: shunts, per-unit branches (tap ratio / phase shift), parallel and
+# ---- out-of-service lines, c_nf / g_us line charging, non-unit ext_grid set-point
+def _featured_net():
+    from mapdn_amd.netspec import NetSpec
+    net, prof = make_case("case33")
+    n = net.copy()
+    # the feeder head (bus 0-1) becomes a transformer-like per-unit branch with off-nominal tap + phase shift
+    keep = np.ones(n.n_line, bool); keep[0] = False
+    def cut(a): return a[keep]
+    kw = dict(name="case33x", bus_vn_kv=n.bus_vn_kv, bus_zone=n.bus_zone,
+              line_from_bus=cut(n.line_from_bus), line_to_bus=cut(n.line_to_bus),
+              line_r_ohm_per_km=cut(n.line_r_ohm_per_km), line_x_ohm_per_km=cut(n.line_x_ohm_per_km),
+              line_c_nf_per_km=np.full(31, 120.0), line_g_us_per_km=np.full(31, 2.0),
+              line_length_km=cut(n.line_length_km), line_parallel=cut(n.line_parallel), line_in_service=cut(n.line_in_service),
+              load_bus=n.load_bus, sgen_bus=n.sgen_bus, sgen_zone=n.sgen_zone,
+              ext_grid_bus=0, ext_grid_vm_pu=1.02, sn_mva=5.0, f_hz=50.0,
+              br_from_bus=[0], br_to_bus=[1], br_r_pu=[0.002], br_x_pu=[0.02], br_b_pu=[0.01], br_ratio=[0.98], br_shift_deg=[1.5],
+              shunt_bus=[5, 17], shunt_p_mw=[0.01, 0.0], shunt_q_mvar=[-0.3, 0.15])
+    x = NetSpec(**kw)
+    # a doubled line (parallel = 2), an extra out-of-service tie line, and a line entered twice (two rows, same bus pair)
+    x.line_parallel[3] = 2
+    for k, v in (("line_from_bus", 20), ("line_to_bus", 7)):
+        setattr(x, k, np.append(getattr(x, k), v).astype(np.int32))
+    for k, v in (("line_r_ohm_per_km", 2.0), ("line_x_ohm_per_km", 2.0), ("line_c_nf_per_km", 0.0), ("line_g_us_per_km", 0.0), ("line_length_km", 1.0)):
+        setattr(x, k, np.append(getattr(x, k), v))
+    x.line_parallel = np.append(x.line_parallel, 1).astype(np.int32)
+    x.line_in_service = np.append(x.line_in_service, 0).astype(np.uint8)
+    dup = 10                                           # duplicate row of an in-service line: Ybus sums both
+    for k in ("line_from_bus", "line_to_bus", "line_parallel"):
+        setattr(x, k, np.append(getattr(x, k), getattr(x, k)[dup]).astype(np.int32))
+    for k in ("line_r_ohm_per_km", "line_x_ohm_per_km", "line_c_nf_per_km", "line_g_us_per_km", "line_length_km"):
+        setattr(x, k, np.append(getattr(x, k), getattr(x, k)[dup]))
+    x.line_in_service = np.append(x.line_in_service, 1).astype(np.uint8)
+    return x, prof
+
+
+def test_generic_network_features():
+    net, prof = _featured_net()
+    B = 21                                             # odd batch size: padded lanes must stay inert
+    a = args_for("case33")
+    env = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0", obs_dtype=torch.float64)
+    from oracle.pp_restated import make_ybus
+    y = env.ybus_dense(); yo = make_ybus(net)[0].toarray()
+    assert np.abs(y - yo).max() < 1e-12 * np.abs(yo).max()
+    rng = np.random.default_rng(9)
+    rows = rng.integers(0, prof.n_rows, B)
+    pl, ql, pv = prof.load_p[rows], prof.load_q[rows], prof.pv[rows]
+    qs = rng.uniform(-0.8, 0.8, (B, net.n_sgen)) * np.sqrt(prof.s_max() ** 2 - pv ** 2)
+    vm, va, it, cv = env.solve(pl, ql, pv, qs)
+    vm, va, it = vm.cpu().numpy(), va.cpu().numpy(), it.cpu().numpy()
+    assert cv.all()
+    for e in range(B):
+        r = runpp_restated(net, pl[e], ql[e], pv[e], qs[e])
+        assert r.converged and r.iterations == it[e]
+        assert np.abs(vm[e] - r.vm_pu).max() < V_TOL and np.abs(va[e] - r.va_degree).max() < 1e-7
+    assert (vm[:, 0] == 1.02).all()
+    # env level: res_bus incl. shunt terms, slack injection through the tapped branch, res_line incl. the
+    # out-of-service (0) and duplicated rows, rewards
+    oracles = [VoltageControlOracle(net, prof, a, env_id=e, do_reset=False) for e in range(3)]
+    env.reset()
+    for o in oracles:
+        o.reset()
+    for t in range(3):
+        act = rng.uniform(-0.8, 0.8, (B, net.n_sgen))
+        r, term, info = env.step(torch.as_tensor(act, device="cuda:0"))
+        res = env.results()
+        for e, o in enumerate(oracles):
+            ro, to, io = o.step(act[e])
+            assert abs(ro - r[e].item()) < 1e-9
+            assert np.abs(res["p_mw"][e].cpu().numpy() - o.res.p_mw).max() < 1e-9
+            assert np.abs(res["q_mvar"][e].cpu().numpy() - o.res.q_mvar).max() < 1e-9
+            assert np.abs(res["pl_mw"][e].cpu().numpy() - o.res.pl_mw).max() < 1e-9
+            assert res["pl_mw"][e, 31].item() == 0.0                       # out-of-service row
+            assert abs(io["total_line_loss"] - info[e, 8].item()) < 1e-9
+    env.close()
+
+
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 100])
+def test_batch_sizes(B):
+    """batches that are not multiples of the workgroup size: padded envs are inert, results unchanged"""
+    net, prof, env = make("case33", B)
+    ref_net, ref_prof, ref = make("case33", 128)
+    env.reset(); ref.reset()
+    assert torch.equal(env.get_obs(), ref.get_obs()[:B])
+    a = torch.linspace(-0.7, 0.7, 128 * net.n_sgen, dtype=torch.float64, device="cuda:0").reshape(128, net.n_sgen)
+    r1, t1, i1 = env.step(a[:B]); r2, t2, i2 = ref.step(a)
+    assert torch.equal(r1, r2[:B]) and torch.equal(i1, i2[:B]) and torch.equal(env.get_obs(), ref.get_obs()[:B])
+    env.close(); ref.close()

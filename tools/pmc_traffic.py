@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — separate runs, as the MI355X guide
+prescribes: they do not fit one pass) of `bench.py` into profiles/<tag>_traffic.json.
+
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [kernel-substring]
+FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  Calibration note (MI355X_MICROARCH.md, HBM):
+FETCH_SIZE under-reports wide (16 B/lane) streaming reads by 2x on gfx950; this kernel's global
+accesses are 8 B/lane buffer ops and its traffic is write-dominated, so the raw value is reported
+together with the 2x-corrected upper bound.
+"""
+import collections, csv, glob, json, sys
+
+
+def mean_counter(d, name, sub):
+    vals = []
+    for f in glob.glob(d + "/*counter_collection.csv"):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == name and sub in row["Kernel_Name"]:
+                vals.append(float(row["Counter_Value"]))
+    vals = [v for v in vals if v > 0.25 * max(vals)] if vals else vals      # drop the early-exit reset retries
+    return sum(vals) / len(vals), len(vals)
+
+
+if __name__ == "__main__":
+    fdir, wdir, out = sys.argv[1:4]
+    sub = sys.argv[4] if len(sys.argv) > 4 else "k_nr_wtree"
+    f, nf = mean_counter(fdir, "FETCH_SIZE", sub)
+    w, nw = mean_counter(wdir, "WRITE_SIZE", sub)
+    res = {"kernel": sub, "fetch_bytes_per_launch": f * 1024, "write_bytes_per_launch": w * 1024,
+           "traffic_bytes_per_launch": (f + w) * 1024, "traffic_bytes_per_launch_fetch_x2": (2 * f + w) * 1024,
+           "launches": [nf, nw], "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py"}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
