@@ -241,7 +241,7 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   {  // stage the step records (and the overflow child list) in LDS
     const uint4* src = (const uint4*)d.sched;
     uint4* dst = (uint4*)s_sched;
-    for (unsigned i = threadIdx.x; i < 5u * Wt * (unsigned)R; i += 64u * W) dst[i] = src[i];
+    for (unsigned i = threadIdx.x; i < 6u * Wt * (unsigned)R; i += 64u * W) dst[i] = src[i];
     for (unsigned i = threadIdx.x; i < (unsigned)d.nr_nclist; i += 64u * W) s_clist[i] = d.clist[i];
     // Sbus of this workgroup's envs -> LDS; flat start (runpp init="auto": every bus at the slack set-point)
     const double* gS = d.nrbuf + (size_t)d.r_sbus * d.Bp + e;
@@ -297,6 +297,8 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     const double apk_r = ep * ur + fp * ui, apk_i = fp * ur - ep * ui;
     const double v2 = ek * ek + fk * fk;
     const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
+    // slack link: A_ks = V_k conj(Y_k,slack V_slack) — a constant-voltage neighbour only feeds S_k
+    const double aks_r = ek * T.cks[0] + fk * T.cks[1], aks_i = fk * T.cks[0] - ek * T.cks[1];
     // (3) children: register carry (same worker, previous row) + LDS slots, canonical order
     const bool cin = (fl & S_CARRY_IN) != 0;
     double aS0 = (cin ? cS0 : 0.0) + g0[0], aS1 = (cin ? cS1 : 0.0) + g0[1], aD0 = (cin ? cD0 : 0.0) + g0[2],
@@ -314,7 +316,7 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
       for (int j = 3; j < nch; ++j) gather((unsigned)s_clist[T.cptr + j - 3]);
     }
     // S_k = V_k conj(sum_j Y_kj V_j), mismatch F_k = S_k - Sbus_k
-    const double sr = akk_r + akp_r + aS0, si = akk_i + akp_i + aS1;
+    const double sr = (akk_r + aks_r) + akp_r + aS0, si = (akk_i + aks_i) + akp_i + aS1;
     const double Fp = sr - o.sr, Fq = si - o.si;
     allok = allok && (!(fl & S_LIVE) || ((fabs(Fp) < tol) && (fabs(Fq) < tol)));
     const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) - aD1;

@@ -116,59 +116,77 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   P.radial = (n_edges == (size_t)nb - 1);
   if (!P.radial) { err = "topology: meshed network (" + std::to_string(n_edges) + " bus pairs for " + std::to_string(nb) + " buses); this build solves radial feeders only"; return MAPDN_E_TOPOLOGY; }
 
-  // NOTE on the stack-DFS above: a node is "seen" when pushed, so preorder is a valid
-  // parent-before-child order, but a child is not necessarily visited right after its parent.
-  // Re-derive a true DFS preorder (child chains contiguous) recursively over the parent map.
+  // ---- elimination forest.  The slack has a known voltage: it is not eliminated, it only adds the
+  // constant term V_k conj(Y_k,slack V_slack) to the S of its neighbours.  Removing it leaves one tree
+  // per slack neighbour; each is rooted at its CENTER (minimum eccentricity), so the critical path of
+  // a sweep is the tree radius instead of the feeder depth.  Positions = reverse DFS pre-order
+  // (children before parents, the largest subtree adjacent to its parent).
+  const int slack = P.root_bus;
+  std::vector<int> el_parent(nb, -1);            // elimination parent (bus id), -1 for elimination roots / slack
+  std::vector<int> el_order; el_order.reserve(nb);
   {
-    std::vector<std::vector<int>> children(nb);
-    for (int v : preorder) if (parent_bus[v] >= 0) children[parent_bus[v]].push_back(v);
-    // visit the child with the largest subtree LAST-in-preorder => it ends up adjacent (k, k+1)... any
-    // child can take the register-carried slot; pick the deepest subtree to keep long chains in registers.
-    std::vector<int> sub(nb, 1);
-    for (auto it = preorder.rbegin(); it != preorder.rend(); ++it) if (parent_bus[*it] >= 0) sub[parent_bus[*it]] += sub[*it];
-    for (int u = 0; u < nb; ++u)
-      std::stable_sort(children[u].begin(), children[u].end(), [&](int a, int b) { return sub[a] > sub[b]; });
-    std::vector<int> order; order.reserve(nb);
-    std::vector<int> stack{P.root_bus};
-    while (!stack.empty()) {
-      int u = stack.back(); stack.pop_back();
-      order.push_back(u);
-      for (auto it = children[u].rbegin(); it != children[u].rend(); ++it) stack.push_back(*it);
+    std::vector<int> dist(nb), from(nb);
+    auto bfs = [&](int src, std::vector<int>& comp) {      // BFS inside (tree - slack); returns farthest node
+      comp.clear();
+      std::fill(dist.begin(), dist.end(), -1);
+      std::vector<int> q{src}; dist[src] = 0; from[src] = -1;
+      for (size_t i = 0; i < q.size(); ++i) {
+        int u = q[i]; comp.push_back(u);
+        for (int w : adj[u]) if (w != slack && dist[w] < 0) { dist[w] = dist[u] + 1; from[w] = u; q.push_back(w); }
+      }
+      int far = src;
+      for (int u : comp) if (dist[u] > dist[far] || (dist[u] == dist[far] && u < far)) far = u;
+      return far;
+    };
+    std::vector<int> comp, comp2;
+    for (int s0 : adj[slack]) {                  // one component per slack neighbour
+      const int a = bfs(s0, comp);
+      const int b = bfs(a, comp2);               // a..b is a diameter path
+      int c = b;
+      for (int i = 0; i < dist[b] / 2; ++i) c = from[c];     // its middle node = the tree center
+      // root the component at c
+      std::vector<std::vector<int>> children(nb);
+      std::vector<int> pre, stack{c};
+      std::vector<char> seen(nb, 0);
+      seen[c] = 1; el_parent[c] = -1;
+      while (!stack.empty()) {
+        int u = stack.back(); stack.pop_back(); pre.push_back(u);
+        for (int w : adj[u]) if (w != slack && !seen[w]) { seen[w] = 1; el_parent[w] = u; children[u].push_back(w); stack.push_back(w); }
+      }
+      std::vector<int> sub(nb, 1);
+      for (auto it = pre.rbegin(); it != pre.rend(); ++it) if (el_parent[*it] >= 0) sub[el_parent[*it]] += sub[*it];
+      for (int u : pre) std::stable_sort(children[u].begin(), children[u].end(), [&](int x, int y) { return sub[x] > sub[y]; });
+      stack.assign(1, c);
+      while (!stack.empty()) {                   // true pre-order: parent, then the largest child's whole subtree, ...
+        int u = stack.back(); stack.pop_back(); el_order.push_back(u);
+        for (auto it = children[u].rbegin(); it != children[u].rend(); ++it) stack.push_back(*it);
+      }
     }
-    preorder.swap(order);   // true preorder: parent, then first child's whole subtree, ...
   }
+  if ((int)el_order.size() != nb - 1) { err = "internal: elimination forest does not cover the network"; return MAPDN_E_INVALID; }
   P.bus_of_pos.assign(nb, -1); P.pos_of_bus.assign(nb, -1);
-  for (int i = 1; i < nb; ++i) {           // reverse preorder, root excluded -> positions 0..n-1
-    int bus = preorder[nb - i];
-    P.bus_of_pos[i - 1] = bus; P.pos_of_bus[bus] = i - 1;
+  for (int i = 0; i < nb - 1; ++i) {             // reverse pre-order -> positions 0..n-1 (children first)
+    const int bus = el_order[nb - 2 - i];
+    P.bus_of_pos[i] = bus; P.pos_of_bus[bus] = i;
   }
-  P.bus_of_pos[P.n] = P.root_bus; P.pos_of_bus[P.root_bus] = P.n;
-  P.par.assign(P.n, 0); P.flags.assign(P.n, 0u); P.yc.assign((size_t)P.n * 6, 0.0);
+  P.bus_of_pos[P.n] = slack; P.pos_of_bus[slack] = P.n;
+  P.par.assign(P.n, 0); P.flags.assign(P.n, 0u); P.yc.assign((size_t)P.n * 8, 0.0);
   for (int k = 0; k < P.n; ++k) {
-    int bus = P.bus_of_pos[k], pb = parent_bus[bus], p = P.pos_of_bus[pb];
+    const int bus = P.bus_of_pos[k], pb = el_parent[bus];
+    const int p = pb >= 0 ? P.pos_of_bus[pb] : P.n;          // elimination roots point at the slack position (Y = 0)
     if (p <= k) { err = "internal: elimination order violated"; return MAPDN_E_INVALID; }
     P.par[k] = p;
-    cplx ykk = Y(bus, bus), ykp = Y(bus, pb), ypk = Y(pb, bus);
-    double* c = &P.yc[(size_t)k * 6];
+    const cplx ykk = Y(bus, bus), ykp = pb >= 0 ? Y(bus, pb) : cplx(0, 0), ypk = pb >= 0 ? Y(pb, bus) : cplx(0, 0);
+    const cplx cks = Y(bus, slack) * P.vroot;                // Y_k,slack V_slack (0 unless k neighbours the slack)
+    double* c = &P.yc[(size_t)k * 8];
     c[0] = ykk.real(); c[1] = ykk.imag(); c[2] = ykp.real(); c[3] = ykp.imag(); c[4] = ypk.real(); c[5] = ypk.imag();
+    c[6] = cks.real(); c[7] = cks.imag();
     if (p == P.n) P.flags[k] |= F_PARENT_ROOT;
     else if (p == k + 1) P.flags[k] |= F_PARENT_NEXT;
   }
-  {
-    std::vector<char> has_scratch_child(P.n + 1, 0);
-    for (int k = 0; k < P.n; ++k) {
-      uint32_t f = P.flags[k];
-      if (f & F_PARENT_ROOT) continue;
-      if (f & F_PARENT_NEXT) { P.flags[k + 1] |= F_CARRY_IN; continue; }
-      int p = P.par[k];
-      if (!has_scratch_child[p]) { has_scratch_child[p] = 1; P.flags[k] |= F_SCRATCH_FIRST; }
-      P.flags[p] |= F_SCRATCH_IN;
-    }
-  }
-  P.yrr[0] = Y(P.root_bus, P.root_bus).real(); P.yrr[1] = Y(P.root_bus, P.root_bus).imag();
-  P.root_children.clear(); P.root_y.clear();
-  for (int k = 0; k < P.n; ++k)
-    if (P.par[k] == P.n) { P.root_children.push_back(k); P.root_y.push_back(P.yc[(size_t)k * 6 + 4]); P.root_y.push_back(P.yc[(size_t)k * 6 + 5]); }
+  P.yrr[0] = Y(slack, slack).real(); P.yrr[1] = Y(slack, slack).imag();
+  P.root_children.clear(); P.root_y.clear();     // the slack's neighbours and Y[slack, k] (slack injection in res_bus)
+  for (int w : adj[slack]) { P.root_children.push_back(P.pos_of_bus[w]); P.root_y.push_back(Y(slack, w).real()); P.root_y.push_back(Y(slack, w).imag()); }
 
   // ---- res_line flows ---------------------------------------------------------------------------
   P.lines.resize(net.n_line);
@@ -340,8 +358,9 @@ void build_schedule(const Plan& P, int W, Schedule& S) {
       T.slots = c_trash | (x_trash << 10) | (x_zero << 20);
       T.chs = c_zero | (c_zero << 10) | (c_zero << 20);
       if (k < 0) continue;
-      const double* c = &P.yc[(size_t)k * 6];
+      const double* c = &P.yc[(size_t)k * 8];
       T.ykk[0] = c[0]; T.ykk[1] = c[1]; T.ykp[0] = c[2]; T.ykp[1] = c[3]; T.ypk[0] = c[4]; T.ypk[1] = c[5];
+      T.cks[0] = c[6]; T.cks[1] = c[7];
       const int p = P.par[k];
       T.k = k; T.p = p;
       uint32_t f = S_LIVE, os = c_trash, xsl = x_trash, pxs = x_zero;

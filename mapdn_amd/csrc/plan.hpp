@@ -19,7 +19,7 @@ using cplx = std::complex<double>;
 
 // node flags of the elimination schedule (wave-uniform control flow in the NR kernel)
 enum : uint32_t {
-  F_PARENT_ROOT = 1u,    // parent is the slack bus: no off-diagonal Jacobian block
+  F_PARENT_ROOT = 1u,    // elimination root (no parent): no off-diagonal Jacobian block
   F_PARENT_NEXT = 2u,    // parent is node k+1: Schur update / S contribution carried in registers
   F_CARRY_IN = 4u,       // node k-1 is a child of k (its contribution arrives in registers)
   F_SCRATCH_IN = 8u,     // k has children other than k-1: their contributions sit in scratch
@@ -32,24 +32,25 @@ enum : int32_t {
   G_P = 7, G_Q = 8, G_VA_DEG = 9, G_NKIND = 10
 };
 
-// One step of one NR worker: 80 bytes, staged in LDS by the kernel and read per lane (5 x
+// One step of one NR worker: 96 bytes, staged in LDS by the kernel and read per lane (6 x
 // ds_read_b128).  Every slot / node index is always valid: the host substitutes a ZERO slot for
 // absent children / parents and a TRASH slot or node for outputs nobody reads, so the kernel's
 // step body is branch-free.  flags: S_* in the low 16 bits, number of children in the high 16.
 struct StepRec {
-  double ykk[2], ykp[2], ypk[2];
+  double ykk[2], ykp[2], ypk[2];   // Y_kk, Y_k,parent, Y_parent,k (elimination parent; 0 for elimination roots)
+  double cks[2];                   // Y_k,slack * V_slack (0 unless k neighbours the slack)
   uint32_t flags;
   uint32_t slots;   // oslot | xslot << 10 | pxslot << 20 : contribution / x slots this node writes, parent's x slot
   uint32_t chs;     // ch0 | ch1 << 10 | ch2 << 20 : contribution slots of the first three children (canonical order)
   int32_t cptr;     // overflow list (children 3..) in Schedule::clist
-  int32_t k, p;     // node / parent position (idle step: trash node n+1 / slack n)
+  int32_t k, p;     // node / parent position (idle step: trash node n+1; no parent: slack position n with Y = 0)
   int32_t pad[2];
 };
-static_assert(sizeof(StepRec) == 80, "StepRec must be 80 bytes (5 x ds_read_b128)");
+static_assert(sizeof(StepRec) == 96, "StepRec must be 96 bytes (6 x ds_read_b128)");
 
 // schedule-step flags
 enum : uint32_t {
-  S_PARENT_ROOT = 1u,    // parent is the slack bus: no off-diagonal Jacobian block
+  S_PARENT_ROOT = 1u,    // elimination root (no parent): no off-diagonal Jacobian block
   S_CARRY_OUT = 2u,      // the same worker processes the parent in the next row: contribution stays in registers
   S_CARRY_IN = 4u,       // the chain child's contribution arrives in registers
   S_SCRATCH_OUT = 8u,    // own contribution goes to a real LDS slot (parent gathers it)
@@ -81,10 +82,10 @@ struct Plan {
   std::vector<int32_t> bus_of_pos, pos_of_bus;  // [nb]; pos n == root
   std::vector<int32_t> par;                     // [n] parent position
   std::vector<uint32_t> flags;                  // [n]
-  std::vector<double> yc;                       // [n*6] ykk, ykp, ypk (re, im)
+  std::vector<double> yc;                       // [n*8] ykk, ykp, ypk, Y_k,slack*V_slack (re, im)
   double yrr[2] = {0, 0};
-  std::vector<int32_t> root_children;           // positions whose parent is the slack
-  std::vector<double> root_y;                   // [2*len] Y[slack, child] (re, im)
+  std::vector<int32_t> root_children;           // positions of the slack's neighbours
+  std::vector<double> root_y;                   // [2*len] Y[slack, neighbour] (re, im)
   std::vector<cplx> ybus;                       // dense [nb*nb], debug export only
 
   std::vector<LineFlow> lines;                  // [n_line]
