@@ -411,3 +411,35 @@ def test_batch_sizes(B):
     r1, t1, i1 = env.step(a[:B]); r2, t2, i2 = ref.step(a)
     assert torch.equal(r1, r2[:B]) and torch.equal(i1, i2[:B]) and torch.equal(env.get_obs(), ref.get_obs()[:B])
     env.close(); ref.close()
+
+
+def test_full_episode_with_reset_boundary():
+    """one complete 240-step episode + the reset into the next one, large batch, two envs checked
+    against the oracle at every step (catches drift, termination and reset bookkeeping errors)"""
+    case, B = "case141", 1024
+    net, prof, env = make(case, B, voltage_barrier_type="bowl")
+    a = args_for(case)
+    watch = [0, 777]
+    oracles = {e: VoltageControlOracle(net, prof, a, env_id=e, do_reset=False) for e in watch}
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(3)
+    for episode in range(2):
+        obs, _ = env.reset()
+        for e, o in oracles.items():
+            oo, _ = o.reset()
+            assert np.abs(np.array(oo) - obs[e].cpu().numpy()).max() < 1e-9
+        for t in range(239):
+            act = (torch.rand(B, net.n_sgen, device="cuda:0", generator=gen, dtype=torch.float64) * 2 - 1) * 0.6
+            r, term, info = env.step(act)
+            if t % 17 == 0 or t >= 236:
+                obs = env.get_obs()
+            for e, o in oracles.items():
+                ro, to, io = o.step(act[e].cpu().numpy())
+                assert abs(ro - r[e].item()) < 1e-9 and to == bool(term[e].item()), (episode, t, e)
+                if t % 17 == 0 or t >= 236:
+                    assert np.abs(np.array(o.get_obs()) - obs[e].cpu().numpy()).max() < 1e-9
+            assert bool(term.all().item()) == (t == 238)
+        ret = env.episode_returns()
+        for e, o in oracles.items():
+            assert abs(ret[e].item() - o.sum_rewards) < 1e-7
+    assert env.stats()["reset_failures"] == 0
+    env.close()
