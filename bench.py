@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--case", default="case141")
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm); 'gloo' only to "
+                                                        "exercise the N>1 path on a box with fewer GPUs than ranks")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
 
@@ -86,11 +88,16 @@ def main():
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
     dist = None
+    if a.backend != "nccl":                       # test mode: ranks may share a GPU
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     from mapdn_amd.env import VoltageControlBatch
     from mapdn_amd.netspec import make_case
@@ -133,12 +140,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_step()
-    if dist is not None:
-        gather_rollout(env.episode_returns())                 # end-of-rollout RCCL gather
+    if dist is not None:                                      # end-of-rollout RCCL gather
+        ret = env.episode_returns()
+        allret = gather_rollout(ret if a.backend == "nccl" else ret.cpu())
+        assert allret.shape[0] == world * B
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stats = env.stats()

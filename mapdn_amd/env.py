@@ -317,14 +317,16 @@ def _resolve_data(args):
     """
     if args.get("net") is not None and args.get("profiles") is not None:
         return args["net"], args["profiles"]
-    name = os.path.basename(os.path.normpath(str(args.get("data_path", ""))))
-    if name not in _SCENARIOS:
-        raise FileNotFoundError(f"unknown scenario {name!r}: pass net=/profiles= or a data_path ending in one of {sorted(_SCENARIOS)}")
-    if os.path.exists(os.path.join(str(args.get("data_path")), "model.p")):
-        raise NotImplementedError("loading a pandapower model.p needs pandapower (not installable offline); "
-                                  "convert it to a NetSpec and pass net=/profiles=")
-    net, prof = make_case(_SCENARIOS[name], seed=0)
+    dp = str(args.get("data_path", ""))
     ps, ds = float(args.get("pv_scale", 1.0)), float(args.get("demand_scale", 1.0))       # :415,426,437
+    if os.path.isdir(dp) and (os.path.exists(os.path.join(dp, "netspec.npz")) or os.path.exists(os.path.join(dp, "model.p"))):
+        from .data import load_scenario
+        return load_scenario(dp, ps, ds)                                                  # real scenario directory
+    name = os.path.basename(os.path.normpath(dp))
+    if name not in _SCENARIOS:
+        raise FileNotFoundError(f"unknown scenario {name!r}: pass net=/profiles=, a directory with netspec.npz + the three "
+                                f"CSV tables, or a data_path ending in one of {sorted(_SCENARIOS)}")
+    net, prof = make_case(_SCENARIOS[name], seed=0)
     if ps != 1.0 or ds != 1.0:
         prof = Profiles(pv=prof.pv * ps, load_p=prof.load_p * ds, load_q=prof.load_q * ds,
                         time_delta_min=prof.time_delta_min, days=prof.days)
