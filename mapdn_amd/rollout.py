@@ -1,0 +1,85 @@
+"""Batched, GPU-resident rollout driver — the direct caller of the hot path.
+
+Mirrors `Model.train_process` / `Model.evaluation` of the reference (models/model.py:197-302) for B
+envs at once: policy forward, `translate_action` (utilities/util.py:123-132), env step, next obs and
+statistics all stay on the device — the reference crosses host<->GPU twice per env step
+(models/model.py:211,214).  The transition window is the GPU-resident counterpart of the fields of
+`Transition` (models/model.py:18) the DDPG-style learners consume.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from ._lib import INFO_KEYS
+
+
+def translate_action(action: torch.Tensor, action_scale: float, action_bias: float) -> torch.Tensor:
+    """utilities/util.py:123-132 (continuous branch), batched and on device:
+    clamp to [-1, 1], then map linearly onto [bias - scale, bias + scale]."""
+    cp = torch.clamp(action, min=-1.0, max=1.0)
+    low = action_bias - action_scale
+    high = action_bias + action_scale
+    return 0.5 * (cp + 1.0) * (high - low) + low
+
+
+@dataclass
+class TransitionWindow:
+    """[T, B, ...] tensors on the env's device (models/model.py:18 fields: state, action, reward,
+    next_state, done, last_step); `reward` is repeated per agent as at models/model.py:217."""
+    state: torch.Tensor        # [T, B, n_agents, obs]   f32
+    action: torch.Tensor       # [T, B, n_agents, 1]     f32 (policy space, before translate_action)
+    reward: torch.Tensor       # [T, B, n_agents]        f32
+    next_state: torch.Tensor   # [T, B, n_agents, obs]   f32
+    done: torch.Tensor         # [T, B]                  bool
+    last_step: torch.Tensor    # [T, B]                  bool  (done or t == max_steps-1, model.py:225)
+    steps: int = 0
+
+
+class BatchedRollout:
+    """policy: callable (obs [B, n, obs_size] f32, hidden) -> (action [B, n] or [B, n, 1] in [-1, 1] space, hidden)."""
+
+    def __init__(self, env, policy, max_steps: int = 240):
+        self.env, self.policy, self.max_steps = env, policy, int(max_steps)
+        a = env.args
+        self.action_scale, self.action_bias = float(a["action_scale"]), float(a["action_bias"])
+        B, n, o, dv, T = env.n_envs, env.n_agents, env.obs_size, env.device, self.max_steps
+        self.win = TransitionWindow(
+            state=torch.empty(T, B, n, o, device=dv), action=torch.empty(T, B, n, 1, device=dv),
+            reward=torch.empty(T, B, n, device=dv), next_state=torch.empty(T, B, n, o, device=dv),
+            done=torch.empty(T, B, dtype=torch.bool, device=dv), last_step=torch.empty(T, B, dtype=torch.bool, device=dv))
+
+    @torch.no_grad()
+    def run(self, prefix: str = "mean_train_", hidden=None, add_noise: bool = True):
+        """One episode for every env.  Returns (window, stat): stat[prefix + key] = mean over steps and
+        envs of every info key and of the reward (models/model.py:243-248,257-261), computed on device."""
+        env, win, T = self.env, self.win, self.max_steps
+        obs, _ = env.reset()
+        obs = obs.float().clone()
+        info_sum = torch.zeros(len(INFO_KEYS), dtype=torch.float64, device=env.device)
+        rew_sum = torch.zeros((), dtype=torch.float64, device=env.device)
+        alive_steps = torch.zeros((), dtype=torch.float64, device=env.device)
+        alive = torch.ones(env.n_envs, dtype=torch.bool, device=env.device)
+        t = 0
+        for t in range(T):
+            action, hidden = self.policy(obs, hidden)
+            action = action.reshape(env.n_envs, env.n_agents, 1).float()
+            actual = translate_action(action.squeeze(-1), self.action_scale, self.action_bias)
+            reward, done, info = env.step(actual, add_noise=add_noise)
+            nxt = env.get_obs().float()
+            win.state[t].copy_(obs); win.action[t].copy_(action)
+            win.reward[t].copy_(reward.float().unsqueeze(-1).expand(-1, env.n_agents))
+            win.next_state[t].copy_(nxt); win.done[t].copy_(done)
+            win.last_step[t].copy_(done | (t == T - 1))
+            w = alive.double()                                  # frozen (already terminated) envs do not count
+            info_sum += (info * w.unsqueeze(-1)).sum(0); rew_sum += (reward * w).sum(); alive_steps += w.sum()
+            alive &= ~done
+            obs = nxt.clone()
+            if t % 16 == 15 and not bool(alive.any()):          # the only host sync, once per 16 steps
+                break
+        win.steps = t + 1
+        denom = torch.clamp(alive_steps, min=1.0)
+        stat = {prefix + k: float(v) for k, v in zip(INFO_KEYS, (info_sum / denom).tolist())}
+        stat[prefix + "reward"] = float(rew_sum / denom)
+        return win, stat
