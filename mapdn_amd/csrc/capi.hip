@@ -129,7 +129,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   d.cur_q = d.gbuf + (size_t)r_q * Bp; d.vm = d.gbuf + (size_t)r_vm * Bp; d.va = d.gbuf + (size_t)r_va * Bp;
   d.res_p = d.gbuf + (size_t)r_rp * Bp; d.res_q = d.gbuf + (size_t)r_rq * Bp;
   AL(sum_rewards, 1); AL(steps, 1); AL(start_row, 1); AL(draw, 1); AL(done, 1); AL(pending, 1);
-  AL(active, 1); AL(adv_row, 1); AL(adv_draw, 1); AL(iters, 1); AL(conv, 1);
+  AL(active, 1); AL(commit, 1); AL(adv_row, 1); AL(adv_draw, 1); AL(iters, 1); AL(conv, 1);
   {
     std::vector<uint8_t> ones(Bp, 1);
     HIPCHK(h, hipMemcpy(d.done, ones.data(), Bp, hipMemcpyHostToDevice));   // nothing is steppable before reset
@@ -198,6 +198,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   const size_t lds_need = nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, h->sched.R, ncl);
   if (lds_need > 160 * 1024) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
   d.nr_waves = W; d.nr_lanes = L;
+
   d.nr_rows = h->sched.R; d.nr_cslots = h->sched.n_cslots; d.nr_xslots = h->sched.n_xslots; d.nr_nclist = ncl;
   {
     const int lr = nr_set_lds_limit(W, L, lds_need);
@@ -330,9 +331,10 @@ int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, i
   const Dev& d = h->d;
   for (int t = 0; t < max_tries; ++t) {
     launch_reset_begin(d, start_rows, t == 0, st);
-    launch_advance(d, add_noise, st);
+    launch_advance(d, add_noise, 1, 0, st);
     launch_inject(d, MODE_RESET, nullptr, MAPDN_F64, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, st);
     nr_launch(h, MODE_RESET, nullptr, nullptr, nullptr, st);
+    launch_advance(d, 0, 0, 1, st);              // res_bus commit of the envs that found a solvable start
   }
   HIPCHK(h, hipGetLastError());
   h->was_reset = true;
@@ -351,7 +353,7 @@ int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int3
   const Dev& d = h->d;
   launch_inject(d, MODE_STEP, actions, actions_dtype, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, st);
   nr_launch(h, MODE_STEP, reward, terminated, info, st);
-  launch_advance(d, add_noise, st);
+  launch_advance(d, add_noise, 1, 1, st);        // next profile row + res_bus commit in one wide launch
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
 }

@@ -474,47 +474,31 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   typedef const __attribute__((address_space(4))) int32_t* c_i32;
   typedef const __attribute__((address_space(4))) double* c_f64;
   const c_i32 bus_of_pos = (c_i32)(unsigned long long)d.bus_of_pos;
-  const c_f64 shunt_p = (c_f64)(unsigned long long)d.shunt_p, shunt_q = (c_f64)(unsigned long long)d.shunt_q;
   const c_f64 linec = (c_f64)(unsigned long long)d.lines;          // LineFlow = {int32 fpos, tpos; double y[8]} = 9 x 8 bytes
-  // ---- buses (elimination positions 0..n-1; the slack follows)
+  // ---- buses: voltage statistics for the reward; the solution (e, f) goes to Vout, from where the
+  // wide k_post kernel (thread per bus x env) commits res_bus — |V|, angle(V), p_mw, q_mvar — for the
+  // envs flagged in d.commit: throughput work does not belong in this 512-wave kernel
+  double* gV = d.nrbuf + (size_t)d.r_vout * SB + e;
 #pragma unroll 4
   for (unsigned k = t; k < n; k += Wt) {
-    const size_t o = (size_t)bus_of_pos[k] * SB + e;
     const double ek = sV[(size_t)(2 * k) * L], fk = sV[(size_t)(2 * k + 1) * L];
     const double v = sqrt(ek * ek + fk * fk);                        // res_bus.vm_pu = |V|
-    if (commitf) {
-      d.vm[o] = v;
-      d.va[o] = atan2(fk, ek);                                       // res_bus.va (rad here) = angle(V)
-      d.res_p[o] = -sS[(size_t)(2 * k) * L] * d.sn + shunt_p[k] * v * v;      // bus demand = -Sbus * sn_mva (+ shunt)
-      d.res_q[o] = -sS[(size_t)(2 * k + 1) * L] * d.sn + shunt_q[k] * v * v;
-    }
+    if (commitf) { gV[((size_t)VOF * k + VO_E) * SB] = ek; gV[((size_t)VOF * k + VO_F) * SB] = fk; }
     n_lo += (v < vlo) ? 1.0 : 0.0; n_hi += (v > vhi) ? 1.0 : 0.0;
     dev += fabs(v - vref); vsum += v;
     mdrop = fmax(mdrop, (v < vlo) ? (vlo - v) : 0.0);
     mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
     bar += barrier(d.barrier_type, v);
   }
-  if (t == n % Wt) {                              // the slack bus (position n)
-    const size_t o = (size_t)bus_of_pos[n] * SB + e;
-    const double v = vroot;                       // committed slack voltage never changes
-    if (commitf) {
-      // res_bus = -(V conj(I)) * sn, I = Y_rr V_r + sum_children Y_rk V_k   (consumer sign)
-      double ir = d.yrr0 * vroot, ii = d.yrr1 * vroot;
-      for (int j = 0; j < d.n_root_children; ++j) {
-        const unsigned c = (unsigned)d.root_children[j];
-        const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ec = sV[(size_t)(2 * c) * L], fc = sV[(size_t)(2 * c + 1) * L];
-        ir += g * ec - b * fc; ii += g * fc + b * ec;
-      }
-      d.vm[o] = vroot; d.va[o] = 0.0;
-      d.res_p[o] = -(vroot * ir) * d.sn + shunt_p[n] * vroot * vroot;
-      d.res_q[o] = (vroot * ii) * d.sn + shunt_q[n] * vroot * vroot;
-    }
+  if (t == n % Wt) {                              // the slack bus: committed voltage never changes
+    const double v = vroot;
     n_lo += (v < vlo) ? 1.0 : 0.0; n_hi += (v > vhi) ? 1.0 : 0.0;
     dev += fabs(v - vref); vsum += v;
     mdrop = fmax(mdrop, (v < vlo) ? (vlo - v) : 0.0);
     mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
     bar += barrier(d.barrier_type, v);
   }
+  if (t == 0 && valid) d.commit[e] = commitf ? 1 : 0;
   // ---- res_line.pl_mw = Re(Sf + St) * sn   (out-of-service rows: fpos = tpos = slack, all-zero admittances)
 #pragma unroll 4
   for (unsigned l = t; l < (unsigned)d.n_line; l += Wt) {
@@ -642,13 +626,43 @@ __global__ void __launch_bounds__(256) k_reset_begin(Dev d, const int64_t* __res
 }
 
 // =================================================================================================
-// K9b  advance — _set_demand_and_pv (voltage_control_env.py:491-513): next row of the three
+// K9b  advance (+ K6 bus commit) — _set_demand_and_pv (voltage_control_env.py:491-513): next row of the three
 //      profile tables + std/100 * |N(0,1)| noise (:498,503,508).  thread = (Philox block, env):
 //      one Philox4x32-10 call + one Box-Muller pair serves two adjacent table columns.
 // =================================================================================================
-__global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise) {
+__global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_profiles) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.B) return;
+  const int npairs = do_profiles ? ((d.ns + 1) >> 1) + 2 * ((d.nl + 1) >> 1) : 0;
+  if ((int)blockIdx.y >= npairs) {
+    // ---- K6 commit of res_bus (pandapower pfsoln/_extract_results) for envs whose solve was accepted:
+    // vm_pu = |V|, va = angle(V), p_mw/q_mvar = bus demand (-Sbus*sn) + shunt*|V|^2, slack = -(V conj(I))*sn
+    if (!d.commit[e]) return;
+    const int k = (int)blockIdx.y - npairs;      // elimination position, n == slack
+    const size_t S = (size_t)d.Bp;
+    const size_t o = (size_t)d.bus_of_pos[k] * S + e;
+    double v, P, Q;
+    if (k < d.n) {
+      const double* vo = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * k) * S + e;
+      const double* sb = d.nrbuf + ((size_t)d.r_sbus + 2 * (size_t)k) * S + e;
+      const double ek = vo[(size_t)VO_E * S], fk = vo[(size_t)VO_F * S];
+      v = sqrt(ek * ek + fk * fk);
+      d.va[o] = atan2(fk, ek);
+      P = -sb[0] * d.sn; Q = -sb[S] * d.sn;
+    } else {
+      v = d.vroot; d.va[o] = 0.0;
+      double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;     // I = Y_rr V_r + sum_neighbours Y_rk V_k
+      for (int j = 0; j < d.n_root_children; ++j) {
+        const double* cb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * d.root_children[j]) * S + e;
+        const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ec = cb[(size_t)VO_E * S], fc = cb[(size_t)VO_F * S];
+        ir += g * ec - b * fc; ii += g * fc + b * ec;
+      }
+      P = -(d.vroot * ir) * d.sn; Q = (d.vroot * ii) * d.sn;
+    }
+    d.vm[o] = v;
+    d.res_p[o] = P + d.shunt_p[k] * v * v; d.res_q[o] = Q + d.shunt_q[k] * v * v;
+    return;
+  }
   const int64_t row = d.adv_row[e];
   if (row < 0) return;
   int b = blockIdx.y;                  // pair index over [pv pairs | load_p pairs | load_q pairs]
@@ -808,9 +822,13 @@ int nr_set_lds_limit(int waves, int lanes, size_t bytes) {
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st) {
   hipLaunchKernelGGL(k_reset_begin, dim3((d.B + 255) / 256), dim3(256), 0, st, d, start_rows, first_try);
 }
-void launch_advance(const Dev& d, int add_noise, hipStream_t st) {
-  const int pairs = ((d.ns + 1) >> 1) + 2 * ((d.nl + 1) >> 1);
-  hipLaunchKernelGGL(k_advance, dim3((d.B + 255) / 256, pairs), dim3(256), 0, st, d, add_noise);
+// do_profiles: next profile row + noise for the envs queued in adv_row; do_commit: res_bus commit of
+// the envs flagged by the preceding k_nr_wtree launch
+void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, hipStream_t st) {
+  const int pairs = do_profiles ? ((d.ns + 1) >> 1) + 2 * ((d.nl + 1) >> 1) : 0;
+  const int rows = pairs + (do_commit ? d.nb : 0);
+  if (rows == 0) return;
+  hipLaunchKernelGGL(k_advance, dim3((d.B + 255) / 256, rows), dim3(256), 0, st, d, add_noise, do_profiles);
 }
 void launch_gather(const Dev& d, const double* base, const int32_t* rows, const double* scales, double scale_all,
                    const int32_t* x_ptr, const int32_t* x_row, void* out, int dtype, int C, hipStream_t st) {

@@ -48,7 +48,7 @@ struct Dev {
   double *pl;                                         // [n_line][Bp] res_line.pl_mw
   double *sum_rewards;                                // [Bp]
   int32_t* steps; int64_t* start_row; uint32_t* draw;
-  uint8_t *done, *pending, *active;
+  uint8_t *done, *pending, *active, *commit;
   int64_t* adv_row; uint32_t* adv_draw;
   // ---- NR scratch (see NB_* / VO_*): row offsets of the Sbus and Vout regions
   double* nrbuf; uint32_t nrbuf_bytes; uint32_t r_sbus, r_vout;
@@ -71,7 +71,7 @@ static inline size_t nr_lds_bytes(int W, int L, int n, int cslots, int xslots, i
          Wt * R * sizeof(StepRec) + (size_t)nclist * sizeof(int32_t);
 }
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);
-void launch_advance(const Dev& d, int add_noise, hipStream_t st);
+void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, hipStream_t st);
 void launch_gather(const Dev& d, const double* base, const int32_t* rows, const double* scales, double scale_all,
                    const int32_t* x_ptr, const int32_t* x_row, void* out, int dtype, int C, hipStream_t st);
 void launch_to_envminor(const Dev& d, const double* src, double* dst, int n, hipStream_t st);
