@@ -705,7 +705,7 @@ __global__ void __launch_bounds__(256)
 k_gather(const double* __restrict__ base, const int32_t* rows_g, const double* scales_g,
          double scale_all, const int32_t* x_ptr_g, const int32_t* x_row_g,
          T* __restrict__ out, int C, int B, int Bp) {
-  __shared__ double tile[64][65];
+  __shared__ T tile[64][65];                      // output-typed tile: 16.6 KB for f32 -> 8 workgroups per CU
   // descriptors are wave-uniform (a wave handles whole columns): read them through the constant
   // address space -> s_load on the scalar unit, no VMEM round trip ahead of the data loads
   typedef const __attribute__((address_space(4))) int32_t* c_i32;
@@ -731,7 +731,7 @@ k_gather(const double* __restrict__ base, const int32_t* rows_g, const double* s
       const int c = c0 + ty + 4 * i;
       for (int q = x_ptr[c]; q < x_ptr[c + 1]; ++q) v[i] += base[(size_t)x_row[q] * Bp + e0 + tx];
     }
-    tile[ty + 4 * i][tx] = v[i];
+    tile[ty + 4 * i][tx] = (T)v[i];
   }
   __syncthreads();
   // write phase: 16 threads x 4 consecutive columns per env row -> 16-byte (f32) / 32-byte (f64) stores
@@ -744,10 +744,10 @@ k_gather(const double* __restrict__ base, const int32_t* rows_g, const double* s
     T* o = out + (size_t)e * C + c;
     if (vec) {                                   // C % 4 == 0 and c % 4 == 0: the 4 columns exist and are aligned
       struct alignas(sizeof(T) * 4) V4 { T a, b, c, d; };
-      *reinterpret_cast<V4*>(o) = V4{(T)tile[q4][r], (T)tile[q4 + 1][r], (T)tile[q4 + 2][r], (T)tile[q4 + 3][r]};
+      *reinterpret_cast<V4*>(o) = V4{tile[q4][r], tile[q4 + 1][r], tile[q4 + 2][r], tile[q4 + 3][r]};
     } else {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) if (c + u < C) o[u] = (T)tile[q4 + u][r];
+      for (int u = 0; u < 4; ++u) if (c + u < C) o[u] = tile[q4 + u][r];
     }
   }
 }
