@@ -195,13 +195,15 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   build_schedule(P, Wt, h->sched);
   if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
   const int ncl = (int)h->sched.clist.size();
-  const size_t lds_need = nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, h->sched.R, ncl);
+  // h factors in LDS too when the workgroup still fits in one CU's 160 KB (then only G goes to global scratch)
+  int h_lds = nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, h->sched.R, ncl, 1) <= 150 * 1024 ? 1 : 0;
+  if (const char* s = getenv("MAPDN_NR_H_LDS")) h_lds = atoi(s) ? 1 : 0;
+  const size_t lds_need = nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, h->sched.R, ncl, h_lds);
   if (lds_need > 160 * 1024) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
-  d.nr_waves = W; d.nr_lanes = L;
-
+  d.nr_waves = W; d.nr_lanes = L; d.nr_h_lds = h_lds;
   d.nr_rows = h->sched.R; d.nr_cslots = h->sched.n_cslots; d.nr_xslots = h->sched.n_xslots; d.nr_nclist = ncl;
   {
-    const int lr = nr_set_lds_limit(W, L, lds_need);
+    const int lr = nr_set_lds_limit(W, L, h_lds, lds_need);
     if (lr == -2) { h->err = "this (MAPDN_NR_WAVES, MAPDN_NR_LANES) combination is not compiled in"; return MAPDN_E_INVALID; }
     if (lr != 0) { h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return MAPDN_E_HIP; }
   }

@@ -206,7 +206,7 @@ __device__ __forceinline__ void bst(double x, __amdgpu_buffer_rsrc_t r, unsigned
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, voff, soff, 0);
 }
 
-template <int W, int L>
+template <int W, int L, bool HL>   // HL: the h factors live in LDS as well (when they fit), only G goes to global scratch
 __global__ void __launch_bounds__(64 * W)
 k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ terminated, double* __restrict__ info) {
   extern __shared__ double lds[];
@@ -235,7 +235,8 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   double* sS = sV + (size_t)2 * (n + 2) * L;                // sS[(2k + c)*L]
   double* cs = sS + (size_t)2 * (n + 2) * L;                // cs[(slot*8 + item)*L]
   double* xs = cs + (size_t)d.nr_cslots * 8 * L;            // xs[(slot*2 + item)*L]
-  uint8_t* s_ok = (uint8_t*)(xs - el + (size_t)d.nr_xslots * 2 * L);   // [Wt][L], Wt*L = 64*W
+  double* sH = xs + (size_t)d.nr_xslots * 2 * L;            // sH[(2k + c)*L]  (HL only; n+2 nodes)
+  uint8_t* s_ok = (uint8_t*)(sH - el + (HL ? (size_t)2 * (n + 2) * L : 0));   // [Wt][L], Wt*L = 64*W
   StepRec* s_sched = (StepRec*)(s_ok + 64 * W);             // 16-byte aligned: all sizes above are multiples of 64
   int32_t* s_clist = (int32_t*)(s_sched + (size_t)Wt * R);
   {  // stage the step records (and the overflow child list) in LDS
@@ -273,7 +274,7 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     o.sr = sS[(size_t)(2 * k) * L]; o.si = sS[(size_t)(2 * k + 1) * L];
   };
   auto load_bwd = [&](unsigned sb, BwdOps& o) {
-    o.h0 = bld(rs, vo[NB_H0], sb); o.h1 = bld(rs, vo[NB_H1], sb);
+    if (!HL) { o.h0 = bld(rs, vo[NB_H0], sb); o.h1 = bld(rs, vo[NB_H1], sb); }
     o.g0 = bld(rs, vo[NB_G0], sb); o.g1 = bld(rs, vo[NB_G1], sb); o.g2 = bld(rs, vo[NB_G2], sb); o.g3 = bld(rs, vo[NB_G3], sb);
   };
 
@@ -336,7 +337,8 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     cS0 = apk_r; cS1 = apk_i; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
     double* c = cs + (size_t)(T.slots & 1023u) * (8 * L);
     c[0] = apk_r; c[L] = apk_i; c[2 * L] = s0; c[3 * L] = s1; c[4 * L] = s2; c[5 * L] = s3; c[6 * L] = t0; c[7 * L] = t1;
-    bst(h0, rs, vo[NB_H0], sb); bst(h1, rs, vo[NB_H1], sb);
+    if (HL) { const unsigned k = (unsigned)T.k; sH[(size_t)(2 * k) * L] = h0; sH[(size_t)(2 * k + 1) * L] = h1; }
+    else { bst(h0, rs, vo[NB_H0], sb); bst(h1, rs, vo[NB_H1], sb); }
     bst(G0, rs, vo[NB_G0], sb); bst(G1, rs, vo[NB_G1], sb); bst(G2, rs, vo[NB_G2], sb); bst(G3, rs, vo[NB_G3], sb);
   };
   // ek/fk: this node's voltage, read from LDS one row ahead (only its own step ever writes it)
@@ -347,8 +349,9 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     const double q0 = xp[0], q1 = xp[L];
     const bool cout = (fl & S_CARRY_OUT) != 0;
     const double p0 = cout ? x0 : q0, p1 = cout ? x1 : q1;
-    const double y0 = o.h0 - (o.g0 * p0 + o.g1 * p1);
-    const double y1 = o.h1 - (o.g2 * p0 + o.g3 * p1);
+    const double hh0 = HL ? sH[(size_t)(2 * (unsigned)T.k) * L] : o.h0, hh1 = HL ? sH[(size_t)(2 * (unsigned)T.k + 1) * L] : o.h1;
+    const double y0 = hh0 - (o.g0 * p0 + o.g1 * p1);
+    const double y1 = hh1 - (o.g2 * p0 + o.g3 * p1);
     x0 = y0; x1 = y1;
     double* xo = xs + (size_t)((slots >> 10) & 1023u) * (2 * L);   // TRASH unless S_X_OUT
     xo[0] = y0; xo[L] = y1;
@@ -808,13 +811,16 @@ void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const
 #define NR_FOR_EACH(X) X(1, 4) X(1, 8) X(1, 16) X(1, 32) X(2, 4) X(2, 8) X(2, 16) X(2, 32) X(4, 8) X(4, 16) X(4, 32) X(8, 16) X(8, 32)
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
   const dim3 grid(d.Bp / d.nr_lanes);
-  const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.n, d.nr_cslots, d.nr_xslots, d.nr_rows, d.nr_nclist);
-#define X(w, l) if (d.nr_waves == w && d.nr_lanes == l) { hipLaunchKernelGGL((k_nr_wtree<w, l>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); return; }
+  const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.n, d.nr_cslots, d.nr_xslots, d.nr_rows, d.nr_nclist, d.nr_h_lds);
+#define X(w, l) if (d.nr_waves == w && d.nr_lanes == l) { \
+    if (d.nr_h_lds) hipLaunchKernelGGL((k_nr_wtree<w, l, true>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
+    else hipLaunchKernelGGL((k_nr_wtree<w, l, false>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
+    return; }
   NR_FOR_EACH(X)
 #undef X
 }
-int nr_set_lds_limit(int waves, int lanes, size_t bytes) {
-#define X(w, l) if (waves == w && lanes == l) return hipFuncSetAttribute((const void*)k_nr_wtree<w, l>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
+int nr_set_lds_limit(int waves, int lanes, int h_lds, size_t bytes) {
+#define X(w, l) if (waves == w && lanes == l) return hipFuncSetAttribute(h_lds ? (const void*)k_nr_wtree<w, l, true> : (const void*)k_nr_wtree<w, l, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
   NR_FOR_EACH(X)
 #undef X
   return -2;   // unsupported geometry

@@ -473,3 +473,44 @@ def test_batched_rollout_driver():
     assert set(stat) == {"mean_train_" + k for k in INFO_KEYS} | {"mean_train_reward"}
     assert abs(stat["mean_train_reward"] - win.reward[:, :, 0].double().mean().item()) < 1e-6
     env.close()
+
+
+@pytest.mark.parametrize("kw", [dict(state_space=["vm_pu", "pv", "reactive"]), dict(line_weight=0.5, q_weight=None),
+                                dict(line_weight=2.0), dict(reset_action=False), dict(v_lower=0.97, v_upper=1.03, voltage_weight=3.0, q_weight=0.3)])
+def test_constructor_options(kw):
+    """env kwargs that change the reward / obs composition (var_voltage_control.yaml:3-20)"""
+    case, B = "case33", 3
+    net, prof, env = make(case, B, **kw)
+    a = args_for(case, **kw)
+    oracles = [VoltageControlOracle(net, prof, a, env_id=e, do_reset=False) for e in range(B)]
+    obs, state = env.reset()
+    for e, o in enumerate(oracles):
+        oo, os_ = o.reset()
+        assert obs[e].shape == np.array(oo).shape and np.abs(np.array(oo) - obs[e].cpu().numpy()).max() < 1e-9
+        assert np.abs(os_ - state[e].cpu().numpy()).max() < 1e-7
+    if kw.get("reset_action") is False:
+        assert (env.results()["sgen_q"] == 0).all()
+    rng = np.random.default_rng(2)
+    for t in range(3):
+        act = rng.uniform(-0.8, 0.8, (B, net.n_sgen))
+        r, term, info = env.step(torch.as_tensor(act, device="cuda:0"))
+        obs = env.get_obs()
+        for e, o in enumerate(oracles):
+            ro, to, io = o.step(act[e])
+            assert abs(ro - r[e].item()) < 1e-9
+            assert np.abs(np.array(o.get_obs()) - obs[e].cpu().numpy()).max() < 1e-9
+            assert max(abs(io[k] - info[e, c].item()) for c, k in enumerate(INFO_KEYS)) < 1e-9
+    env.close()
+
+
+def test_reset_keeps_time_when_asked():
+    """reset(reset_time=False) re-uses the episode start (voltage_control_env.py:110-113)"""
+    net, prof, env = make("case33", 5)
+    env.reset()
+    s0 = env.start_rows().clone()
+    env.step(torch.zeros(5, net.n_sgen, device="cuda:0"))
+    env.reset(reset_time=False)
+    assert torch.equal(env.start_rows(), s0)
+    env.reset()
+    assert not torch.equal(env.start_rows(), s0)
+    env.close()
