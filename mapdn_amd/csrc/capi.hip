@@ -203,7 +203,9 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   d.nr_waves = W; d.nr_lanes = L; d.nr_h_lds = h_lds;
   d.nr_rows = h->sched.R; d.nr_cslots = h->sched.n_cslots; d.nr_xslots = h->sched.n_xslots; d.nr_nclist = ncl;
   {
-    const int lr = nr_set_lds_limit(W, L, h_lds, lds_need);
+    // the attribute is per kernel function, not per handle: always raise it to the full 160 KB so that
+    // handles with different LDS needs can share an instantiation
+    const int lr = nr_set_lds_limit(W, L, h_lds, 160 * 1024);
     if (lr == -2) { h->err = "this (MAPDN_NR_WAVES, MAPDN_NR_LANES) combination is not compiled in"; return MAPDN_E_INVALID; }
     if (lr != 0) { h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return MAPDN_E_HIP; }
   }
