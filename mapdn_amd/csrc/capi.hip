@@ -191,7 +191,6 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   if (!(W == 1 || W == 2 || W == 4 || W == 8) || !(L == 32 || L == 16 || L == 8 || L == 4)) {
     h->err = "MAPDN_NR_WAVES must be 1/2/4/8 and MAPDN_NR_LANES 32/16/8/4"; return MAPDN_E_INVALID; }
   const int Wt = W * (64 / L);
-  if (10 * Wt > 2 * (P.n + 2)) { h->err = "network too small for this many NR workers (epilogue scratch): raise MAPDN_NR_LANES or lower MAPDN_NR_WAVES"; return MAPDN_E_INVALID; }
   build_schedule(P, Wt, h->sched);
   if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
   const int ncl = (int)h->sched.clist.size();

@@ -237,7 +237,8 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   double* xs = cs + (size_t)d.nr_cslots * 8 * L;            // xs[(slot*2 + item)*L]
   double* sH = xs + (size_t)d.nr_xslots * 2 * L;            // sH[(2k + c)*L]  (HL only; n+2 nodes)
   uint8_t* s_ok = (uint8_t*)(sH - el + (HL ? (size_t)2 * (n + 2) * L : 0));   // [Wt][L], Wt*L = 64*W
-  StepRec* s_sched = (StepRec*)(s_ok + 64 * W);             // 16-byte aligned: all sizes above are multiples of 64
+  double* s_epi = (double*)(s_ok + 64 * W) + el;            // epilogue partials: s_epi[(q*Wt + worker)*L], 10*64*W doubles
+  StepRec* s_sched = (StepRec*)(s_ok + 64 * W + 10 * 64 * W * sizeof(double));   // 16-byte aligned: all sizes above are multiples of 64
   int32_t* s_clist = (int32_t*)(s_sched + (size_t)Wt * R);
   {  // stage the step records (and the overflow child list) in LDS
     const uint4* src = (const uint4*)d.sched;
@@ -549,9 +550,8 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     }
     return;
   }
-  // ---- combine the workers' partials through LDS (the Sbus region is free now), fixed order
-  __syncthreads();
-  double* sm = sS;                                // sm[(q*Wt + worker)*L]
+  // ---- combine the workers' partials through LDS, fixed order
+  double* sm = s_epi;                             // sm[(q*Wt + worker)*L]
   const double part[10] = {n_lo, n_hi, dev, vsum, mdrop, mrise, bar, line_loss, q_loss, q_fail};
 #pragma unroll
   for (int q = 0; q < 10; ++q) sm[(size_t)(q * Wt + t) * L] = part[q];

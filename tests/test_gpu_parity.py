@@ -534,3 +534,63 @@ def test_unsolvable_reset_is_reported_not_hidden():
     a.reset(); b.reset(); a.step(torch.zeros(4, 6, device="cuda:0")); b.step(torch.zeros(4, 6, device="cuda:0"))
     assert torch.isfinite(a.get_obs()).all() and torch.isfinite(b.get_obs()).all()
     a.close(); b.close()
+
+
+def _random_radial_net(seed):
+    """random tree, slack at a random bus (=> several elimination components), random lines / loads / sgens"""
+    from mapdn_amd.netspec import NetSpec, Profiles
+    rng = np.random.default_rng(seed)
+    nb = int(rng.integers(6, 150)) if seed < 100 else int(rng.integers(3, 8))     # seeds >= 100: tiny nets
+    parent = np.array([-1] + [int(rng.integers(max(0, i - int(rng.integers(1, 6))), i)) for i in range(1, nb)])
+    perm = rng.permutation(nb)                                   # scramble labels: slack lands anywhere in the tree
+    f = perm[parent[1:]]; t = perm[np.arange(1, nb)]
+    slack = int(perm[int(rng.integers(0, nb))])
+    n_line = nb - 1
+    nz = int(rng.integers(1, 5))
+    zone = rng.integers(1, nz + 1, nb).astype(np.int32); zone[slack] = 0
+    ns = int(rng.integers(1, 9))
+    cand = np.array([b for b in range(nb) if b != slack])
+    sgen_bus = rng.choice(cand, size=ns, replace=True).astype(np.int32)
+    nl = int(rng.integers(1, 2 * nb))
+    load_bus = rng.integers(0, nb, nl).astype(np.int32)          # loads may sit on the slack bus too
+    vn = float(rng.choice([0.4, 11.0, 20.0]))
+    sn = float(rng.choice([0.5, 1.0, 10.0]))
+    zb = vn * vn / sn
+    net = NetSpec(name=f"rand{seed}", bus_vn_kv=np.full(nb, vn), bus_zone=zone, line_from_bus=f, line_to_bus=t,
+                  line_r_ohm_per_km=rng.uniform(0.05, 0.5, n_line) * zb * 0.02, line_x_ohm_per_km=rng.uniform(0.02, 0.4, n_line) * zb * 0.02,
+                  line_c_nf_per_km=rng.uniform(0, 50, n_line), line_g_us_per_km=rng.uniform(0, 1, n_line),
+                  line_length_km=rng.uniform(0.2, 1.5, n_line), line_parallel=rng.integers(1, 3, n_line).astype(np.int32),
+                  line_in_service=np.ones(n_line, np.uint8), load_bus=load_bus, sgen_bus=sgen_bus, sgen_zone=zone[sgen_bus],
+                  ext_grid_bus=slack, ext_grid_vm_pu=float(rng.uniform(0.98, 1.03)), sn_mva=sn, f_hz=50.0)
+    T = 1500
+    pv = rng.uniform(0, 0.3 * sn / ns, (T, ns)); lp = rng.uniform(0, 0.4 * sn / nl, (T, nl)); lq = lp * rng.uniform(0.1, 0.5, (T, nl))
+    return net, Profiles(pv=pv, load_p=lp, load_q=lq, time_delta_min=3)
+
+
+@pytest.mark.parametrize("seed", list(range(12)) + [101, 102, 103])
+def test_random_topologies(seed):
+    net, prof = _random_radial_net(seed)
+    a = dict(episode_limit=240, action_scale=0.8, action_bias=0.0, voltage_barrier_type="l2", seed=seed)
+    B = 9
+    env = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0", obs_dtype=torch.float64)
+    from oracle.pp_restated import make_ybus
+    y = env.ybus_dense(); yo = make_ybus(net)[0].toarray()
+    assert np.abs(y - yo).max() <= 1e-12 * np.abs(yo).max()
+    oracles = [VoltageControlOracle(net, prof, a, env_id=e, do_reset=False) for e in range(2)]
+    obs, state = env.reset()
+    for e, o in enumerate(oracles):
+        oo, os_ = o.reset()
+        assert np.abs(np.array(oo) - obs[e].cpu().numpy()).max() < 1e-9 and np.abs(os_ - state[e].cpu().numpy()).max() < 1e-7
+    rng = np.random.default_rng(seed)
+    for t in range(3):
+        act = rng.uniform(-0.8, 0.8, (B, net.n_sgen))
+        r, term, info = env.step(torch.as_tensor(act, device="cuda:0"))
+        res = env.results(); obs = env.get_obs()
+        for e, o in enumerate(oracles):
+            ro, to, io = o.step(act[e])
+            assert abs(ro - r[e].item()) < 1e-9 and to == bool(term[e].item())
+            assert np.abs(res["vm_pu"][e].cpu().numpy() - o.res.vm_pu).max() < V_TOL
+            assert np.abs(res["p_mw"][e].cpu().numpy() - o.res.p_mw).max() < 1e-9
+            assert np.abs(res["pl_mw"][e].cpu().numpy() - o.res.pl_mw).max() < 1e-9
+            assert np.abs(np.array(o.get_obs()) - obs[e].cpu().numpy()).max() < 1e-9
+    env.close()
