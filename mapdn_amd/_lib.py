@@ -89,9 +89,15 @@ def load():
     # and the second runtime then fails with "no ROCm-capable device".)
     import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            f"{LIB_PATH} not found: build it with `python -m mapdn_amd.build` "
-            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # not a fallback: compile the same HIP sources in-tree (hipcc cross-compiles gfx950), once,
+        # race-free when several ranks start together; raise if that is impossible
+        from . import build as _build
+        try:
+            _build.build_locked()
+        except Exception as exc:
+            raise ImportError(
+                f"{LIB_PATH} not found and could not be built ({exc}); build it with "
+                "`python -m mapdn_amd.build` (hipcc --offload-arch=gfx950); there is no CPU fallback") from exc
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.mapdn_last_error.restype = C.c_char_p

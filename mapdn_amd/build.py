@@ -24,15 +24,42 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-Wall",
-           "-Wno-unused-result", "-o", LIB]
-    cmd = [c for c in cmd if c]
+    tmp = LIB + f".tmp{os.getpid()}"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-o", tmp]
     # .cpp host files are compiled as plain C++ by hipcc; .hip as HIP
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB)          # atomic: a concurrent loader never sees a half-written library
     return LIB
+
+
+def build_locked(timeout: float = 600.0) -> str:
+    """build() guarded by a lock file, for several processes (ranks) that find the library missing."""
+    import time
+    lock = LIB + ".lock"
+    t0 = time.time()
+    while True:
+        try:
+            fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+            break
+        except FileExistsError:
+            if os.path.exists(LIB) and not os.path.exists(lock):
+                return LIB
+            if time.time() - t0 > timeout:
+                raise TimeoutError(f"waiting for {lock}")
+            time.sleep(0.5)
+            if os.path.exists(LIB) and not os.path.exists(lock):
+                return LIB
+    try:
+        os.close(fd)
+        return build() if _stale() else LIB
+    finally:
+        try:
+            os.remove(lock)
+        except OSError:
+            pass
 
 
 if __name__ == "__main__":
