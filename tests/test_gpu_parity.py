@@ -63,6 +63,26 @@ def test_solve_only_matches_oracle(case):
     env.close()
 
 
+def test_ieee33_published_profile_on_gpu():
+    """Known-answer pin that does not pass through the oracle: the HIP solver on the public Baran-Wu
+    33-bus base case against the voltage profile tabulated in the literature (4 decimals), the
+    202.68 kW / 135.14 kVAr losses and Vmin 0.9131 p.u. at bus 18."""
+    from mapdn_amd.netspec import case33bw_base
+    _, p, q = case33bw_base()                      # the literature loads; make_case adds 6 PVs to the same feeder
+    net, prof, env = make("case33", 3)
+    z = np.zeros((3, net.n_sgen))
+    vm, va, it, cv = env.solve(np.tile(p, (3, 1)), np.tile(q, (3, 1)), z, z)
+    vm = vm.cpu().numpy()
+    published = np.array([1.0000, 0.9970, 0.9829, 0.9755, 0.9681, 0.9497, 0.9462, 0.9413, 0.9351, 0.9292, 0.9284,
+                          0.9269, 0.9208, 0.9185, 0.9171, 0.9157, 0.9137, 0.9131, 0.9965, 0.9929, 0.9922, 0.9916,
+                          0.9794, 0.9727, 0.9694, 0.9477, 0.9452, 0.9337, 0.9255, 0.9220, 0.9178, 0.9169, 0.9166])
+    assert cv.cpu().numpy().all() and (it.cpu().numpy() == 4).all()
+    for e in range(3):
+        assert np.abs(vm[e] - published).max() <= 5.0e-5 + 1e-12
+        assert int(vm[e].argmin()) + 1 == 18
+    env.close()
+
+
 def test_solve_nonconvergence_flag():
     """LoadflowNotConverged after 10 iterations (pandapower max_iteration='auto'), per env, while the
     other lanes of the same wavefront converge normally"""

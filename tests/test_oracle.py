@@ -26,6 +26,14 @@ def test_ieee33_known_answer():
     assert int(r.vm_pu.argmin()) + 1 == 18
     # power balance at the slack: injection == load + losses
     assert abs(-r.p_mw[0] - (p.sum() + r.pl_mw.sum())) < 1e-9
+    # the full published voltage profile of the base case (4 decimals, as tabulated in the 33-bus
+    # literature), the reactive loss 135.14 kVAr and the angle at the weakest bus (-0.495 deg)
+    published = np.array([1.0000, 0.9970, 0.9829, 0.9755, 0.9681, 0.9497, 0.9462, 0.9413, 0.9351, 0.9292, 0.9284,
+                          0.9269, 0.9208, 0.9185, 0.9171, 0.9157, 0.9137, 0.9131, 0.9965, 0.9929, 0.9922, 0.9916,
+                          0.9794, 0.9727, 0.9694, 0.9477, 0.9452, 0.9337, 0.9255, 0.9220, 0.9178, 0.9169, 0.9166])
+    assert np.abs(r.vm_pu - published).max() <= 5.0e-5 + 1e-12          # rounding of the table
+    assert abs((-r.q_mvar[0] - q.sum()) * 1e3 - 135.14) < 0.01
+    assert abs(r.va_degree[17] - (-0.495)) < 5e-4
 
 
 @pytest.mark.parametrize("case", ["case33", "case141", "case322"])
