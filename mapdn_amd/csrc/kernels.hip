@@ -124,7 +124,7 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
 //     owns one FACTOR BLOCK addressed as block(worker,row) + field through one buffer resource
 //     (scalar row offset, loop-invariant lane VGPR offsets); the backward sweep prefetches them two
 //     rows ahead.  Every step issues the same VMEM instructions, so vmcnt waits are exact.
-//   * step constants (Y entries, flags, slot ids) are 80-byte records staged once in LDS.
+//   * step constants (Y entries, flags, slot ids) are 96-byte records staged once in LDS.
 //   * |V| and angle are formed once at the end (Vm = |V|, Va = angle(V) as newtonpf) and written
 //     with e,f to the Vout region for the commit kernel.
 //  The linear system is solved for z = [dtheta ; d|V|/|V|] (|V| columns scaled by |V_k|): the
@@ -230,7 +230,7 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
 #pragma unroll
   for (int f = 0; f < NBF; ++f) vo[f] = e * 8u + (unsigned)f * rb + t * (unsigned)R * bb;
   // LDS map (doubles, each x L envs): [V (n+2) x 2][Sbus (n+2) x 2][contribution slots x 8][x slots x 2]
-  //          then [verdict bytes 64*W][schedule Wt*R*80 B][overflow child list]; node n = slack, n+1 = trash
+  //          then [verdict bytes 64*W][schedule Wt*R*96 B][overflow child list]; node n = slack, n+1 = trash
   double* sV = lds + el;                                    // sV[(2k + c)*L]
   double* sS = sV + (size_t)2 * (n + 2) * L;                // sS[(2k + c)*L]
   double* cs = sS + (size_t)2 * (n + 2) * L;                // cs[(slot*8 + item)*L]

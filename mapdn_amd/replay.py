@@ -1,0 +1,183 @@
+"""GPU-resident replay buffers with the reference's sampling semantics.
+
+The reference keeps Python lists of `Transition` namedtuples on the host
+(utilities/replay_buffer.py:5-58) — at most a few thousand entries, one env.  Here every field is
+ONE preallocated device tensor used as a ring, B transitions (one per env of a batch) are appended
+per call, and a sample is a single `index_select` per field; nothing crosses to the host.  What is
+kept from the reference, exactly:
+
+* FIFO eviction: when the buffer is full the OLDEST entry is dropped (`offset()` = `pop(0)`,
+  replay_buffer.py:12-13,25-29).
+* `TransReplayBuffer.get_batch(batch_size)` returns a CONTIGUOUS WINDOW of `batch_size`
+  transitions in insertion order, whose start is drawn uniformly from
+  `len(buffer) - batch_size + 1` positions with `np.random.choice(sample_range, 1,
+  replace=False)[0]` on numpy's global RNG (replay_buffer.py:19-23) — the same call, so a seeded
+  reference run and a seeded run of this class pick the same windows.
+* `EpisodeReplayBuffer.get_batch(batch_size)` draws `batch_size` distinct episodes with
+  `np.random.choice(length, batch_size, replace=False)` and concatenates their transitions in the
+  drawn order (replay_buffer.py:45-51).
+
+Insertion order for a batch of envs is (step, env): `add_experience` with B transitions is
+equivalent to B reference `add_experience` calls in env order.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+Batch = Dict[str, torch.Tensor]
+
+
+class TransReplayBuffer:
+    """Ring of `size` transitions; every field of a transition is a tensor [...], stored as [size, ...]."""
+
+    def __init__(self, size: int, device=None):
+        self.size = int(size)
+        if self.size <= 0:
+            raise ValueError("replay buffer size must be positive")
+        self.device = torch.device(device) if device is not None else None
+        self.store: Dict[str, torch.Tensor] = {}
+        self._tail = 0          # ring position of the oldest entry
+        self._len = 0
+
+    def __len__(self) -> int:
+        return self._len
+
+    @property
+    def buffer(self):
+        """`len(trainer.replay_buffer.buffer)` is what the reference's update condition reads
+        (models/model.py:42-44); a sized view is enough."""
+        return range(self._len)
+
+    def _allocate(self, trans: Batch) -> None:
+        for k, v in trans.items():
+            dev = self.device if self.device is not None else v.device
+            self.store[k] = torch.empty((self.size,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev)
+        if self.device is None:
+            self.device = next(iter(self.store.values())).device
+
+    def add_experience(self, trans: Batch) -> None:
+        """trans[field]: [B, ...] — B transitions appended in env order (replay_buffer.py:25-29)."""
+        if not self.store:
+            self._allocate(trans)
+        if trans.keys() != self.store.keys():
+            raise KeyError(f"transition fields {sorted(trans)} != buffer fields {sorted(self.store)}")
+        B = next(iter(trans.values())).shape[0]
+        skip = max(0, B - self.size)            # more than a buffer-full at once: only the newest survive
+        n = B - skip
+        head = (self._tail + self._len) % self.size
+        first = min(n, self.size - head)
+        for k, v in trans.items():
+            if v.shape[0] != B:
+                raise ValueError(f"field {k}: leading dimension {v.shape[0]} != {B}")
+            dst = self.store[k]
+            dst[head:head + first].copy_(v[skip:skip + first])
+            if n > first:
+                dst[0:n - first].copy_(v[skip + first:B])
+        overflow = max(0, self._len + n - self.size)
+        self._tail = (self._tail + overflow) % self.size
+        self._len = min(self.size, self._len + n)
+
+    def _window(self, start: int, count: int) -> torch.Tensor:
+        base = (self._tail + start) % self.size
+        idx = torch.arange(base, base + count, device=self.device)
+        return idx % self.size if base + count > self.size else idx
+
+    def get_single(self, index: int) -> Batch:
+        if index < 0:
+            index += self._len
+        if not 0 <= index < self._len:
+            raise IndexError("list index out of range")
+        pos = (self._tail + index) % self.size
+        return {k: v[pos] for k, v in self.store.items()}
+
+    def get_batch(self, batch_size: int, start: Optional[int] = None) -> Batch:
+        return self.get_truncated_episodes_batch(batch_size, start)
+
+    def get_truncated_episodes_batch(self, batch_size: int, start: Optional[int] = None) -> Batch:
+        sample_range = self._len - batch_size + 1
+        if sample_range <= 0:
+            raise ValueError("a must be greater than 0 unless no samples are taken")   # numpy's message
+        if start is None:
+            start = int(np.random.choice(sample_range, 1, replace=False)[0])
+        elif not 0 <= start < sample_range:
+            raise IndexError(f"window start {start} outside [0, {sample_range})")
+        idx = self._window(start, batch_size)
+        return {k: v.index_select(0, idx) for k, v in self.store.items()}
+
+    def clear(self) -> None:
+        self._tail = 0
+        self._len = 0
+
+
+class EpisodeReplayBuffer:
+    """Ring of `size` episodes of at most `max_steps` transitions each; fields stored [size, max_steps, ...]."""
+
+    def __init__(self, size: int, max_steps: int, device=None):
+        self.size, self.max_steps = int(size), int(max_steps)
+        if self.size <= 0 or self.max_steps <= 0:
+            raise ValueError("replay buffer size and max_steps must be positive")
+        self.device = torch.device(device) if device is not None else None
+        self.store: Dict[str, torch.Tensor] = {}
+        self.lengths = np.zeros(self.size, dtype=np.int64)     # host side: needed to size a sample
+        self._tail = 0
+        self._len = 0
+
+    def __len__(self) -> int:
+        return self._len
+
+    @property
+    def buffer(self):
+        return range(self._len)
+
+    def add_experience(self, episodes: Batch, lengths) -> None:
+        """episodes[field]: [T, B, ...] (time-major window of a batched rollout); lengths[b] = number of
+        valid steps of env b's episode.  Appends B episodes in env order (replay_buffer.py:53-57)."""
+        lengths = np.asarray(lengths.cpu() if isinstance(lengths, torch.Tensor) else lengths, dtype=np.int64)
+        T, B = next(iter(episodes.values())).shape[:2]
+        if T > self.max_steps or lengths.shape != (B,) or lengths.min() < 1 or lengths.max() > T:
+            raise ValueError("episode window does not fit the buffer / bad lengths")
+        if not self.store:
+            for k, v in episodes.items():
+                dev = self.device if self.device is not None else v.device
+                self.store[k] = torch.zeros((self.size, self.max_steps) + tuple(v.shape[2:]), dtype=v.dtype, device=dev)
+            if self.device is None:
+                self.device = next(iter(self.store.values())).device
+        skip = max(0, B - self.size)
+        for b in range(skip, B, max(1, self.size)):             # chunks that never wrap more than once
+            nb = min(self.size, B - b)
+            head = (self._tail + self._len) % self.size
+            first = min(nb, self.size - head)
+            for k, v in episodes.items():
+                dst = self.store[k]
+                dst[head:head + first, :T].copy_(v[:, b:b + first].transpose(0, 1))
+                if nb > first:
+                    dst[0:nb - first, :T].copy_(v[:, b + first:b + nb].transpose(0, 1))
+            pos = (head + np.arange(nb)) % self.size
+            self.lengths[pos] = lengths[b:b + nb]
+            overflow = max(0, self._len + nb - self.size)
+            self._tail = (self._tail + overflow) % self.size
+            self._len = min(self.size, self._len + nb)
+
+    def get_single(self, index: int) -> Batch:
+        if index < 0:
+            index += self._len
+        if not 0 <= index < self._len:
+            raise IndexError("list index out of range")
+        pos = (self._tail + index) % self.size
+        return {k: v[pos, :self.lengths[pos]] for k, v in self.store.items()}
+
+    def get_batch(self, batch_size: int, indices=None) -> Batch:
+        if indices is None:
+            indices = np.random.choice(self._len, batch_size, replace=False)
+        pos = (self._tail + np.asarray(indices, dtype=np.int64)) % self.size
+        flat = np.concatenate([p * self.max_steps + np.arange(self.lengths[p]) for p in pos])
+        idx = torch.from_numpy(flat).to(self.device)
+        return {k: v.reshape((self.size * self.max_steps,) + tuple(v.shape[2:])).index_select(0, idx)
+                for k, v in self.store.items()}
+
+    def clear(self) -> None:
+        self._tail = 0
+        self._len = 0
