@@ -1,0 +1,473 @@
+"""MADDPG / IDDPG learners for the batched env (BASELINE.json configs[4]).
+
+What is learned, and every quirk of how, follows the reference (file:line cited at each piece):
+`models/maddpg.py`, `models/iddpg.py`, `learning_algorithms/ddpg.py`, `models/model.py`,
+`agents/rnn_agent.py`, `critics/mlp_critic.py`, `utilities/trainer.py`, `utilities/util.py`,
+defaults from `args/default.yaml` + `args/alg_args/{maddpg,iddpg}.yaml`.  Module and parameter names
+are the reference's (`policy_dicts.0.fc1.weight`, `value_dicts.0.fc3.bias`, `target_net.…`,
+`batchnorm.…`), so a reference `model.pt` (`{"model_state_dict": …}`, train.py:119) loads with
+`strict=True` and vice versa.
+
+What is different is how it runs: tensors in, tensors out, no Python lists or host round trips —
+a batch is a dict of device tensors straight from `mapdn_amd.replay`; the centralised MADDPG critic
+never materialises the reference's [batch, n, n·obs] input (maddpg.py:41-66) — its first layer is
+evaluated as (shared observation term) + (agent-id column) + (joint-action term), with the
+"other agents' actions are detached" rule (maddpg.py:52-58) kept by a zero-valued, gradient-carrying
+own-action term; data-parallel ranks average gradients through one flat RCCL all-reduce per update.
+
+Only the configuration the DDPG family trains with exists: continuous actions, deterministic
+(non-Gaussian) policy head.  Anything else raises.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ._lib import INFO_KEYS
+from .replay import TransReplayBuffer
+from .rollout import translate_action
+
+# args/default.yaml:6-51 merged with args/alg_args/maddpg.yaml (== iddpg.yaml)
+ALG_DEFAULTS = dict(
+    gumbel_softmax=False, epsilon_softmax=False, softmax_eps=None, episodic=False, cuda=True, grad_clip_eps=1.0,
+    save_model_freq=40, replay_warmup=0, policy_lrate=1.0e-4, value_lrate=1.0e-4, mixer_lrate=None, target=True,
+    target_lr=0.1, entr=1.0e-3, max_steps=240, batch_size=32, replay=True, replay_buffer_size=5.0e3,
+    agent_type="rnn", agent_id=True, shared_params=True, layernorm=True, mixer=False, gaussian_policy=False,
+    LOG_STD_MIN=0.0, LOG_STD_MAX=0.5, fixed_policy_std=1.0, hid_activation="relu", init_type="normal", init_std=0.1,
+    action_enforcebound=True, double_q=True, clip_c=1.0, gamma=0.99, hid_size=64, continuous=True,
+    normalize_advantages=False, train_episodes_num=400, behaviour_update_freq=60, target_update_freq=120,
+    policy_update_epochs=1, value_update_epochs=10, mixer_update_epochs=None, reward_normalisation=True,
+    eval_freq=20, num_eval_episodes=10,
+)
+
+Batch = Dict[str, torch.Tensor]
+
+
+def make_alg_args(agent_num: int, obs_size: int, action_dim: int = 1, action_scale: float = 0.8,
+                  action_bias: float = 0.0, **overrides) -> SimpleNamespace:
+    """The `args` namedtuple train.py:64-67 assembles, as a namespace."""
+    d = dict(ALG_DEFAULTS)
+    unknown = set(overrides) - set(d)
+    if unknown:
+        raise KeyError(f"unknown algorithm argument(s): {sorted(unknown)}")
+    d.update(overrides)
+    d.update(agent_num=int(agent_num), obs_size=int(obs_size), action_dim=int(action_dim),
+             action_scale=float(action_scale), action_bias=float(action_bias))
+    a = SimpleNamespace(**d)
+    if not a.continuous or a.gaussian_policy or a.mixer or a.episodic or a.agent_type != "rnn":
+        raise NotImplementedError("the DDPG-family learners here cover continuous, non-Gaussian, recurrent, "
+                                  "transition-update training (args/alg_args/maddpg.yaml, iddpg.yaml)")
+    return a
+
+
+def _activation(name: str):
+    if name == "relu":
+        return F.relu
+    if name == "tanh":
+        return torch.tanh
+    raise ValueError(f"hid_activation {name!r}")
+
+
+class RNNAgent(nn.Module):
+    """fc1 -> LayerNorm -> act -> GRUCell -> fc2 (agents/rnn_agent.py:5-32)."""
+
+    def __init__(self, input_shape: int, args):
+        super().__init__()
+        self.hid_size = args.hid_size
+        self.fc1 = nn.Linear(input_shape, args.hid_size)
+        if args.layernorm:
+            self.layernorm = nn.LayerNorm(args.hid_size)
+        self.rnn = nn.GRUCell(args.hid_size, args.hid_size)
+        self.fc2 = nn.Linear(args.hid_size, args.action_dim)
+        self.use_ln = bool(args.layernorm)
+        self.act = _activation(args.hid_activation)
+
+    def trunk(self, x: torch.Tensor, hidden: torch.Tensor):
+        """x: pre-activation of fc1, [rows, hid]"""
+        if self.use_ln:
+            x = self.layernorm(x)
+        h = self.rnn(self.act(x), hidden.reshape(-1, self.hid_size))
+        return self.fc2(h), h
+
+    def forward(self, inputs, hidden):
+        a, h = self.trunk(self.fc1(inputs), hidden)
+        return a, None, h
+
+
+class MLPCritic(nn.Module):
+    """fc1 -> LayerNorm -> act -> fc2 -> act -> fc3 (critics/mlp_critic.py:7-36)."""
+
+    def __init__(self, input_shape: int, output_shape: int, args):
+        super().__init__()
+        self.fc1 = nn.Linear(input_shape, args.hid_size)
+        if args.layernorm:
+            self.layernorm = nn.LayerNorm(args.hid_size)
+        self.fc2 = nn.Linear(args.hid_size, args.hid_size)
+        self.fc3 = nn.Linear(args.hid_size, output_shape)
+        self.use_ln = bool(args.layernorm)
+        self.act = _activation(args.hid_activation)
+
+    def trunk(self, x: torch.Tensor):
+        if self.use_ln:
+            x = self.layernorm(x)
+        h = self.act(self.fc2(self.act(x)))
+        return self.fc3(h), h
+
+    def forward(self, inputs, hidden=None):
+        return self.trunk(self.fc1(inputs))
+
+
+class DDPGNet(nn.Module):
+    """`MADDPG(Model)` (models/maddpg.py:10) or `IDDPG(Model)` (models/iddpg.py:9): behaviour net holding
+    its target net, the per-agent reward BatchNorm (models/model.py:26) and the DDPG loss."""
+
+    def __init__(self, args, alg: str = "maddpg", target_net: Optional["DDPGNet"] = None):
+        super().__init__()
+        if alg not in ("maddpg", "iddpg"):
+            raise KeyError(alg)                                    # models/model_registry.py:14-25
+        self.args, self.alg = args, alg
+        self.n_, self.obs_dim, self.act_dim, self.hid_dim = args.agent_num, args.obs_size, args.action_dim, args.hid_size
+        n, o, a = self.n_, self.obs_dim, self.act_dim
+        ids = n if args.agent_id else 0
+        self.batchnorm = nn.BatchNorm1d(n)
+        # advantage normalisation: MADDPG re-uses `batchnorm` (maddpg.py:17,120); IDDPG's lives in its DDPG
+        # helper object, which is not an nn.Module — so it is NOT part of the state_dict (ddpg.py:10,34)
+        self.__dict__["_adv_batchnorm"] = self.batchnorm if alg == "maddpg" else nn.BatchNorm1d(n)
+        critic_in = (o + a) * n + ids if alg == "maddpg" else o + a + ids     # maddpg.py:20-24, iddpg.py:19-23
+        copies = 1 if args.shared_params else n
+        self.value_dicts = nn.ModuleList([MLPCritic(critic_in, 1, args) for _ in range(copies)])
+        self.policy_dicts = nn.ModuleList([RNNAgent(o + ids, args) for _ in range(copies)])   # model.py:141-164
+        self.apply(self._init_weights)
+        if target_net is not None:
+            self.target_net = target_net
+            self.reload_params_to_target()
+
+    # ---- initialisation / target handling (models/model.py:28-48,169-177) ----------------------
+    def _init_weights(self, m):
+        if type(m) == nn.Linear:
+            if self.args.init_type == "normal":
+                nn.init.normal_(m.weight, 0.0, self.args.init_std)
+            elif self.args.init_type == "orthogonal":
+                nn.init.orthogonal_(m.weight, gain=nn.init.calculate_gain(self.args.hid_activation))
+
+    def reload_params_to_target(self):
+        self.target_net.policy_dicts.load_state_dict(self.policy_dicts.state_dict())
+        self.target_net.value_dicts.load_state_dict(self.value_dicts.state_dict())
+
+    @torch.no_grad()
+    def update_target(self):
+        """soft update over every state_dict entry of the policy and value nets (model.py:34-48)"""
+        lr = self.args.target_lr
+        for mine, theirs in ((self.policy_dicts, self.target_net.policy_dicts), (self.value_dicts, self.target_net.value_dicts)):
+            src = mine.state_dict()
+            for name, param in theirs.state_dict().items():
+                param.copy_((1 - lr) * param + lr * src[name])
+
+    def init_hidden(self, batch: int = 1):
+        return self.policy_dicts[0].fc1.weight.new_zeros(batch, self.n_, self.hid_dim)    # rnn_agent.py:22-24
+
+    # ---- policy (models/model.py:101-139) --------------------------------------------------------
+    def policy(self, obs: torch.Tensor, last_hid: torch.Tensor):
+        """obs [b, n, o], last_hid [b, n, h] -> means [b, n, a], log_stds, hiddens [b, n, h]"""
+        b, n, o = obs.shape[0], self.n_, self.obs_dim
+        if self.args.shared_params:
+            ag = self.policy_dicts[0]
+            w = ag.fc1.weight
+            x = F.linear(obs, w[:, :o], ag.fc1.bias)                     # observation columns
+            if self.args.agent_id:
+                x = x + w[:, o:].t().unsqueeze(0)                        # one-hot id i selects column o + i
+            means, hid = ag.trunk(x.reshape(b * n, -1), last_hid)
+            means, hid = means.view(b, n, -1), hid.view(b, n, -1)
+            log_stds = torch.full_like(means, math.log(self.args.fixed_policy_std))       # model.py:119-120
+        else:
+            ms, hs = [], []
+            for i, ag in enumerate(self.policy_dicts):
+                w = ag.fc1.weight
+                x = F.linear(obs[:, i], w[:, :o], ag.fc1.bias)
+                if self.args.agent_id:
+                    x = x + w[:, o + i]
+                m, h = ag.trunk(x, last_hid[:, i])
+                ms.append(m); hs.append(h)
+            means, hid = torch.stack(ms, 1), torch.stack(hs, 1)
+            log_stds = torch.zeros_like(means)                            # model.py:134-135
+        return means, log_stds, hid
+
+    # ---- critics ---------------------------------------------------------------------------------
+    def value(self, obs: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
+        """obs [b, n, o], act [b, n, a] -> [b, n, 1]"""
+        return self._value_central(obs, act) if self.alg == "maddpg" else self._value_independent(obs, act)
+
+    def _value_independent(self, obs, act):
+        """IDDPG (iddpg.py:32-58): critic input [obs_i | id_i | act_i]"""
+        b, n, o = obs.shape[0], self.n_, self.obs_dim
+        ids = n if self.args.agent_id else 0
+
+        def first_layer(cr, ob, ac, who):
+            w = cr.fc1.weight
+            x = F.linear(ob, w[:, :o], cr.fc1.bias) + F.linear(ac, w[:, o + ids:])
+            if ids:
+                x = x + (w[:, o:o + n].t().unsqueeze(0) if who is None else w[:, o + who])
+            return x
+
+        if self.args.shared_params:
+            cr = self.value_dicts[0]
+            v, _ = cr.trunk(first_layer(cr, obs, act, None).reshape(b * n, -1))
+            return v.view(b, n, -1)
+        return torch.stack([cr.trunk(first_layer(cr, obs[:, i], act[:, i], i))[0] for i, cr in enumerate(self.value_dicts)], 1)
+
+    def _value_central(self, obs, act):
+        """MADDPG (maddpg.py:35-79): agent i's critic sees [all obs | id_i | all actions] and only its OWN
+        action carries gradient.  First layer = W_obs·obs_all + W_id[:, i] + W_act·act_all, where the joint
+        action enters detached and agent i's own (act_i - act_i.detach()) — zero in value — restores its
+        gradient path; no [b, n, n·o] tensor is ever built."""
+        b, n, o, a = obs.shape[0], self.n_, self.obs_dim, self.act_dim
+        ids = n if self.args.agent_id else 0
+        obs_all, act_all = obs.reshape(b, n * o), act.reshape(b, n * a)
+        own = (act - act.detach()) if act.requires_grad else None
+
+        def first_layer(cr, who):
+            w = cr.fc1.weight
+            w_act = w[:, n * o + ids:]
+            base = F.linear(obs_all, w[:, :n * o], cr.fc1.bias) + F.linear(act_all.detach(), w_act)      # [b, h]
+            if who is None:                                              # all agents at once: [b, n, h]
+                x = base.unsqueeze(1)
+                if ids:
+                    x = x + w[:, n * o:n * o + n].t().unsqueeze(0)
+                else:
+                    x = x.expand(b, n, -1)
+                if own is not None:
+                    x = x + torch.einsum("bna,hna->bnh", own, w_act.reshape(-1, n, a))
+                return x
+            x = base + w[:, n * o + who] if ids else base
+            if own is not None:
+                x = x + F.linear(own[:, who], w_act[:, who * a:(who + 1) * a])
+            return x
+
+        if self.args.shared_params:
+            cr = self.value_dicts[0]
+            v, _ = cr.trunk(first_layer(cr, None).reshape(b * n, -1))
+            return v.view(b, n, 1)
+        return torch.stack([cr.trunk(first_layer(cr, i))[0] for i, cr in enumerate(self.value_dicts)], 1)
+
+    # ---- action selection (maddpg.py:81-101 == iddpg.py:60-80; utilities/util.py:52-98) ----------
+    def get_actions(self, state, status, exploration, actions_avail, target=False, last_hid=None):
+        net = self.target_net if (target and self.args.target) else self
+        means, log_stds, hiddens = net.policy(state, last_hid)
+        if means.size(-1) > 1:                                   # maddpg.py:85-87 (action_dim > 1 sums over agents)
+            means_, log_stds_ = means.sum(dim=1, keepdim=True), log_stds.sum(dim=1, keepdim=True)
+        else:
+            means_, log_stds_ = means, log_stds
+        actions, log_prob = self._select_action(means_, log_stds_, status, exploration)
+        restore_mask = 1.0 - (actions_avail == 0).to(actions.dtype)
+        return actions, restore_mask * actions, log_prob, (means, log_stds), hiddens
+
+    def _select_action(self, mean, log_std, status, exploration):
+        a = self.args
+        if status == "train":
+            if not exploration:
+                return mean, None
+            std = log_std.exp()
+            if a.action_enforcebound:                            # util.py:57-66
+                x_t = mean + std * torch.randn_like(mean)        # Normal(mean, std).rsample()
+                y_t = torch.tanh(x_t)
+                log_prob = -((x_t - mean) ** 2) / (2 * std ** 2) - log_std - math.log(math.sqrt(2 * math.pi))
+                return y_t, log_prob - torch.log(1 - y_t.pow(2) + 1e-6)
+            x_t = std * torch.randn_like(mean)                   # util.py:67-76
+            log_prob = -(x_t ** 2) / (2 * std ** 2) - log_std - math.log(math.sqrt(2 * math.pi))
+            return mean + x_t, log_prob
+        if status == "test":                                     # util.py:80-87
+            return (torch.tanh(mean) if a.action_enforcebound else mean), None
+        raise ValueError(status)
+
+    # ---- loss (models/maddpg.py:103-125 == learning_algorithms/ddpg.py:15-39) ----------------------
+    def normalise_reward(self, reward: torch.Tensor) -> torch.Tensor:
+        return self.batchnorm(reward) if self.args.reward_normalisation else reward     # model.py:316-317
+
+    def get_loss(self, batch: Batch, want=("policy", "value")):
+        """batch: state/next_state [bs, n, o], action/action_avail [bs, n, a], reward [bs, n], done [bs, 1],
+        last_hid/hid [bs, n, h] float32 (the `unpack_data` tensors, model.py:304-319); optional `valid`
+        [bs] weights the means (1 everywhere = the reference).  Returns (policy_loss, value_loss,
+        (means, log_stds)); a loss not in `want` is None and its forward passes are skipped."""
+        n = self.n_
+        state, actions, next_state = batch["state"], batch["action"], batch["next_state"]
+        avail, last_hid, hid = batch["action_avail"], batch["last_hid"], batch["hid"]
+        rewards = self.normalise_reward(batch["reward"].float())
+        done = batch["done"].float().view(-1, 1)
+        valid = batch.get("valid")
+        wmean = (lambda t: t.mean()) if valid is None else \
+            (lambda t: (t * valid.float().view(-1, 1)).sum() / (valid.float().sum().clamp(min=1.0) * t.shape[1]))
+        policy_loss = value_loss = action_out = None
+        if "policy" in want:
+            _, actions_pol, _, action_out, _ = self.get_actions(state, "train", False, avail, False, last_hid)
+            advantages = self.value(state, actions_pol).view(-1, n)
+            if self.args.normalize_advantages:
+                advantages = self._adv_batchnorm.to(advantages.device)(advantages)
+            policy_loss = wmean(-advantages)
+        if "value" in want:
+            with torch.no_grad():
+                _, next_actions, _, _, _ = self.get_actions(next_state, "train", False, avail,
+                                                            not self.args.double_q, hid)
+                next_values = self.target_net.value(next_state, next_actions).view(-1, n)
+                returns = rewards + self.args.gamma * (1 - done) * next_values
+            values = self.value(state, actions).view(-1, n)
+            value_loss = wmean((returns - values).pow(2))
+        return policy_loss, value_loss, action_out
+
+
+def normal_entropy(log_stds: torch.Tensor) -> torch.Tensor:
+    """Normal(mean, std).entropy().mean() (utilities/util.py:37-38)"""
+    return (0.5 + 0.5 * math.log(2 * math.pi) + log_stds).mean()
+
+
+class PGTrainer:
+    """`PGTrainer` (utilities/trainer.py:9-108) + the rollout/update schedule of `Model.train_process`,
+    `transition_update` and `evaluation` (models/model.py:39-70,197-302) for a batch of B envs.
+
+    One `run()` is one episode of every env.  `steps` counts batched steps, so with B == 1 the update
+    schedule is the reference's; with B envs each update still draws `batch_size` transitions (a
+    contiguous window of the (step, env)-ordered replay, see mapdn_amd/replay.py).  With
+    torch.distributed initialised, gradients are averaged over ranks (one flat all-reduce per
+    update) before clipping, so every rank applies the same step to identical replicas."""
+
+    def __init__(self, args, alg: str, env, device=None, data_parallel: Optional[bool] = None):
+        self.args, self.env = args, env
+        self.device = torch.device(device if device is not None else getattr(env, "device", "cpu"))
+        target = DDPGNet(args, alg).to(self.device) if args.target else None
+        self.behaviour_net = DDPGNet(args, alg, target).to(self.device)
+        self.replay_buffer = TransReplayBuffer(int(args.replay_buffer_size), device=self.device)
+        rms = dict(alpha=0.99, eps=1e-5)                                                   # trainer.py:26-27
+        self.policy_optimizer = torch.optim.RMSprop(self.behaviour_net.policy_dicts.parameters(), lr=args.policy_lrate, **rms)
+        self.value_optimizer = torch.optim.RMSprop(self.behaviour_net.value_dicts.parameters(), lr=args.value_lrate, **rms)
+        self.steps = 0
+        self.episodes = 0
+        self.entr = args.entr
+        import torch.distributed as dist
+        self._dist = dist if (data_parallel if data_parallel is not None else (dist.is_available() and dist.is_initialized())) else None
+        if self._dist is not None:                               # identical replicas to start from
+            for t in self.behaviour_net.state_dict().values():
+                self._dist.broadcast(t, src=0)
+
+    # ---- one optimiser step (trainer.py:73-98) ---------------------------------------------------
+    def _all_reduce_grads(self, params):
+        if self._dist is None:
+            return
+        grads = [p.grad for p in params if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        self._dist.all_reduce(flat)
+        flat /= self._dist.get_world_size()
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+
+    def _apply(self, optimizer, loss, stat, key):
+        optimizer.zero_grad()
+        loss.backward()
+        params = optimizer.param_groups[0]["params"]
+        self._all_reduce_grads(params)
+        norm = torch.nn.utils.clip_grad_norm_(params, self.args.grad_clip_eps)          # util.py:161-163
+        optimizer.step()
+        stat[f"mean_train_{key}_grad_norm"] = norm
+        stat[f"mean_train_{key}_loss"] = loss.detach()
+
+    def value_transition_process(self, stat, batch: Batch):
+        _, value_loss, _ = self.behaviour_net.get_loss(batch, want=("value",))
+        self._apply(self.value_optimizer, value_loss, stat, "value")
+
+    def policy_transition_process(self, stat, batch: Batch):
+        policy_loss, _, (means, log_stds) = self.behaviour_net.get_loss(batch, want=("policy",))
+        stat["mean_train_policy_loss_raw"] = policy_loss.detach()
+        if self.entr > 0:                                        # trainer.py:39-49
+            entropy = normal_entropy(log_stds)
+            policy_loss = policy_loss - self.entr * entropy
+            stat["mean_train_entropy"] = entropy.detach()
+        self._apply(self.policy_optimizer, policy_loss, stat, "policy")
+
+    def value_replay_process(self, stat):
+        self.value_transition_process(stat, self.replay_buffer.get_batch(self.args.batch_size))
+
+    def policy_replay_process(self, stat):
+        self.policy_transition_process(stat, self.replay_buffer.get_batch(self.args.batch_size))
+
+    def transition_update(self, trans: Batch, stat):
+        """models/model.py:39-70 with replay=True, mixer=False"""
+        a = self.args
+        self.replay_buffer.add_experience(trans)
+        if self.steps > a.replay_warmup and len(self.replay_buffer) >= a.batch_size and self.steps % a.behaviour_update_freq == 0:
+            for _ in range(a.value_update_epochs):
+                self.value_replay_process(stat)
+            for _ in range(a.policy_update_epochs):
+                self.policy_replay_process(stat)
+        if a.target and self.steps % a.target_update_freq == 0:
+            self.behaviour_net.update_target()
+
+    # ---- rollouts (models/model.py:197-302) -------------------------------------------------------
+    def _episode(self, stat, train: bool):
+        env, net, a = self.env, self.behaviour_net, self.args
+        B, dv = env.n_envs, self.device
+        prefix = "mean_train_" if train else "mean_test_"
+        obs, _ = env.reset()
+        obs = obs.float().clone()
+        last_hid = net.init_hidden(B)
+        avail = env.get_avail_actions().to(dv)
+        alive = torch.ones(B, dtype=torch.bool, device=dv)
+        info_sum = torch.zeros(len(INFO_KEYS), dtype=torch.float64, device=dv)
+        rew_sum = torch.zeros((), dtype=torch.float64, device=dv)
+        n_alive = torch.zeros((), dtype=torch.float64, device=dv)
+        for t in range(a.max_steps):
+            with torch.no_grad():
+                if train:
+                    action, action_pol, _, _, hid = net.get_actions(obs, "train", True, avail, False, last_hid)
+                else:
+                    action, action_pol, _, _, hid = net.get_actions(obs, "test", False, avail, False, last_hid)
+                actual = translate_action(action.squeeze(-1), a.action_scale, a.action_bias)      # util.py:123-132
+            reward, done, info = env.step(actual)
+            next_obs = env.get_obs().float().clone()
+            w = alive.double()
+            info_sum += (info.double() * w.unsqueeze(-1)).sum(0); rew_sum += (reward.double() * w).sum(); n_alive += w.sum()
+            if train:
+                trans = dict(state=obs, action=action_pol, reward=reward.float().unsqueeze(-1).expand(B, net.n_).contiguous(),
+                             next_state=next_obs, done=done.view(B, 1).float(),
+                             last_step=(done | (t == a.max_steps - 1)).view(B, 1).float(), action_avail=avail,
+                             last_hid=last_hid, hid=hid, valid=alive.clone())
+                self.transition_update(trans, stat)
+                self.steps += 1
+            alive = alive & ~done.bool()
+            obs, last_hid = next_obs, hid
+            if t % 16 == 15 and not bool(alive.any()):          # the only host sync: once per 16 steps
+                break
+        denom = n_alive.clamp(min=1.0)
+        for k, v in zip(INFO_KEYS, (info_sum / denom).tolist()):
+            stat[prefix + k] = stat.get(prefix + k, 0.0) + v if not train else v
+        stat[prefix + "reward"] = (stat.get(prefix + "reward", 0.0) if not train else 0.0) + float(rew_sum / denom)
+
+    def train_process(self, stat):
+        self._episode(stat, train=True)
+        self.episodes += 1
+        for k, v in list(stat.items()):
+            if torch.is_tensor(v):
+                stat[k] = float(v)
+
+    def evaluation(self, stat):
+        """num_eval_episodes episodes in total, B at a time (model.py:265-302)"""
+        rounds = max(1, -(-self.args.num_eval_episodes // self.env.n_envs))
+        test = {}
+        for _ in range(rounds):
+            self._episode(test, train=False)
+        stat.update({k: v / rounds for k, v in test.items()})
+
+    def run(self, stat, episode: int):
+        """trainer.py:110-113"""
+        self.train_process(stat)
+        if episode % self.args.eval_freq == self.args.eval_freq - 1 or episode == 0:
+            self.evaluation(stat)
+
+    def save(self, path):
+        torch.save({"model_state_dict": self.behaviour_net.state_dict()}, path)          # train.py:119
+
+    def load(self, path):
+        self.behaviour_net.load_state_dict(torch.load(path, map_location=self.device)["model_state_dict"])

@@ -1,0 +1,205 @@
+"""MADDPG / IDDPG learner against fixtures produced by the reference's own code
+(tests/golden/make_learner_golden.py): forward passes, both DDPG losses, and every entry of the
+state_dict after two value steps, one policy step and one soft target update.  float32 throughout;
+tolerances cover the different (factored) summation order of the first layers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mapdn_amd.learner import DDPGNet, PGTrainer, make_alg_args
+
+HERE = os.path.dirname(__file__)
+VARIANTS = {
+    "maddpg_shared": dict(alg="maddpg"),
+    "iddpg_shared": dict(alg="iddpg"),
+    "maddpg_separate": dict(alg="maddpg", shared_params=False, agent_id=False, hid_activation="tanh"),
+    "iddpg_separate_noln": dict(alg="iddpg", shared_params=False, layernorm=False, double_q=False,
+                                reward_normalisation=False, normalize_advantages=True),
+}
+RTOL, ATOL = 2e-5, 2e-6
+
+
+def _load(name):
+    z = np.load(os.path.join(HERE, "golden", f"learner_{name}.npz"))
+    over = dict(VARIANTS[name]); alg = over.pop("alg")
+    n, o = z["batch/state"].shape[1:]
+    h = z["batch/hid"].shape[-1]
+    args = make_alg_args(n, o, 1, hid_size=h, **over)
+    trainer = PGTrainer(args, alg, env=None, device="cpu", data_parallel=False)
+    init = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("init/")}
+    trainer.behaviour_net.load_state_dict(init, strict=True)          # names/shapes == reference model.pt
+    batch = {k[6:]: torch.from_numpy(z[k]).float() for k in z.files if k.startswith("batch/")}
+    return z, args, trainer, batch
+
+
+def _close(a, b, what):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    assert np.allclose(a, b, rtol=RTOL, atol=ATOL), (what, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_forward_and_losses_match_reference(name):
+    z, args, tr, b = _load(name)
+    net = tr.behaviour_net
+    means, log_stds, hid = net.policy(b["state"], b["last_hid"])
+    _close(means, z["out/means"], "means"); _close(log_stds, z["out/log_stds"], "log_stds"); _close(hid, z["out/hiddens"], "hid")
+    _close(net.value(b["state"], b["action"]), z["out/value"], "value")
+    a, _, lp, _, _ = net.get_actions(b["state"], "test", False, b["action_avail"], False, b["last_hid"])
+    assert lp is None
+    _close(a, z["out/test_action"], "test action")
+    a, _, _, _, _ = net.get_actions(b["state"], "train", False, b["action_avail"], True, b["last_hid"])
+    _close(a, z["out/target_mean_action"], "target policy")
+    act = b["action"].clone().requires_grad_(True)
+    net.value(b["state"], act).sum().backward()
+    _close(act.grad, z["out/dvalue_daction"], "d value / d action (own-action gradient rule)")
+    net.zero_grad()
+    pl, vl, (m2, ls2) = net.get_loss(b)
+    _close(pl, z["out/policy_loss"], "policy loss"); _close(vl, z["out/value_loss"], "value loss")
+    only_v = net.get_loss(b, want=("value",))
+    assert only_v[0] is None and only_v[2] is None
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_update_steps_match_reference(name):
+    z, args, tr, b = _load(name)
+    net = tr.behaviour_net
+    net.get_loss(b)                                    # the generator's loss probe also moved the BatchNorm statistics
+    stat = {}
+    tr.value_transition_process(stat, b)
+    tr.value_transition_process(stat, b)
+    tr.policy_transition_process(stat, b)
+    net.update_target()
+    for k in ("value_grad_norm", "value_loss", "entropy", "policy_grad_norm", "policy_loss"):
+        _close(stat["mean_train_" + k], z["stat/mean_train_" + k], k)
+    final = net.state_dict()
+    ref_keys = sorted(k[6:] for k in z.files if k.startswith("final/"))
+    assert sorted(final) == ref_keys
+    for k in ref_keys:
+        if k.endswith("num_batches_tracked"):
+            assert int(final[k]) == int(z["final/" + k]), k
+        else:
+            # parameters moved by lr 1e-4 RMSprop steps: compare the MOVE, not just the value
+            init = z["init/" + k]
+            assert np.allclose(final[k].numpy() - init, z["final/" + k] - init, rtol=2e-3, atol=2e-6), k
+
+
+def test_valid_mask_and_argument_checks():
+    z, args, tr, b = _load("maddpg_shared")
+    net = tr.behaviour_net
+    torch.manual_seed(0)
+    p0, v0, _ = net.get_loss(b)
+    b2 = dict(b); b2["valid"] = torch.ones(b["state"].shape[0], dtype=torch.bool)
+    p1, v1, _ = net.get_loss(b2)
+    assert torch.allclose(p0, p1) and torch.allclose(v0, v1)
+    with pytest.raises(KeyError):
+        make_alg_args(3, 7, nonsense=1)
+    with pytest.raises(NotImplementedError):
+        make_alg_args(3, 7, gaussian_policy=True)
+    with pytest.raises(KeyError):
+        DDPGNet(args, "coma")
+    a, a_pol, lp, _, hid = net.get_actions(b["state"], "train", True, b["action_avail"], False, b["last_hid"])
+    assert a.abs().max() <= 1.0 and lp.shape == a.shape and hid.shape == b["hid"].shape
+
+
+class _ToyEnv:
+    """stand-in with the VoltageControlBatch surface (the real one needs a GPU): reward = -|a - target|"""
+
+    def __init__(self, B, n, o, device="cpu", episode_limit=12):
+        self.n_envs, self.n_agents, self.obs_size, self.device, self.episode_limit = B, n, o, torch.device(device), episode_limit
+        self.g = torch.Generator().manual_seed(0)
+
+    def reset(self):
+        self.t = 0
+        self.o = torch.randn(self.n_envs, self.n_agents, self.obs_size, generator=self.g)
+        return self.o, None
+
+    def get_avail_actions(self):
+        return torch.ones(self.n_envs, self.n_agents, 1)
+
+    def get_obs(self):
+        return self.o
+
+    def step(self, a):
+        self.t += 1
+        r = -(a - 0.3 * self.o[..., 0]).abs().mean(1).double()
+        self.o = torch.randn(self.n_envs, self.n_agents, self.obs_size, generator=self.g)
+        done = torch.full((self.n_envs,), self.t >= self.episode_limit, dtype=torch.bool)
+        return r, done, torch.zeros(self.n_envs, 11, dtype=torch.float64)
+
+
+def test_trainer_schedule_and_checkpoint(tmp_path):
+    torch.manual_seed(0); np.random.seed(0)
+    env = _ToyEnv(4, 3, 5)
+    args = make_alg_args(3, 5, 1, hid_size=16, max_steps=12, batch_size=8, replay_buffer_size=64,
+                         behaviour_update_freq=4, target_update_freq=6, value_update_epochs=2, num_eval_episodes=4)
+    tr = PGTrainer(args, "iddpg", env, device="cpu", data_parallel=False)
+    before = {k: v.clone() for k, v in tr.behaviour_net.state_dict().items()}
+    stat = {}
+    tr.run(stat, 0)
+    assert tr.steps == 12 and tr.episodes == 1 and len(tr.replay_buffer) == 48
+    assert {"mean_train_reward", "mean_test_reward", "mean_train_value_loss", "mean_train_policy_loss"} <= set(stat)
+    assert all(isinstance(v, float) for v in stat.values())
+    after = tr.behaviour_net.state_dict()
+    assert any(not torch.equal(before[k], after[k]) for k in before if k.startswith("policy_dicts"))
+    assert any(not torch.equal(before[k], after[k]) for k in before if k.startswith("target_net.value_dicts"))
+    p = tmp_path / "model.pt"
+    tr.save(p)
+    tr2 = PGTrainer(args, "iddpg", env, device="cpu", data_parallel=False)
+    tr2.load(p)
+    for k, v in tr.behaviour_net.state_dict().items():
+        assert torch.equal(v, tr2.behaviour_net.state_dict()[k])
+
+
+# ---- data-parallel update: world_size-2 gloo processes vs. one process on the union batch -----------
+def _dp_batch(n, o, h, bs, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)      # noqa: E731
+    return dict(state=r(bs, n, o), action=torch.tanh(r(bs, n, 1)), reward=r(bs, 1).expand(bs, n).contiguous(),
+                next_state=r(bs, n, o), done=(torch.rand(bs, 1, generator=g) < 0.2).float(), last_step=torch.zeros(bs, 1),
+                action_avail=torch.ones(bs, n, 1), last_hid=0.3 * r(bs, n, h), hid=0.3 * r(bs, n, h))
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                      # different initial weights: rank 0's must win (broadcast)
+    args = make_alg_args(3, 5, 1, hid_size=8, reward_normalisation=False)
+    tr = PGTrainer(args, "maddpg", env=None, device="cpu")
+    assert tr._dist is not None
+    stat = {}
+    b = _dp_batch(3, 5, 8, 6, seed=7 + rank)
+    tr.value_transition_process(stat, b)
+    tr.policy_transition_process(stat, b)
+    q.put((rank, {k: v.numpy().copy() for k, v in tr.behaviour_net.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_update_equals_union_batch():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in got[0]:
+        assert np.array_equal(got[0][k], got[1][k]), k                   # replicas stay identical
+    torch.manual_seed(100)
+    args = make_alg_args(3, 5, 1, hid_size=8, reward_normalisation=False)
+    tr = PGTrainer(args, "maddpg", env=None, device="cpu", data_parallel=False)
+    b0, b1 = _dp_batch(3, 5, 8, 6, 7), _dp_batch(3, 5, 8, 6, 8)
+    union = {k: torch.cat([b0[k], b1[k]]) for k in b0}
+    stat = {}
+    tr.value_transition_process(stat, union)
+    tr.policy_transition_process(stat, union)
+    for k, v in tr.behaviour_net.state_dict().items():
+        assert np.allclose(v.numpy(), got[0][k], rtol=1e-4, atol=1e-6), k
