@@ -16,6 +16,10 @@
 
 #include "kernels.hpp"
 
+#ifndef MAPDN_NR_PF
+#define MAPDN_NR_PF 2
+#endif
+
 namespace mapdn {
 
 // =================================================================================================
@@ -241,14 +245,49 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   StepRec* s_sched = (StepRec*)(s_ok + 64 * W + 10 * 64 * W * sizeof(double));   // 16-byte aligned: all sizes above are multiples of 64
   int32_t* s_clist = (int32_t*)(s_sched + (size_t)Wt * R);
   {  // stage the step records (and the overflow child list) in LDS
+    // Global -> LDS staging in batches: the loads of a batch are unconditional (index clamped) and issued
+    // back to back, only the LDS stores are predicated — a load-per-iteration loop would pay the full
+    // memory latency once per element with one or two waves per SIMD.
     const uint4* src = (const uint4*)d.sched;
     uint4* dst = (uint4*)s_sched;
-    for (unsigned i = threadIdx.x; i < 6u * Wt * (unsigned)R; i += 64u * W) dst[i] = src[i];
-    for (unsigned i = threadIdx.x; i < (unsigned)d.nr_nclist; i += 64u * W) s_clist[i] = d.clist[i];
+    const unsigned n4 = 6u * Wt * (unsigned)R, n2 = 2u * n;
     // Sbus of this workgroup's envs -> LDS; flat start (runpp init="auto": every bus at the slack set-point)
     const double* gS = d.nrbuf + (size_t)d.r_sbus * d.Bp + e;
-    for (unsigned i = t; i < 2u * (n + 2); i += Wt) sS[(size_t)i * L] = (i < 2u * n) ? gS[(size_t)i * d.Bp] : 0.0;
-    for (unsigned k = t; k < n + 2; k += Wt) { sV[(size_t)(2 * k) * L] = vroot; sV[(size_t)(2 * k + 1) * L] = 0.0; }
+    constexpr unsigned RC = 8, SC = 20;
+    {                                            // first batch of both streams in flight together
+      double sv[SC];
+      const unsigned q = threadIdx.x, qs = 64u * W;   // named registers: an indexed uint4 array is not promoted out of scratch
+      const uint4 r0 = src[min(q, n4 - 1)], r1 = src[min(q + qs, n4 - 1)], r2 = src[min(q + 2 * qs, n4 - 1)],
+                  r3 = src[min(q + 3 * qs, n4 - 1)], r4 = src[min(q + 4 * qs, n4 - 1)], r5 = src[min(q + 5 * qs, n4 - 1)],
+                  r6 = src[min(q + 6 * qs, n4 - 1)], r7 = src[min(q + 7 * qs, n4 - 1)];
+#pragma unroll
+      for (unsigned j = 0; j < SC; ++j) sv[j] = gS[(size_t)min(t + j * Wt, n2 - 1) * d.Bp];
+      for (unsigned i = threadIdx.x; i < (unsigned)d.nr_nclist; i += 64u * W) s_clist[i] = d.clist[i];
+      for (unsigned k = t; k < n + 2; k += Wt) { sV[(size_t)(2 * k) * L] = vroot; sV[(size_t)(2 * k + 1) * L] = 0.0; }
+      for (unsigned i = n2 + t; i < 2u * (n + 2); i += Wt) sS[(size_t)i * L] = 0.0;
+      if (q < n4) dst[q] = r0;
+      if (q + qs < n4) dst[q + qs] = r1;
+      if (q + 2 * qs < n4) dst[q + 2 * qs] = r2;
+      if (q + 3 * qs < n4) dst[q + 3 * qs] = r3;
+      if (q + 4 * qs < n4) dst[q + 4 * qs] = r4;
+      if (q + 5 * qs < n4) dst[q + 5 * qs] = r5;
+      if (q + 6 * qs < n4) dst[q + 6 * qs] = r6;
+      if (q + 7 * qs < n4) dst[q + 7 * qs] = r7;
+#pragma unroll
+      for (unsigned j = 0; j < SC; ++j) if (t + j * Wt < n2) sS[(size_t)(t + j * Wt) * L] = sv[j];
+    }
+    for (unsigned base = threadIdx.x + RC * 64u * W; base < n4; base += 2 * 64u * W) {      // long schedules: the rest, two at a time
+      const uint4 r0 = src[base], r1 = src[min(base + 64u * W, n4 - 1)];
+      dst[base] = r0;
+      if (base + 64u * W < n4) dst[base + 64u * W] = r1;
+    }
+    for (unsigned base = t + SC * Wt; base < n2; base += SC * Wt) {
+      double sv[SC];
+#pragma unroll
+      for (unsigned j = 0; j < SC; ++j) sv[j] = gS[(size_t)min(base + j * Wt, n2 - 1) * d.Bp];
+#pragma unroll
+      for (unsigned j = 0; j < SC; ++j) if (base + j * Wt < n2) sS[(size_t)(base + j * Wt) * L] = sv[j];
+    }
     if (t == 0) {                                // the ZERO slots (second-to-last of each kind) read as 0 forever
 #pragma unroll
       for (int i = 0; i < 8; ++i) cs[((size_t)(d.nr_cslots - 2) * 8 + i) * L] = 0.0;
@@ -259,6 +298,11 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   const StepRec* seq = s_sched + (size_t)t * R;  // per lane: this worker's records
 
   const bool act = d.active[e] != 0;              // this env takes part in the solve (same for all its workers)
+  // step() bookkeeping inputs, fetched now so that their latency is not paid at the very end
+  const int bk_steps = d.steps[e];
+  const int64_t bk_start = d.start_row[e];
+  const uint32_t bk_draw = d.draw[e];
+  const double bk_sum = d.sum_rewards[e];
   bool done = !act;
   bool conv = false;
   int it = 0;
@@ -381,16 +425,19 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
       load_ops(T0, o0);
       unsigned sb = 0;
       int r = 0;
+      // prefetches past the last row are clamped to it instead of skipped: every pass through the loop body
+      // issues the same LDS / VMEM instructions, so the compiler's s_waitcnt counts stay exact (a
+      // conditional load makes it fall back to waiting for everything in flight)
       for (; r + 2 < R; r += 3) {
         T2 = seq[r + 2]; load_ops(T1, o1);
         fwd_step(T0, o0, sb);
         if (W > 1) lds_barrier();
-        if (r + 3 < R) T0 = seq[r + 3];
+        T0 = seq[min(r + 3, R - 1)];
         load_ops(T2, o2);
         fwd_step(T1, o1, sb + bb);
         if (W > 1) lds_barrier();
-        if (r + 4 < R) T1 = seq[r + 4];
-        if (r + 3 < R) load_ops(T0, o0);
+        T1 = seq[min(r + 4, R - 1)];
+        load_ops(T0, o0);
         fwd_step(T2, o2, sb + 2 * bb);
         if (W > 1) lds_barrier();
         sb += 3 * bb;
@@ -412,37 +459,33 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     }
     if (__all(done)) break;                      // same envs, same values in every wave of the group
     // ------------------------------------------------------------------ backward sweep + update
-    // factor loads (global scratch) two rows ahead, own voltage (LDS) one row ahead
+    // factor loads (global scratch) PF rows ahead through a static register ring, record two rows and
+    // own voltage (LDS) one row ahead.  The loop is unrolled by PF + 1 (a multiple of 3) so every ring
+    // index is a compile-time constant; prefetches below row 0 are clamped to it, never skipped (see above)
     x0 = x1 = 0.0;
     {
-      StepRec T0 = seq[R - 1], T1 = seq[R > 1 ? R - 2 : 0], T2;
-      BwdOps o0 = {}, o1 = {}, o2 = {};
-      double e0, f0, e1, f1, e2, f2;
-      unsigned sb = (unsigned)(R - 1) * bb;
-      load_bwd(sb, o0);
-      if (R > 1) load_bwd(sb - bb, o1);
-      e0 = sV[(size_t)(2 * (unsigned)T0.k) * L]; f0 = sV[(size_t)(2 * (unsigned)T0.k + 1) * L];
+      constexpr int PF = MAPDN_NR_PF, U = PF + 1;
+      BwdOps fo[U];
+      StepRec Tq[3];
+      double eq[3], fq[3];
+#pragma unroll
+      for (int j = 0; j < PF; ++j) load_bwd(__builtin_amdgcn_readfirstlane((unsigned)max(R - 1 - j, 0) * bb), fo[j]);
+      Tq[0] = seq[R - 1]; Tq[1] = seq[max(R - 2, 0)];
+      eq[0] = sV[(size_t)(2 * (unsigned)Tq[0].k) * L]; fq[0] = sV[(size_t)(2 * (unsigned)Tq[0].k + 1) * L];
       int r = R - 1;
-      for (; r - 2 >= 0; r -= 3) {
-        T2 = seq[r - 2]; load_bwd(sb - 2 * bb, o2);
-        e1 = sV[(size_t)(2 * (unsigned)T1.k) * L]; f1 = sV[(size_t)(2 * (unsigned)T1.k + 1) * L];
-        bwd_step(T0, o0, e0, f0);
-        if (W > 1) lds_barrier();
-        if (r - 3 >= 0) { T0 = seq[r - 3]; load_bwd(sb - 3 * bb, o0); }
-        e2 = sV[(size_t)(2 * (unsigned)T2.k) * L]; f2 = sV[(size_t)(2 * (unsigned)T2.k + 1) * L];
-        bwd_step(T1, o1, e1, f1);
-        if (W > 1) lds_barrier();
-        if (r - 4 >= 0) { T1 = seq[r - 4]; load_bwd(sb - 4 * bb, o1); }
-        if (r - 3 >= 0) { e0 = sV[(size_t)(2 * (unsigned)T0.k) * L]; f0 = sV[(size_t)(2 * (unsigned)T0.k + 1) * L]; }
-        bwd_step(T2, o2, e2, f2);
-        if (W > 1) lds_barrier();
-        sb -= 3 * bb;
+      while (r >= 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (r < 0) break;
+          load_bwd(__builtin_amdgcn_readfirstlane((unsigned)max(r - PF, 0) * bb), fo[(u + PF) % U]);   // block offset as an SGPR
+          Tq[(u + 2) % 3] = seq[max(r - 2, 0)];
+          eq[(u + 1) % 3] = sV[(size_t)(2 * (unsigned)Tq[(u + 1) % 3].k) * L];
+          fq[(u + 1) % 3] = sV[(size_t)(2 * (unsigned)Tq[(u + 1) % 3].k + 1) * L];
+          bwd_step(Tq[u % 3], fo[u % U], eq[u % 3], fq[u % 3]);
+          if (W > 1) lds_barrier();
+          --r;
+        }
       }
-      if (r >= 0) {
-        if (r - 1 >= 0) { e1 = sV[(size_t)(2 * (unsigned)T1.k) * L]; f1 = sV[(size_t)(2 * (unsigned)T1.k + 1) * L]; }
-        bwd_step(T0, o0, e0, f0); if (W > 1) lds_barrier();
-      }
-      if (r - 1 >= 0) { bwd_step(T1, o1, e1, f1); if (W > 1) lds_barrier(); }
     }
     if (!done) ++it;
   }
@@ -587,12 +630,12 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     inf[8] = tot[7]; inf[9] = ql; inf[10] = 0.0;
     if (!ok) { rew -= 200.0; inf[10] = 1.0; inf[3] = 0.0; inf[9] = qf; }                 // :192-196
     // ---- bookkeeping: next profile row uses t = steps BEFORE the increment (:199 vs :202)
-    const int st = d.steps[e];
-    d.adv_row[e] = d.start_row[e] + st;
-    d.adv_draw[e] = d.draw[e];
-    d.draw[e] += 1;
+    const int st = bk_steps;
+    d.adv_row[e] = bk_start + st;
+    d.adv_draw[e] = bk_draw;
+    d.draw[e] = bk_draw + 1;
     d.steps[e] = st + 1;
-    d.sum_rewards[e] += rew;
+    d.sum_rewards[e] = bk_sum + rew;
     const bool term = (st + 1 >= d.episode_limit) || !ok;                                 // :204
     d.done[e] = term ? 1 : 0;
     reward[e] = rew; terminated[e] = term ? 1 : 0;

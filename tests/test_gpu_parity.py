@@ -614,3 +614,31 @@ def test_random_topologies(seed):
             assert np.abs(res["pl_mw"][e].cpu().numpy() - o.res.pl_mw).max() < 1e-9
             assert np.abs(np.array(o.get_obs()) - obs[e].cpu().numpy()).max() < 1e-9
     env.close()
+
+
+def test_end_to_end_ddpg_training_on_device(tmp_path):
+    """rollout through the HIP env + GPU replay + MADDPG/IDDPG updates: runs, learns state, checkpoints
+    in the reference's model.pt layout"""
+    from mapdn_amd.learner import PGTrainer, make_alg_args
+    net, prof = make_case("case33")
+    for alg in ("maddpg", "iddpg"):
+        torch.manual_seed(0); np.random.seed(0)
+        env = VoltageControlBatch(net, prof, args_for("case33", episode_limit=24), n_envs=64, device="cuda:0", copy=True)
+        args = make_alg_args(env.n_agents, env.obs_size, 1, 0.8, 0.0, max_steps=24, batch_size=128,
+                             replay_buffer_size=64 * 16, behaviour_update_freq=8, target_update_freq=8,
+                             value_update_epochs=2, num_eval_episodes=64)
+        tr = PGTrainer(args, alg, env)
+        before = {k: v.clone() for k, v in tr.behaviour_net.state_dict().items()}
+        stat = {}
+        tr.run(stat, 0)
+        assert tr.steps == 24 and len(tr.replay_buffer) == 64 * 16
+        assert np.isfinite([stat["mean_train_reward"], stat["mean_test_reward"], stat["mean_train_value_loss"]]).all()
+        assert 0.0 <= stat["mean_train_totally_controllable_ratio"] <= 1.0
+        after = tr.behaviour_net.state_dict()
+        assert any(not torch.equal(before[k], after[k]) for k in before if k.startswith("policy_dicts"))
+        b = tr.replay_buffer.get_batch(128)
+        assert b["state"].is_cuda and b["state"].shape == (128, env.n_agents, env.obs_size) and bool(b["valid"].all())
+        tr.save(tmp_path / f"{alg}.pt")
+        sd = torch.load(tmp_path / f"{alg}.pt")["model_state_dict"]
+        assert "policy_dicts.0.rnn.weight_ih" in sd and "target_net.value_dicts.0.fc3.bias" in sd
+        env.close()
