@@ -209,6 +209,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     if (lr != 0) { h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return MAPDN_E_HIP; }
   }
   UP(sched, h->sched.steps); UP(clist, h->sched.clist);
+  UP(flat, h->sched.flat); d.flat_bytes = (uint32_t)(h->sched.flat.size() * sizeof(double));
   {  // NR scratch: factor blocks (one per (worker,row) step) | Sbus | Vout; a single buffer resource addresses it
     const int nblk = Wt * h->sched.R;
     d.r_sbus = (uint32_t)nblk * NBF;

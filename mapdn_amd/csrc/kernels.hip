@@ -14,10 +14,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.hpp"
 
 #ifndef MAPDN_NR_PF
 #define MAPDN_NR_PF 2
+#endif
+// a Newton step smaller than this (max over buses of |dtheta|, |d|V|/|V||) predicts convergence: the next
+// forward sweep is then run in its cheap mismatch-only form first (see k_nr_wtree)
+#ifndef MAPDN_NR_CHECK_DX
+#define MAPDN_NR_CHECK_DX 1e-7
 #endif
 
 namespace mapdn {
@@ -162,6 +169,7 @@ __device__ __forceinline__ double barrier(int type, double v) {
 
 struct FwdOps { double ek, fk, ep, fp, sr, si; };
 struct BwdOps { double h0, h1, g0, g1, g2, g3; };
+struct FlatOps { double sr, si, i0, i1, i2, i3, apr, api; };   // first eight fields of a Schedule::flat step
 
 __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -230,6 +238,9 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d.nrbuf, 0, d.nrbuf_bytes, 0x00020000);
   const unsigned rb = (unsigned)d.Bp * 8u;       // bytes per row
   const unsigned bb = (unsigned)NBF * rb;        // bytes per factor block
+  const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(d.flat), 0, d.flat_bytes, 0x00020000);
+  constexpr unsigned FB = (unsigned)FLAT_N * 8u; // bytes per flat-start step
+  const unsigned voF = t * (unsigned)R * FB;     // this worker's flat-start steps (same address for its L lanes)
   unsigned vo[NBF];                              // env + field + worker offsets (loop-invariant VGPRs)
 #pragma unroll
   for (int f = 0; f < NBF; ++f) vo[f] = e * 8u + (unsigned)f * rb + t * (unsigned)R * bb;
@@ -318,15 +329,27 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     o.ep = sV[(size_t)(2 * p) * L]; o.fp = sV[(size_t)(2 * p + 1) * L];
     o.sr = sS[(size_t)(2 * k) * L]; o.si = sS[(size_t)(2 * k + 1) * L];
   };
-  auto load_bwd = [&](unsigned sb, BwdOps& o) {
+  // backward-sweep operands of row `row`: h of this env from its factor block; G from the factor block or,
+  // in the first iteration, from the flat-start table (rsG / voG / strideG select the source without a branch)
+  auto load_bwd = [&](unsigned row, __amdgpu_buffer_rsrc_t rsG, const unsigned (&voG)[4], unsigned strideG, BwdOps& o) {
+    const unsigned sb = __builtin_amdgcn_readfirstlane(row * bb), sg = __builtin_amdgcn_readfirstlane(row * strideG);
     if (!HL) { o.h0 = bld(rs, vo[NB_H0], sb); o.h1 = bld(rs, vo[NB_H1], sb); }
-    o.g0 = bld(rs, vo[NB_G0], sb); o.g1 = bld(rs, vo[NB_G1], sb); o.g2 = bld(rs, vo[NB_G2], sb); o.g3 = bld(rs, vo[NB_G3], sb);
+    o.g0 = bld(rsG, voG[0], sg); o.g1 = bld(rsG, voG[1], sg); o.g2 = bld(rsG, voG[2], sg); o.g3 = bld(rsG, voG[3], sg);
+  };
+  auto load_flat = [&](unsigned row, FlatOps& o) {
+    const unsigned sf = __builtin_amdgcn_readfirstlane(row * FB);
+    o.sr = bld(rsF, voF + FL_SR * 8u, sf); o.si = bld(rsF, voF + FL_SI * 8u, sf);
+    o.i0 = bld(rsF, voF + FL_I0 * 8u, sf); o.i1 = bld(rsF, voF + FL_I1 * 8u, sf);
+    o.i2 = bld(rsF, voF + FL_I2 * 8u, sf); o.i3 = bld(rsF, voF + FL_I3 * 8u, sf);
+    o.apr = bld(rsF, voF + FL_APR * 8u, sf); o.api = bld(rsF, voF + FL_API * 8u, sf);
   };
 
   // Every step issues EXACTLY the same memory instructions whatever its flags (fwd: 16 gather reads,
   // 8 contribution writes, 6 factor stores; bwd: 2 x reads, 2 x writes, 2 V writes, 6 factor loads):
   // absent children / parents are the ZERO slot, unread outputs go to the TRASH slot / node.
-  auto fwd_step = [&](const StepRec& T, const FwdOps& o, unsigned sb) {
+  // `prefetch` issues the next rows' record / operand reads: it runs right AFTER this step's gathers so that
+  // those — the head of the row's dependency chain — are first in the in-order LDS queue
+  auto fwd_step = [&](const StepRec& T, const FwdOps& o, unsigned sb, auto&& prefetch) {
     const uint32_t fl = T.flags;
     // (1) the gathers first: they depend on the previous row's writes and head the critical path
     const double* c0 = cs + (size_t)(T.chs & 1023u) * (8 * L);
@@ -334,6 +357,7 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     double g0[8], g1[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { g0[i] = c0[i * L]; g1[i] = c1[i * L]; }
+    prefetch();
     // (2) child-independent part: A_kp = V_k conj(Y_kp V_p), A_pk = V_p conj(Y_pk V_k), A_kk = |V_k|^2 conj(Y_kk)
     const double gkk = T.ykk[0], bkk = T.ykk[1], gkp = T.ykp[0], bkp = T.ykp[1], gpk = T.ypk[0], bpk = T.ypk[1];
     const double ek = o.ek, fk = o.fk, ep = o.ep, fp = o.fp;
@@ -386,18 +410,108 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     else { bst(h0, rs, vo[NB_H0], sb); bst(h1, rs, vo[NB_H1], sb); }
     bst(G0, rs, vo[NB_G0], sb); bst(G1, rs, vo[NB_G1], sb); bst(G2, rs, vo[NB_G2], sb); bst(G3, rs, vo[NB_G3], sb);
   };
+  // Mismatch-only form of the forward step (no Jacobian, no elimination, no factor stores): only the S
+  // part of the contributions (items 0, 1) travels.  Same expressions, same order as fwd_step, so the
+  // verdict is the one the full step would reach.
+  auto fwd_step_light = [&](const StepRec& T, const FwdOps& o, auto&& prefetch) {
+    const uint32_t fl = T.flags;
+    const double* c0 = cs + (size_t)(T.chs & 1023u) * (8 * L);
+    const double* c1 = cs + (size_t)((T.chs >> 10) & 1023u) * (8 * L);
+    const double g00 = c0[0], g01 = c0[L], g10 = c1[0], g11 = c1[L];
+    prefetch();
+    const double gkk = T.ykk[0], bkk = T.ykk[1], gkp = T.ykp[0], bkp = T.ykp[1], gpk = T.ypk[0], bpk = T.ypk[1];
+    const double ek = o.ek, fk = o.fk, ep = o.ep, fp = o.fp;
+    const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
+    const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
+    const double ur = gpk * ek - bpk * fk, ui = gpk * fk + bpk * ek;
+    const double apk_r = ep * ur + fp * ui, apk_i = fp * ur - ep * ui;
+    const double v2 = ek * ek + fk * fk;
+    const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
+    const double aks_r = ek * T.cks[0] + fk * T.cks[1], aks_i = fk * T.cks[0] - ek * T.cks[1];
+    const bool cin = (fl & S_CARRY_IN) != 0;
+    double aS0 = (cin ? cS0 : 0.0) + g00, aS1 = (cin ? cS1 : 0.0) + g01;
+    aS0 += g10; aS1 += g11;
+    const int nch = (int)(fl >> 16);
+    if (nch > 2) {
+      auto gather = [&](unsigned slot) { const double* c = cs + (size_t)slot * (8 * L); aS0 += c[0]; aS1 += c[L]; };
+      gather((T.chs >> 20) & 1023u);
+      for (int j = 3; j < nch; ++j) gather((unsigned)s_clist[T.cptr + j - 3]);
+    }
+    const double sr = (akk_r + aks_r) + akp_r + aS0, si = (akk_i + aks_i) + akp_i + aS1;
+    const double Fp = sr - o.sr, Fq = si - o.si;
+    allok = allok && (!(fl & S_LIVE) || ((fabs(Fp) < tol) && (fabs(Fq) < tol)));
+    cS0 = apk_r; cS1 = apk_i;
+    double* c = cs + (size_t)(T.slots & 1023u) * (8 * L);
+    c[0] = apk_r; c[L] = apk_i;
+  };
+  // First iteration: every V is the flat start, so D^-1 (I), G and the link terms are the host-made
+  // constants of Schedule::flat; per env there is only the forward substitution of the right-hand side
+  // r = F - sum of the children's t (items 6, 7 of the contribution slots), h = I r, t = L h.
+  auto fwd_step_flat = [&](const StepRec& T, const FwdOps& o, const FlatOps& q, unsigned sb, auto&& prefetch) {
+    const uint32_t fl = T.flags;
+    const double* c0 = cs + (size_t)(T.chs & 1023u) * (8 * L);
+    const double* c1 = cs + (size_t)((T.chs >> 10) & 1023u) * (8 * L);
+    const double g06 = c0[6 * L], g07 = c0[7 * L], g16 = c1[6 * L], g17 = c1[7 * L];
+    prefetch();
+    const bool cin = (fl & S_CARRY_IN) != 0;
+    double aR0 = (cin ? cR0 : 0.0) + g06, aR1 = (cin ? cR1 : 0.0) + g07;
+    aR0 += g16; aR1 += g17;
+    const int nch = (int)(fl >> 16);
+    if (nch > 2) {
+      auto gather = [&](unsigned slot) { const double* c = cs + (size_t)slot * (8 * L); aR0 += c[6 * L]; aR1 += c[7 * L]; };
+      gather((T.chs >> 20) & 1023u);
+      for (int j = 3; j < nch; ++j) gather((unsigned)s_clist[T.cptr + j - 3]);
+    }
+    const double Fp = q.sr - o.sr, Fq = q.si - o.si;
+    allok = allok && (!(fl & S_LIVE) || ((fabs(Fp) < tol) && (fabs(Fq) < tol)));
+    const double r0 = Fp - aR0, r1 = Fq - aR1;
+    const double h0 = q.i0 * r0 + q.i1 * r1, h1 = q.i2 * r0 + q.i3 * r1;
+    const double t0 = q.api * h0 + q.apr * h1, t1 = q.api * h1 - q.apr * h0;
+    cR0 = t0; cR1 = t1;
+    double* c = cs + (size_t)(T.slots & 1023u) * (8 * L);
+    c[6 * L] = t0; c[7 * L] = t1;
+    if (HL) { const unsigned k = (unsigned)T.k; sH[(size_t)(2 * k) * L] = h0; sH[(size_t)(2 * k + 1) * L] = h1; }
+    else { bst(h0, rs, vo[NB_H0], sb); bst(h1, rs, vo[NB_H1], sb); }
+  };
+  // the row loop of those two forms: record two rows, operands one row (flat constants two rows) ahead
+  auto fwd_sweep_alt = [&](auto kind) {
+    constexpr int K = decltype(kind)::value;       // 1: mismatch only, 2: flat start
+    StepRec Tq[3]; FwdOps oq[3]; FlatOps fq[3];
+    Tq[0] = seq[0]; Tq[1] = seq[min(1, R - 1)];
+    load_ops(Tq[0], oq[0]);
+    if constexpr (K == 2) { load_flat(0u, fq[0]); load_flat((unsigned)min(1, R - 1), fq[1]); }
+    int r = 0;
+    while (r < R) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (r >= R) break;
+        auto pf = [&]() { Tq[(u + 2) % 3] = seq[min(r + 2, R - 1)]; load_ops(Tq[(u + 1) % 3], oq[(u + 1) % 3]); };
+        if constexpr (K == 2) {
+          load_flat((unsigned)min(r + 2, R - 1), fq[(u + 2) % 3]);
+          fwd_step_flat(Tq[u % 3], oq[u % 3], fq[u % 3], __builtin_amdgcn_readfirstlane((unsigned)r * bb), pf);
+        } else {
+          fwd_step_light(Tq[u % 3], oq[u % 3], pf);
+        }
+        if (W > 1) lds_barrier();
+        ++r;
+      }
+    }
+  };
+  double dxm = 0.0;                                // largest Newton step component of this worker's nodes, per env
   // ek/fk: this node's voltage, read from LDS one row ahead (only its own step ever writes it)
-  auto bwd_step = [&](const StepRec& T, const BwdOps& o, double ek, double fk) {
+  auto bwd_step = [&](const StepRec& T, const BwdOps& o, double ek, double fk, auto&& prefetch) {
     const uint32_t fl = T.flags;
     const uint32_t slots = T.slots;
     const double* xp = xs + (size_t)(slots >> 20) * (2 * L);       // parent's x slot (ZERO slot for slack parents)
     const double q0 = xp[0], q1 = xp[L];
+    prefetch();
     const bool cout = (fl & S_CARRY_OUT) != 0;
     const double p0 = cout ? x0 : q0, p1 = cout ? x1 : q1;
     const double hh0 = HL ? sH[(size_t)(2 * (unsigned)T.k) * L] : o.h0, hh1 = HL ? sH[(size_t)(2 * (unsigned)T.k + 1) * L] : o.h1;
     const double y0 = hh0 - (o.g0 * p0 + o.g1 * p1);
     const double y1 = hh1 - (o.g2 * p0 + o.g3 * p1);
     x0 = y0; x1 = y1;
+    dxm = fmax(dxm, (fl & S_LIVE) ? fmax(fabs(y0), fabs(y1)) : 0.0);
     double* xo = xs + (size_t)((slots >> 10) & 1023u) * (2 * L);   // TRASH unless S_X_OUT
     xo[0] = y0; xo[L] = y1;
     // newtonpf update: Va += dx_a, Vm += dx_m, V = Vm e^{jVa}, with dx_a = -y0, dx_m = -|V| y1
@@ -413,13 +527,23 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     sV[(size_t)(2 * k + 1) * L] = done ? fk : fn;
   };
 
+  // Sweep forms.  `first`: the flat-start iteration (host-factorised constants).  `light`: the previous Newton
+  // step of every unfinished env of this workgroup was tiny, so convergence is expected and the sweep is
+  // first run mismatch-only; if some env then fails the test after all, the sweep is redone in full (its
+  // factors are needed for another iteration).  All three flags are uniform over the workgroup: every
+  // wave holds the same envs and derives them from the same per-env values.
+  bool first = true, light = false;
   while (!nothing_to_solve) {
     // ------------------------------------------------------------------ forward sweep
-    // three rotating record / operand sets (loop unrolled by 3 so the rotation is static): while
-    // row r computes, record r+2 and the LDS operands of row r+1 are already on their way
     allok = true;
     cS0 = cS1 = cD0 = cD1 = cD2 = cD3 = cR0 = cR1 = 0.0;
-    {
+    if (first) {
+      fwd_sweep_alt(std::integral_constant<int, 2>{});
+    } else if (light) {
+      fwd_sweep_alt(std::integral_constant<int, 1>{});
+    } else {
+      // three rotating record / operand sets (loop unrolled by 3 so the rotation is static): while
+      // row r computes, record r+2 and the LDS operands of row r+1 are already on their way
       StepRec T0 = seq[0], T1 = seq[R > 1 ? 1 : 0], T2;
       FwdOps o0, o1, o2;
       load_ops(T0, o0);
@@ -429,29 +553,30 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
       // issues the same LDS / VMEM instructions, so the compiler's s_waitcnt counts stay exact (a
       // conditional load makes it fall back to waiting for everything in flight)
       for (; r + 2 < R; r += 3) {
-        T2 = seq[r + 2]; load_ops(T1, o1);
-        fwd_step(T0, o0, sb);
+        fwd_step(T0, o0, sb, [&]() { T2 = seq[r + 2]; load_ops(T1, o1); });
         if (W > 1) lds_barrier();
-        T0 = seq[min(r + 3, R - 1)];
-        load_ops(T2, o2);
-        fwd_step(T1, o1, sb + bb);
+        fwd_step(T1, o1, sb + bb, [&]() { T0 = seq[min(r + 3, R - 1)]; load_ops(T2, o2); });
         if (W > 1) lds_barrier();
-        T1 = seq[min(r + 4, R - 1)];
-        load_ops(T0, o0);
-        fwd_step(T2, o2, sb + 2 * bb);
+        fwd_step(T2, o2, sb + 2 * bb, [&]() { T1 = seq[min(r + 4, R - 1)]; load_ops(T0, o0); });
         if (W > 1) lds_barrier();
         sb += 3 * bb;
       }
       if (r < R) {
-        if (r + 1 < R) load_ops(T1, o1);
-        fwd_step(T0, o0, sb); if (W > 1) lds_barrier();
+        fwd_step(T0, o0, sb, [&]() { if (r + 1 < R) load_ops(T1, o1); }); if (W > 1) lds_barrier();
       }
-      if (r + 1 < R) { fwd_step(T1, o1, sb + bb); if (W > 1) lds_barrier(); }
+      if (r + 1 < R) { fwd_step(T1, o1, sb + bb, []() {}); if (W > 1) lds_barrier(); }
     }
     {                                            // AND of the workers' verdicts, per env
       s_ok[t * L + el] = allok ? 1 : 0;
       if (W > 1) lds_barrier();
       for (unsigned tt = 0; tt < Wt; ++tt) allok = allok && (s_ok[tt * L + el] != 0);
+    }
+    if (light) {
+      light = false;
+      if (__any(!done && !allok && it < d.max_it)) {   // mispredicted: this env iterates on and needs the factors
+        if (W > 1) lds_barrier();                      // s_ok is rewritten by the redone sweep's verdict
+        continue;
+      }
     }
     if (!done) {
       conv = allok;
@@ -463,13 +588,18 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     // own voltage (LDS) one row ahead.  The loop is unrolled by PF + 1 (a multiple of 3) so every ring
     // index is a compile-time constant; prefetches below row 0 are clamped to it, never skipped (see above)
     x0 = x1 = 0.0;
+    dxm = 0.0;
     {
       constexpr int PF = MAPDN_NR_PF, U = PF + 1;
+      const __amdgpu_buffer_rsrc_t rsG = first ? rsF : rs;
+      const unsigned voG[4] = {first ? voF + FL_G0 * 8u : vo[NB_G0], first ? voF + FL_G1 * 8u : vo[NB_G1],
+                               first ? voF + FL_G2 * 8u : vo[NB_G2], first ? voF + FL_G3 * 8u : vo[NB_G3]};
+      const unsigned strideG = first ? FB : bb;
       BwdOps fo[U];
       StepRec Tq[3];
       double eq[3], fq[3];
 #pragma unroll
-      for (int j = 0; j < PF; ++j) load_bwd(__builtin_amdgcn_readfirstlane((unsigned)max(R - 1 - j, 0) * bb), fo[j]);
+      for (int j = 0; j < PF; ++j) load_bwd((unsigned)max(R - 1 - j, 0), rsG, voG, strideG, fo[j]);
       Tq[0] = seq[R - 1]; Tq[1] = seq[max(R - 2, 0)];
       eq[0] = sV[(size_t)(2 * (unsigned)Tq[0].k) * L]; fq[0] = sV[(size_t)(2 * (unsigned)Tq[0].k + 1) * L];
       int r = R - 1;
@@ -477,17 +607,26 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (r < 0) break;
-          load_bwd(__builtin_amdgcn_readfirstlane((unsigned)max(r - PF, 0) * bb), fo[(u + PF) % U]);   // block offset as an SGPR
-          Tq[(u + 2) % 3] = seq[max(r - 2, 0)];
-          eq[(u + 1) % 3] = sV[(size_t)(2 * (unsigned)Tq[(u + 1) % 3].k) * L];
-          fq[(u + 1) % 3] = sV[(size_t)(2 * (unsigned)Tq[(u + 1) % 3].k + 1) * L];
-          bwd_step(Tq[u % 3], fo[u % U], eq[u % 3], fq[u % 3]);
+          load_bwd((unsigned)max(r - PF, 0), rsG, voG, strideG, fo[(u + PF) % U]);
+          bwd_step(Tq[u % 3], fo[u % U], eq[u % 3], fq[u % 3], [&]() {
+            Tq[(u + 2) % 3] = seq[max(r - 2, 0)];
+            eq[(u + 1) % 3] = sV[(size_t)(2 * (unsigned)Tq[(u + 1) % 3].k) * L];
+            fq[(u + 1) % 3] = sV[(size_t)(2 * (unsigned)Tq[(u + 1) % 3].k + 1) * L];
+          });
           if (W > 1) lds_barrier();
           --r;
         }
       }
     }
+    first = false;
     if (!done) ++it;
+    {                                            // size of the step just taken, per env: max over the workers
+      s_epi[(size_t)t * L] = dxm;                // (the epilogue's LDS scratch is free during the solve)
+      if (W > 1) lds_barrier();
+      double dxe = 0.0;
+      for (unsigned tt = 0; tt < Wt; ++tt) dxe = fmax(dxe, s_epi[(size_t)tt * L]);
+      light = __all(done || dxe < MAPDN_NR_CHECK_DX);
+    }
   }
   if (t == 0) { d.iters[e] = it; d.conv[e] = conv ? 1 : 0; }
   // =================================================================== fused epilogue

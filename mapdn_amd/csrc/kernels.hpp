@@ -56,6 +56,7 @@ struct Dev {
   // ---- NR schedule (k_nr_wtree): W waves per workgroup, L envs per workgroup (64/L lane-group workers per wave), R rows
   int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots, nr_nclist, nr_h_lds;
   const StepRec* sched; const int32_t* clist;
+  const double* flat; uint32_t flat_bytes;   // Schedule::flat, [Wt][R][FLAT_N]
 };
 
 void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,

@@ -381,6 +381,39 @@ void build_schedule(const Plan& P, int W, Schedule& S) {
       T.flags = f | ((uint32_t)kids.size() << 16);
     }
   if (S.clist.empty()) S.clist.push_back(0);
+  // ---- flat-start factorisation (same formulas as k_nr_wtree's forward step with V == vroot everywhere)
+  {
+    const double v = P.vroot, v2 = v * v;
+    std::vector<double> aS((size_t)n * 2, 0.0), aD((size_t)n * 4, 0.0), node((size_t)n * FLAT_N, 0.0);
+    for (int k = 0; k < n; ++k) {                 // children have smaller positions than their parents
+      const double* c = &P.yc[(size_t)k * 8];
+      const double gkk = c[0], bkk = c[1], gkp = c[2], bkp = c[3], gpk = c[4], bpk = c[5];
+      const double akp_r = v2 * gkp, akp_i = -v2 * bkp, apk_r = v2 * gpk, apk_i = -v2 * bpk;
+      const double akk_r = v2 * gkk, akk_i = -v2 * bkk, aks_r = v * c[6], aks_i = -v * c[7];
+      const double sr = (akk_r + aks_r) + akp_r + aS[2 * k], si = (akk_i + aks_i) + akp_i + aS[2 * k + 1];
+      const double D0 = -(si - akk_i) - aD[4 * k], D1 = (sr + akk_r) - aD[4 * k + 1];
+      const double D2 = (sr - akk_r) - aD[4 * k + 2], D3 = (si + akk_i) - aD[4 * k + 3];
+      const double idet = 1.0 / (D0 * D3 - D1 * D2);
+      const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
+      const double G0 = I0 * akp_i - I1 * akp_r, G1 = I0 * akp_r + I1 * akp_i;
+      const double G2 = I2 * akp_i - I3 * akp_r, G3 = I2 * akp_r + I3 * akp_i;
+      double* o = &node[(size_t)k * FLAT_N];
+      o[FL_SR] = sr; o[FL_SI] = si; o[FL_I0] = I0; o[FL_I1] = I1; o[FL_I2] = I2; o[FL_I3] = I3;
+      o[FL_APR] = apk_r; o[FL_API] = apk_i; o[FL_G0] = G0; o[FL_G1] = G1; o[FL_G2] = G2; o[FL_G3] = G3;
+      const int p = P.par[k];
+      if (p < n) {
+        aS[2 * p] += apk_r; aS[2 * p + 1] += apk_i;
+        aD[4 * p] += apk_i * G0 + apk_r * G2; aD[4 * p + 1] += apk_i * G1 + apk_r * G3;
+        aD[4 * p + 2] += apk_i * G2 - apk_r * G0; aD[4 * p + 3] += apk_i * G3 - apk_r * G1;
+      }
+    }
+    S.flat.assign((size_t)W * R * FLAT_N, 0.0);   // idle steps: all zero (h = t = 0 go to the trash slots)
+    for (int w = 0; w < W; ++w)
+      for (int r = 0; r < R; ++r) {
+        const int k = rows[r][w];
+        if (k >= 0) std::copy_n(&node[(size_t)k * FLAT_N], (size_t)FLAT_N, &S.flat[((size_t)w * R + r) * FLAT_N]);
+      }
+  }
 }
 
 }  // namespace mapdn

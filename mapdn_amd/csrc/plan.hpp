@@ -65,7 +65,13 @@ struct Schedule {
   // LDS slots (reused by interval colouring): 8 resp. 2 doubles per env each; the last two of each kind
   // are the ZERO slot (n-2) and the TRASH slot (n-1)
   int32_t n_cslots = 0, n_xslots = 0;
+  // Flat-start constants, [W][R][FLAT_N] doubles: at the flat start every voltage equals the slack set-point, so
+  // the Jacobian of the FIRST Newton iteration — and with it the whole block LU — is the same for all envs
+  // and is factorised here once; only the right-hand side (mismatch against the env's Sbus) is per env.
+  std::vector<double> flat;
 };
+// per-step layout of Schedule::flat
+enum { FL_SR = 0, FL_SI, FL_I0, FL_I1, FL_I2, FL_I3, FL_APR, FL_API, FL_G0, FL_G1, FL_G2, FL_G3, FLAT_N };
 
 struct LineFlow {      // pi-model admittances of one net.line row for res_line.pl_mw
   int32_t fpos, tpos;  // elimination positions (n == root); out of service: both n with zero admittances
