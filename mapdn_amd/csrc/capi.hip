@@ -117,7 +117,12 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   UP(bus_of_pos, P.bus_of_pos); UP(root_children, P.root_children); UP(root_y, P.root_y);
   d.n_root_children = (int32_t)P.root_children.size();
   UP(load_ptr, P.load_ptr); UP(load_idx, P.load_idx); UP(sgen_ptr, P.sgen_ptr); UP(sgen_idx, P.sgen_idx);
-  UP(shunt_p, P.shunt_p); UP(shunt_q, P.shunt_q); UP(lines, P.lines);
+  UP(shunt_p, P.shunt_p); UP(shunt_q, P.shunt_q);
+  {
+    std::vector<LineFlow> padded(P.lines);               // read 16 bytes at a time by the NR kernel's LDS staging
+    if (padded.size() % 2) padded.push_back(LineFlow{});
+    UP(lines, padded);
+  }
   const size_t Bp = d.Bp;
 #define AL(field, rows) do { rc = dalloc(h, &d.field, (size_t)(rows) * Bp); if (rc) return rc; } while (0)
   AL(q_new, d.ns); AL(cur_pl, d.nl); AL(cur_ql, d.nl); AL(pl, d.n_line);
@@ -195,11 +200,15 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
   const int ncl = (int)h->sched.clist.size();
   // h factors in LDS too when the workgroup still fits in one CU's 160 KB (then only G goes to global scratch)
-  int h_lds = nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, h->sched.R, ncl, 1) <= 150 * 1024 ? 1 : 0;
+  // optional LDS residents, in order of benefit: the net.line constants of the fused res_line epilogue, then the h factors
+  auto lds_for = [&](int hl, int ll) { return nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, h->sched.R, ncl, hl, ll ? P.n_line : 0); };
+  int line_lds = (P.n_line > 0 && lds_for(0, 1) <= 160 * 1024) ? 1 : 0;
+  if (const char* s = getenv("MAPDN_NR_LINE_LDS")) line_lds = (atoi(s) && P.n_line > 0) ? 1 : 0;
+  int h_lds = lds_for(1, line_lds) <= 150 * 1024 ? 1 : 0;
   if (const char* s = getenv("MAPDN_NR_H_LDS")) h_lds = atoi(s) ? 1 : 0;
-  const size_t lds_need = nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, h->sched.R, ncl, h_lds);
+  const size_t lds_need = lds_for(h_lds, line_lds);
   if (lds_need > 160 * 1024) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
-  d.nr_waves = W; d.nr_lanes = L; d.nr_h_lds = h_lds;
+  d.nr_waves = W; d.nr_lanes = L; d.nr_h_lds = h_lds; d.nr_line_lds = line_lds;
   d.nr_rows = h->sched.R; d.nr_cslots = h->sched.n_cslots; d.nr_xslots = h->sched.n_xslots; d.nr_nclist = ncl;
   {
     // the attribute is per kernel function, not per handle: always raise it to the full 160 KB so that

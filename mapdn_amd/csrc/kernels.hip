@@ -255,6 +255,7 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   double* s_epi = (double*)(s_ok + 64 * W) + el;            // epilogue partials: s_epi[(q*Wt + worker)*L], 10*64*W doubles
   StepRec* s_sched = (StepRec*)(s_ok + 64 * W + 10 * 64 * W * sizeof(double));   // 16-byte aligned: all sizes above are multiples of 64
   int32_t* s_clist = (int32_t*)(s_sched + (size_t)Wt * R);
+  double* s_lines = (double*)(s_clist + ((d.nr_nclist + 3) & ~3));   // LineFlow rows of net.line (9 doubles each) when d.nr_line_lds
   {  // stage the step records (and the overflow child list) in LDS
     // Global -> LDS staging in batches: the loads of a batch are unconditional (index clamped) and issued
     // back to back, only the LDS stores are predicated — a load-per-iteration loop would pay the full
@@ -291,6 +292,19 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
       const uint4 r0 = src[base], r1 = src[min(base + 64u * W, n4 - 1)];
       dst[base] = r0;
       if (base + 64u * W < n4) dst[base + 64u * W] = r1;
+    }
+    if (d.nr_line_lds) {                         // res_line constants for the epilogue (uniform branch)
+      const uint4* ls = (const uint4*)d.lines;
+      uint4* ld = (uint4*)s_lines;
+      const unsigned nl4 = (unsigned)(nr_line_bytes(d.n_line) / 16);
+      for (unsigned base = threadIdx.x; base < nl4; base += 4 * 64u * W) {
+        const uint4 a0 = ls[base], a1 = ls[min(base + 64u * W, nl4 - 1)], a2 = ls[min(base + 2 * 64u * W, nl4 - 1)],
+                    a3 = ls[min(base + 3 * 64u * W, nl4 - 1)];
+        ld[base] = a0;
+        if (base + 64u * W < nl4) ld[base + 64u * W] = a1;
+        if (base + 2 * 64u * W < nl4) ld[base + 2 * 64u * W] = a2;
+        if (base + 3 * 64u * W < nl4) ld[base + 3 * 64u * W] = a3;
+      }
     }
     for (unsigned base = t + SC * Wt; base < n2; base += SC * Wt) {
       double sv[SC];
@@ -686,21 +700,25 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   }
   if (t == 0 && valid) d.commit[e] = commitf ? 1 : 0;
   // ---- res_line.pl_mw = Re(Sf + St) * sn   (out-of-service rows: fpos = tpos = slack, all-zero admittances)
+  // LineFlow = {int32 fpos, tpos; double y[8]}: from LDS when staged there, else through the constant address space
+  auto line_loop = [&](auto Lbase) {
 #pragma unroll 4
-  for (unsigned l = t; l < (unsigned)d.n_line; l += Wt) {
-    const c_f64 Lc = linec + (size_t)l * 9;
-    const c_i32 Li = (c_i32)Lc;
-    const unsigned a = (unsigned)Li[0], b = (unsigned)Li[1];
-    const double yffr = Lc[1], yffi = Lc[2], yftr = Lc[3], yfti = Lc[4], ytfr = Lc[5], ytfi = Lc[6], yttr = Lc[7], ytti = Lc[8];
-    const double ef = sV[(size_t)(2 * a) * L], ff = sV[(size_t)(2 * a + 1) * L], et = sV[(size_t)(2 * b) * L], ft = sV[(size_t)(2 * b + 1) * L];
-    const double ifr = yffr * ef - yffi * ff + yftr * et - yfti * ft;
-    const double ifi = yffr * ff + yffi * ef + yftr * ft + yfti * et;
-    const double itr = ytfr * ef - ytfi * ff + yttr * et - ytti * ft;
-    const double iti = ytfr * ff + ytfi * ef + yttr * ft + ytti * et;
-    const double pl = ((ef * ifr + ff * ifi) + (et * itr + ft * iti)) * d.sn;
-    if (commitf) d.pl[(size_t)l * SB + e] = pl;
-    line_loss += pl;
-  }
+    for (unsigned l = t; l < (unsigned)d.n_line; l += Wt) {
+      const auto Lc = Lbase + (size_t)l * 9;
+      const double ab = Lc[0];
+      const unsigned a = (unsigned)__double2loint(ab), b = (unsigned)__double2hiint(ab);
+      const double yffr = Lc[1], yffi = Lc[2], yftr = Lc[3], yfti = Lc[4], ytfr = Lc[5], ytfi = Lc[6], yttr = Lc[7], ytti = Lc[8];
+      const double ef = sV[(size_t)(2 * a) * L], ff = sV[(size_t)(2 * a + 1) * L], et = sV[(size_t)(2 * b) * L], ft = sV[(size_t)(2 * b + 1) * L];
+      const double ifr = yffr * ef - yffi * ff + yftr * et - yfti * ft;
+      const double ifi = yffr * ff + yffi * ef + yftr * ft + yfti * et;
+      const double itr = ytfr * ef - ytfi * ff + yttr * et - ytti * ft;
+      const double iti = ytfr * ff + ytfi * ef + yttr * ft + ytti * et;
+      const double pl = ((ef * ifr + ff * ifi) + (et * itr + ft * iti)) * d.sn;
+      if (commitf) d.pl[(size_t)l * SB + e] = pl;
+      line_loss += pl;
+    }
+  };
+  if (d.nr_line_lds) line_loop((const double*)s_lines); else line_loop(linec);
   // ---- sgen.q_mvar of the accepted solve; q statistics
 #pragma unroll 3
   for (unsigned j = t; j < (unsigned)d.ns; j += Wt) {
@@ -993,7 +1011,8 @@ void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const
 #define NR_FOR_EACH(X) X(1, 4) X(1, 8) X(1, 16) X(1, 32) X(2, 4) X(2, 8) X(2, 16) X(2, 32) X(4, 8) X(4, 16) X(4, 32) X(8, 16) X(8, 32)
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
   const dim3 grid(d.Bp / d.nr_lanes);
-  const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.n, d.nr_cslots, d.nr_xslots, d.nr_rows, d.nr_nclist, d.nr_h_lds);
+  const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.n, d.nr_cslots, d.nr_xslots, d.nr_rows, d.nr_nclist, d.nr_h_lds,
+                                  d.nr_line_lds ? d.n_line : 0);
 #define X(w, l) if (d.nr_waves == w && d.nr_lanes == l) { \
     if (d.nr_h_lds) hipLaunchKernelGGL((k_nr_wtree<w, l, true>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
     else hipLaunchKernelGGL((k_nr_wtree<w, l, false>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \

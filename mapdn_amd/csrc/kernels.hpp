@@ -54,7 +54,7 @@ struct Dev {
   double* nrbuf; uint32_t nrbuf_bytes; uint32_t r_sbus, r_vout;
   int32_t* iters; uint8_t* conv;
   // ---- NR schedule (k_nr_wtree): W waves per workgroup, L envs per workgroup (64/L lane-group workers per wave), R rows
-  int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots, nr_nclist, nr_h_lds;
+  int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots, nr_nclist, nr_h_lds, nr_line_lds;
   const StepRec* sched; const int32_t* clist;
   const double* flat; uint32_t flat_bytes;   // Schedule::flat, [Wt][R][FLAT_N]
 };
@@ -65,11 +65,14 @@ void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* in
 int nr_set_lds_limit(int waves, int lanes, int h_lds, size_t bytes);   // -2: (waves, lanes) not instantiated
 // dynamic LDS of k_nr_wtree (W waves, L envs per workgroup => Wt = W*64/L workers): node voltages and
 // Sbus (2 + 2 doubles x (n+2): nodes, slack, trash) per env, contribution slots (8 doubles/env), x slots (2 doubles/env),
-// verdict bytes, epilogue partials (10 x 64*W doubles), the Wt*R step records, overflow child list
-static inline size_t nr_lds_bytes(int W, int L, int n, int cslots, int xslots, int R, int nclist, int h_lds) {
+// verdict bytes, epilogue partials (10 x 64*W doubles), the Wt*R step records, overflow child list (padded to
+// 16 bytes), and — when they fit — the LineFlow constants of net.line for the fused res_line epilogue
+__host__ __device__ static inline size_t nr_line_bytes(int n_line) { return ((size_t)n_line * sizeof(LineFlow) + 15) & ~(size_t)15; }
+static inline size_t nr_lds_bytes(int W, int L, int n, int cslots, int xslots, int R, int nclist, int h_lds, int n_line_lds) {
   const size_t Wt = (size_t)W * (64 / L);
   return ((size_t)((h_lds ? 6 : 4) * (n + 2)) + (size_t)cslots * 8 + (size_t)xslots * 2) * (size_t)L * sizeof(double) + (size_t)W * 64 +
-         (size_t)10 * 64 * W * sizeof(double) + Wt * R * sizeof(StepRec) + (size_t)nclist * sizeof(int32_t);
+         (size_t)10 * 64 * W * sizeof(double) + Wt * R * sizeof(StepRec) + (size_t)((nclist + 3) & ~3) * sizeof(int32_t) +
+         nr_line_bytes(n_line_lds);
 }
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);
 void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, hipStream_t st);
