@@ -209,6 +209,10 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   const size_t lds_need = lds_for(h_lds, line_lds);
   if (lds_need > 160 * 1024) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
   d.nr_waves = W; d.nr_lanes = L; d.nr_h_lds = h_lds; d.nr_line_lds = line_lds;
+  // 1e-7: with quadratic convergence the mismatch after such a step is ~|Y| dx^2 << tol, so a wrong prediction
+  // (which costs one extra mismatch-only sweep for that workgroup) practically never happens
+  d.nr_check_dx = 1e-7;
+  if (const char* s = getenv("MAPDN_NR_CHECK_DX")) d.nr_check_dx = atof(s);
   d.nr_rows = h->sched.R; d.nr_cslots = h->sched.n_cslots; d.nr_xslots = h->sched.n_xslots; d.nr_nclist = ncl;
   {
     // the attribute is per kernel function, not per handle: always raise it to the full 160 KB so that

@@ -21,11 +21,6 @@
 #ifndef MAPDN_NR_PF
 #define MAPDN_NR_PF 2
 #endif
-// a Newton step smaller than this (max over buses of |dtheta|, |d|V|/|V||) predicts convergence: the next
-// forward sweep is then run in its cheap mismatch-only form first (see k_nr_wtree)
-#ifndef MAPDN_NR_CHECK_DX
-#define MAPDN_NR_CHECK_DX 1e-7
-#endif
 
 namespace mapdn {
 
@@ -639,7 +634,7 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
       if (W > 1) lds_barrier();
       double dxe = 0.0;
       for (unsigned tt = 0; tt < Wt; ++tt) dxe = fmax(dxe, s_epi[(size_t)tt * L]);
-      light = __all(done || dxe < MAPDN_NR_CHECK_DX);
+      light = __all(done || dxe < d.nr_check_dx);
     }
   }
   if (t == 0) { d.iters[e] = it; d.conv[e] = conv ? 1 : 0; }

@@ -57,6 +57,9 @@ struct Dev {
   int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots, nr_nclist, nr_h_lds, nr_line_lds;
   const StepRec* sched; const int32_t* clist;
   const double* flat; uint32_t flat_bytes;   // Schedule::flat, [Wt][R][FLAT_N]
+  // a Newton step whose largest component (|dtheta|, |d|V|/|V||) is below this predicts convergence: the next
+  // forward sweep is first run in its mismatch-only form (k_nr_wtree)
+  double nr_check_dx;
 };
 
 void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,

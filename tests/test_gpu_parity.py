@@ -642,3 +642,31 @@ def test_end_to_end_ddpg_training_on_device(tmp_path):
         sd = torch.load(tmp_path / f"{alg}.pt")["model_state_dict"]
         assert "policy_dicts.0.rnn.weight_ih" in sd and "target_net.value_dicts.0.fc3.bias" in sd
         env.close()
+
+
+@pytest.mark.parametrize("check_dx", ["1e30", "0"])
+def test_convergence_prediction_is_only_a_shortcut(check_dx, monkeypatch):
+    """The NR kernel runs a forward sweep mismatch-only when it predicts convergence and redoes it in full
+    when the prediction was wrong.  Forcing the prediction to 'always' (every sweep after the first is tried
+    mismatch-only and redone) and to 'never' must give the same iterations and bit-identical voltages."""
+    case, B = "case141", 96
+    net, prof = make_case(case)
+    rng = np.random.default_rng(5)
+    rows = rng.integers(0, prof.n_rows, B)
+    act = rng.uniform(-SCALE[case], SCALE[case], (B, net.n_sgen))
+    pl, ql, pv = prof.load_p[rows], prof.load_q[rows], prof.pv[rows]
+    qs = act * np.sqrt(prof.s_max() ** 2 - pv ** 2)
+    pl[7] *= 30.0                                    # one env that never converges
+    ref_env = VoltageControlBatch(net, prof, args_for(case), n_envs=B, device="cuda:0")
+    vm0, va0, it0, cv0 = [x.cpu().numpy() for x in ref_env.solve(pl, ql, pv, qs)]
+    ref_env.close()
+    monkeypatch.setenv("MAPDN_NR_CHECK_DX", check_dx)
+    env = VoltageControlBatch(net, prof, args_for(case), n_envs=B, device="cuda:0")
+    vm, va, it, cv = [x.cpu().numpy() for x in env.solve(pl, ql, pv, qs)]
+    env.close()
+    assert np.array_equal(it, it0) and np.array_equal(cv, cv0) and not cv[7] and it[7] == 10
+    ok = cv0.astype(bool)
+    assert np.array_equal(vm[ok], vm0[ok]) and np.array_equal(va[ok], va0[ok])
+    for e in (0, 1, 50):
+        r = runpp_restated(net, pl[e], ql[e], pv[e], qs[e])
+        assert r.iterations == it[e] and np.abs(vm[e] - r.vm_pu).max() < V_TOL
