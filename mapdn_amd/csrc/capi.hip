@@ -196,7 +196,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   if (!(W == 1 || W == 2 || W == 4 || W == 8) || !(L == 32 || L == 16 || L == 8 || L == 4)) {
     h->err = "MAPDN_NR_WAVES must be 1/2/4/8 and MAPDN_NR_LANES 32/16/8/4"; return MAPDN_E_INVALID; }
   const int Wt = W * (64 / L);
-  build_schedule(P, Wt, h->sched);
+  build_schedule(P, Wt, h->sched, nr_min_cslots(W, L));
   if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
   const int ncl = (int)h->sched.clist.size();
   // h factors in LDS too when the workgroup still fits in one CU's 160 KB (then only G goes to global scratch)
@@ -204,7 +204,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   auto lds_for = [&](int hl, int ll) { return nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, h->sched.R, ncl, hl, ll ? P.n_line : 0); };
   int line_lds = (P.n_line > 0 && lds_for(0, 1) <= 160 * 1024) ? 1 : 0;
   if (const char* s = getenv("MAPDN_NR_LINE_LDS")) line_lds = (atoi(s) && P.n_line > 0) ? 1 : 0;
-  int h_lds = lds_for(1, line_lds) <= 150 * 1024 ? 1 : 0;
+  int h_lds = lds_for(1, line_lds) <= 160 * 1024 ? 1 : 0;
   if (const char* s = getenv("MAPDN_NR_H_LDS")) h_lds = atoi(s) ? 1 : 0;
   const size_t lds_need = lds_for(h_lds, line_lds);
   if (lds_need > 160 * 1024) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }

@@ -239,16 +239,19 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   unsigned vo[NBF];                              // env + field + worker offsets (loop-invariant VGPRs)
 #pragma unroll
   for (int f = 0; f < NBF; ++f) vo[f] = e * 8u + (unsigned)f * rb + t * (unsigned)R * bb;
-  // LDS map (doubles, each x L envs): [V (n+2) x 2][Sbus (n+2) x 2][contribution slots x 8][x slots x 2]
-  //          then [verdict bytes 64*W][schedule Wt*R*96 B][overflow child list]; node n = slack, n+1 = trash
+  // LDS map (doubles, each x L envs): [V (n+2) x 2][Sbus (n+2) x 2][contribution slots x 8][x slots x 2][h (n+2) x 2 if HL]
+  //          then [verdict bytes 64*W][step sizes 64*W doubles][schedule Wt*R*96 B][overflow child list][net.line constants];
+  //          node n = slack, n+1 = trash
   double* sV = lds + el;                                    // sV[(2k + c)*L]
   double* sS = sV + (size_t)2 * (n + 2) * L;                // sS[(2k + c)*L]
   double* cs = sS + (size_t)2 * (n + 2) * L;                // cs[(slot*8 + item)*L]
   double* xs = cs + (size_t)d.nr_cslots * 8 * L;            // xs[(slot*2 + item)*L]
   double* sH = xs + (size_t)d.nr_xslots * 2 * L;            // sH[(2k + c)*L]  (HL only; n+2 nodes)
   uint8_t* s_ok = (uint8_t*)(sH - el + (HL ? (size_t)2 * (n + 2) * L : 0));   // [Wt][L], Wt*L = 64*W
-  double* s_epi = (double*)(s_ok + 64 * W) + el;            // epilogue partials: s_epi[(q*Wt + worker)*L], 10*64*W doubles
-  StepRec* s_sched = (StepRec*)(s_ok + 64 * W + 10 * 64 * W * sizeof(double));   // 16-byte aligned: all sizes above are multiples of 64
+  double* s_dx = (double*)(s_ok + 64 * W) + el;             // step-size partials: s_dx[worker*L], 64*W doubles
+  double* s_epi = cs;                                       // epilogue partials s_epi[(q*Wt + worker)*L], 10*64*W doubles: they re-use the
+                                                            // contribution slots, dead once the solve is over (host: cslots >= nr_min_cslots)
+  StepRec* s_sched = (StepRec*)(s_ok + 64 * W + 64 * W * sizeof(double));   // 16-byte aligned: all sizes above are multiples of 64
   int32_t* s_clist = (int32_t*)(s_sched + (size_t)Wt * R);
   double* s_lines = (double*)(s_clist + ((d.nr_nclist + 3) & ~3));   // LineFlow rows of net.line (9 doubles each) when d.nr_line_lds
   {  // stage the step records (and the overflow child list) in LDS
@@ -630,10 +633,10 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     first = false;
     if (!done) ++it;
     {                                            // size of the step just taken, per env: max over the workers
-      s_epi[(size_t)t * L] = dxm;                // (the epilogue's LDS scratch is free during the solve)
+      s_dx[(size_t)t * L] = dxm;
       if (W > 1) lds_barrier();
       double dxe = 0.0;
-      for (unsigned tt = 0; tt < Wt; ++tt) dxe = fmax(dxe, s_epi[(size_t)tt * L]);
+      for (unsigned tt = 0; tt < Wt; ++tt) dxe = fmax(dxe, s_dx[(size_t)tt * L]);
       light = __all(done || dxe < d.nr_check_dx);
     }
   }

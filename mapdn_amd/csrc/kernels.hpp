@@ -68,13 +68,15 @@ void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* in
 int nr_set_lds_limit(int waves, int lanes, int h_lds, size_t bytes);   // -2: (waves, lanes) not instantiated
 // dynamic LDS of k_nr_wtree (W waves, L envs per workgroup => Wt = W*64/L workers): node voltages and
 // Sbus (2 + 2 doubles x (n+2): nodes, slack, trash) per env, contribution slots (8 doubles/env), x slots (2 doubles/env),
-// verdict bytes, epilogue partials (10 x 64*W doubles), the Wt*R step records, overflow child list (padded to
+// verdict bytes, step-size partials (64*W doubles), the Wt*R step records, overflow child list (padded to
 // 16 bytes), and — when they fit — the LineFlow constants of net.line for the fused res_line epilogue
 __host__ __device__ static inline size_t nr_line_bytes(int n_line) { return ((size_t)n_line * sizeof(LineFlow) + 15) & ~(size_t)15; }
+// The epilogue's partial sums (10 x 64*W doubles) re-use the contribution slots, so cslots >= nr_min_cslots(W, L).
+static inline int nr_min_cslots(int W, int L) { return (10 * 64 * W + 8 * L - 1) / (8 * L); }
 static inline size_t nr_lds_bytes(int W, int L, int n, int cslots, int xslots, int R, int nclist, int h_lds, int n_line_lds) {
   const size_t Wt = (size_t)W * (64 / L);
   return ((size_t)((h_lds ? 6 : 4) * (n + 2)) + (size_t)cslots * 8 + (size_t)xslots * 2) * (size_t)L * sizeof(double) + (size_t)W * 64 +
-         (size_t)10 * 64 * W * sizeof(double) + Wt * R * sizeof(StepRec) + (size_t)((nclist + 3) & ~3) * sizeof(int32_t) +
+         (size_t)64 * W * sizeof(double) + Wt * R * sizeof(StepRec) + (size_t)((nclist + 3) & ~3) * sizeof(int32_t) +
          nr_line_bytes(n_line_lds);
 }
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);

@@ -252,7 +252,7 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   return MAPDN_OK;
 }
 
-void build_schedule(const Plan& P, int W, Schedule& S) {
+void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots) {
   const int n = P.n;
   S.W = W; S.steps.clear(); S.clist.clear();
   std::vector<std::vector<int>> children(n + 1);
@@ -325,7 +325,7 @@ void build_schedule(const Plan& P, int W, Schedule& S) {
         release[row_of[P.par[k]] + 1].push_back(sl);
       }
     }
-    S.n_cslots = std::max(next, 1);
+    S.n_cslots = std::max(std::max(next, 1), min_cslots - 2);   // two more (ZERO, TRASH) are appended below
   }
   // x slot of parent p: written in backward row row_of[p], read by its non-carried children at
   // rows < row_of[p]; reusable by writers at rows strictly below the lowest reader row.

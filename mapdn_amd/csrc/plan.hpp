@@ -113,6 +113,7 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& out,
 // parent scheduled right after its canonical chain child (node k-1 -> k when F_PARENT_NEXT) runs on
 // the same wave and receives the contribution through registers.  The sum order of children is
 // canonical (chain child first, then ascending position) and therefore independent of W.
-void build_schedule(const Plan& P, int W, Schedule& out);
+// min_cslots: lower bound on the number of contribution slots (the kernel's epilogue re-uses that LDS region)
+void build_schedule(const Plan& P, int W, Schedule& out, int min_cslots = 0);
 
 }  // namespace mapdn
