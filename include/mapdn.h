@@ -121,7 +121,12 @@ const char* mapdn_last_error(const mapdn_handle* h);
 /* VoltageControl.__init__ up to (not including) data loading — voltage_control_env.py:36-94.
  * Builds per-unit Ybus (pandapower pd2ppc/makeYbus), the elimination order and all gather index
  * tables on the host, uploads them to `device`, allocates state for n_envs envs.
- * device == -1 builds a host-only handle (plan, dims, ybus/obs-index export; no device calls). */
+ * device == -1 builds a host-only handle (plan, dims, ybus/obs-index export; no device calls).
+ * Tuning knobs read from the environment at create time (defaults are chosen per topology):
+ *   MAPDN_NR_WAVES (1/2/4/8), MAPDN_NR_LANES (4/8/16/32)   waves and envs per NR workgroup
+ *   MAPDN_NR_H_LDS, MAPDN_NR_LINE_LDS (0/1)                keep the h factors / net.line constants in LDS
+ *   MAPDN_NR_CHECK_DX (default 1e-7)                       Newton-step size below which the next sweep is
+ *                                                          first tried mismatch-only (never changes results) */
 int mapdn_create(const mapdn_netspec* net, const mapdn_env_config* cfg, int32_t n_envs,
                  int32_t device, mapdn_handle** out);
 void mapdn_destroy(mapdn_handle* h);
