@@ -677,16 +677,28 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   // wide k_post kernel (thread per bus x env) commits res_bus — |V|, angle(V), p_mw, q_mvar — for the
   // envs flagged in d.commit: throughput work does not belong in this 512-wave kernel
   double* gV = d.nrbuf + (size_t)d.r_vout * SB + e;
+  // the barrier type is hoisted out of the loop (one branch-free instance per type), so that the unrolled
+  // iterations — sqrt and exp chains of different buses — can be interleaved by the scheduler
+  auto bus_loop = [&](auto type_tag) {
+    constexpr int BT = decltype(type_tag)::value;
 #pragma unroll 4
-  for (unsigned k = t; k < n; k += Wt) {
-    const double ek = sV[(size_t)(2 * k) * L], fk = sV[(size_t)(2 * k + 1) * L];
-    const double v = sqrt(ek * ek + fk * fk);                        // res_bus.vm_pu = |V|
-    if (commitf) { gV[((size_t)VOF * k + VO_E) * SB] = ek; gV[((size_t)VOF * k + VO_F) * SB] = fk; }
-    n_lo += (v < vlo) ? 1.0 : 0.0; n_hi += (v > vhi) ? 1.0 : 0.0;
-    dev += fabs(v - vref); vsum += v;
-    mdrop = fmax(mdrop, (v < vlo) ? (vlo - v) : 0.0);
-    mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
-    bar += barrier(d.barrier_type, v);
+    for (unsigned k = t; k < n; k += Wt) {
+      const double ek = sV[(size_t)(2 * k) * L], fk = sV[(size_t)(2 * k + 1) * L];
+      const double v = sqrt(ek * ek + fk * fk);                      // res_bus.vm_pu = |V|
+      if (commitf) { gV[((size_t)VOF * k + VO_E) * SB] = ek; gV[((size_t)VOF * k + VO_F) * SB] = fk; }
+      n_lo += (v < vlo) ? 1.0 : 0.0; n_hi += (v > vhi) ? 1.0 : 0.0;
+      dev += fabs(v - vref); vsum += v;
+      mdrop = fmax(mdrop, (v < vlo) ? (vlo - v) : 0.0);
+      mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
+      bar += barrier(BT, v);
+    }
+  };
+  switch (d.barrier_type) {
+    case MAPDN_BARRIER_L1: bus_loop(std::integral_constant<int, MAPDN_BARRIER_L1>{}); break;
+    case MAPDN_BARRIER_L2: bus_loop(std::integral_constant<int, MAPDN_BARRIER_L2>{}); break;
+    case MAPDN_BARRIER_COURANT_BELTRAMI: bus_loop(std::integral_constant<int, MAPDN_BARRIER_COURANT_BELTRAMI>{}); break;
+    case MAPDN_BARRIER_BOWL: bus_loop(std::integral_constant<int, MAPDN_BARRIER_BOWL>{}); break;
+    default: bus_loop(std::integral_constant<int, MAPDN_BARRIER_BUMP>{}); break;
   }
   if (t == n % Wt) {                              // the slack bus: committed voltage never changes
     const double v = vroot;
