@@ -66,6 +66,9 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
     else if (mode == MODE_STEP) act = !d.done[e];
     else act = d.pending[e] != 0;
     if (k == 0) d.active[e] = act ? 1 : 0;
+    // step(): the next profile row is row `steps` (before the increment, :199 vs :202) of the episode window and
+    // uses the env's current draw counter; queued here, before the solve (frozen envs do not advance)
+    if (k == 0 && mode == MODE_STEP) { d.adv_row[e] = act ? d.start_row[e] + d.steps[e] : -1; d.adv_draw[e] = d.draw[e]; }
   }
   double P = 0.0, Q = 0.0;
   for (int i = d.load_ptr[k]; i < d.load_ptr[k + 1]; ++i) {
@@ -323,7 +326,6 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   const bool act = d.active[e] != 0;              // this env takes part in the solve (same for all its workers)
   // step() bookkeeping inputs, fetched now so that their latency is not paid at the very end
   const int bk_steps = d.steps[e];
-  const int64_t bk_start = d.start_row[e];
   const uint32_t bk_draw = d.draw[e];
   const double bk_sum = d.sum_rewards[e];
   bool done = !act;
@@ -767,7 +769,6 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   for (int q = 0; q < 10; ++q) sm[(size_t)(q * Wt + t) * L] = part[q];
   __syncthreads();
   if (t != 0 || !valid) return;
-  d.adv_row[e] = -1;
   if (!act) {                                     // frozen env: terminated earlier in this episode
     reward[e] = 0.0; terminated[e] = 1;
     for (int c = 0; c < MAPDN_N_INFO; ++c) info[(size_t)e * MAPDN_N_INFO + c] = 0.0;
@@ -796,10 +797,8 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     inf[4] = tot[2] * inv_nb; inf[5] = tot[3] * inv_nb; inf[6] = tot[4]; inf[7] = tot[5];
     inf[8] = tot[7]; inf[9] = ql; inf[10] = 0.0;
     if (!ok) { rew -= 200.0; inf[10] = 1.0; inf[3] = 0.0; inf[9] = qf; }                 // :192-196
-    // ---- bookkeeping: next profile row uses t = steps BEFORE the increment (:199 vs :202)
+    // ---- bookkeeping (the next profile row was queued by k_inject from the pre-increment counters)
     const int st = bk_steps;
-    d.adv_row[e] = bk_start + st;
-    d.adv_draw[e] = bk_draw;
     d.draw[e] = bk_draw + 1;
     d.steps[e] = st + 1;
     d.sum_rewards[e] = bk_sum + rew;
