@@ -1,13 +1,12 @@
 // kernels.hip — gfx950 (MI355X, CDNA4) kernels of the batched VoltageControl hot path.
 //
-// Mapping: ONE LANE == ONE ENV.  All per-env state is "env-minor" SoA, X[item][Bp] (Bp = B rounded
-// up to 64), so the lanes of a wavefront touch consecutive doubles (one coalesced request) for
-// every item they process.  Because all envs share the topology, the elimination schedule, the Ybus
-// entries and every index are wave-uniform: they are read through the scalar cache and all branches
-// on them are scalar branches — no divergence.  Parallelism inside one env comes from W wavefronts
-// per env group that eliminate independent subtrees of the feeder concurrently and exchange the
-// few cross-subtree values through LDS slots; the LDS-tiled transposes convert between env-minor
-// state and env-major I/O tensors.
+// Layout: all per-env state is "env-minor" SoA, X[item][Bp] (Bp = B rounded up to 64), so the lanes that
+// serve consecutive envs touch consecutive doubles for every item they process; the LDS-tiled transposes
+// convert between env-minor state and env-major I/O tensors.  The wide kernels (inject, advance, gather) are
+// one thread per (item, env).  The NR kernel gives a workgroup L envs and splits each of its waves into
+// 64/L lane groups ("workers") that eliminate different nodes of the feeder tree for those envs at the same
+// time, following a host-built schedule whose per-step records sit in LDS together with the whole solve
+// state; see the block comment at K2-K5.
 //
 // What is computed follows pandapower 2.7.0's runpp (pypower newtonpf; reference call site
 // voltage_control_env.py:557) and MAPDN's VoltageControl methods cited at each kernel.
@@ -107,18 +106,20 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
 // K2-K5  Newton-Raphson power flow — pandapower/pypower/newtonpf.py (flat start, polar form, full
 //        Jacobian every iteration, ||F||inf < tol, <= 10 iterations), for a radial feeder.
 //
-//  Lane = env.  Per iteration:
+//  Per iteration:
 //   forward sweep over the feeder tree in leaf->root order, fusing
 //     * I = Ybus V and the mismatch F = V conj(I) - Sbus            (dSbus_dV / _evaluate_Fx)
 //     * the four Jacobian entries of every Ybus non-zero              (create_jacobian_matrix)
 //     * block-2x2 Gaussian elimination J y = F without fill          (replaces SuperLU spsolve)
 //   then, unless converged, a backward sweep (root->leaf) that back-substitutes and applies
 //   Va += dx_a, Vm += dx_m, V = Vm e^{jVa} with the abs/angle re-normalisation of newtonpf.
+//  The first forward sweep uses the host's factorisation of the flat-start Jacobian (the same for every
+//  env) and a sweep that is expected to find convergence first runs mismatch-only; see `first` / `light`.
 //
-//  Parallelism inside one env: the W wavefronts of a workgroup share the same L envs and follow a
-//  host-built Hu schedule (plan.cpp::build_schedule): in every row each wave eliminates one node of
-//  an independent subtree (or idles), so the critical path per sweep is ~tree depth instead of n.
-//  A wave may use only its first L lanes (64/32/16) so that small batches still cover many CUs.
+//  Parallelism: a workgroup = L envs x W wavefronts; each wavefront is split into 64/L lane groups
+//  ("workers": lane = worker * L + env) and the Wt = W * 64/L workers follow a host-built Hu schedule
+//  (plan.cpp::build_schedule): in every row each worker eliminates one node of an independent subtree
+//  (or idles) for its L envs, so the critical path per sweep is ~the tree radius instead of n.
 //
 //  Data movement (the solve state is kept ON CHIP; HBM sees one Sbus read, one solution write and
 //  the LU factors):
@@ -129,13 +130,14 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
 //     host with interval colouring; values stay in registers instead when the same worker handles
 //     the parent in the adjacent row.  Rows are separated by an LDS-only barrier when W > 1
 //     (s_waitcnt lgkmcnt(0); s_barrier) and by nothing at all when one wave holds all workers.
-//   * only the LU factors h, G (6 doubles per node) go to global scratch: every (worker,row) step
-//     owns one FACTOR BLOCK addressed as block(worker,row) + field through one buffer resource
-//     (scalar row offset, loop-invariant lane VGPR offsets); the backward sweep prefetches them two
-//     rows ahead.  Every step issues the same VMEM instructions, so vmcnt waits are exact.
+//   * only the LU factors G (4 doubles per node; with h, 6, when h does not fit in LDS) go to global
+//     scratch: every (worker,row) step owns one FACTOR BLOCK addressed as block(worker,row) + field through
+//     one buffer resource (scalar row offset, loop-invariant lane VGPR offsets); the backward sweep
+//     prefetches them two rows ahead.  Every step issues the same VMEM instructions (prefetches past the
+//     ends are clamped, never skipped), so vmcnt waits are exact.
 //   * step constants (Y entries, flags, slot ids) are 96-byte records staged once in LDS.
-//   * |V| and angle are formed once at the end (Vm = |V|, Va = angle(V) as newtonpf) and written
-//     with e,f to the Vout region for the commit kernel.
+//   * the solution (e, f) goes to the Vout region; |V| and angle are formed once, by the commit part of
+//     k_advance (Vm = |V|, Va = angle(V) as newtonpf) — or here, in mapdn_solve_only's MODE_SOLVE.
 //  The linear system is solved for z = [dtheta ; d|V|/|V|] (|V| columns scaled by |V_k|): the
 //  entries are j(S - A_kk), S + A_kk on the diagonal and -jA_ik, A_ik off it — no division by |V|;
 //  1/det uses v_rcp_f64 + two Newton steps; the update rotates V by the small step angle
