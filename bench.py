@@ -182,7 +182,7 @@ def main():
                          "algorithmic_bytes_per_env_step": bytes_step, "envs_per_launch": B,
                          "kernel_avg_ms": nr_avg_s * 1e3, "kernel_launches_timed": nr_launches},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.case, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     env.close()
