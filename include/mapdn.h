@@ -188,6 +188,12 @@ int mapdn_get_obs_index(const mapdn_handle* h, int32_t* kind, int32_t* index);
  * (n = n_bus-1 means the slack).  Call with rows == NULL to query *n_rows first. */
 int mapdn_get_schedule(const mapdn_handle* h, int32_t n_waves, int32_t* n_rows, int32_t* rows, int32_t* parent);
 
+/* Host-side export of the flat-start factorisation the NR kernel's first iteration uses (plan check, CPU tests):
+ * factors [n][12] per elimination position = S_calc (re, im), D^-1 (4, row-major), A_pk (re, im), G (4, row-major)
+ * of the block LU of the Jacobian at V = ext_grid vm_pu everywhere, unknowns [dtheta, d|V|/|V|];
+ * bus_of_pos [n+1] (optional) = bus id of every elimination position (position n is the slack). */
+int mapdn_get_flat_factors(const mapdn_handle* h, double* factors, int32_t* bus_of_pos);
+
 /* counters (host, synchronises the given stream): number of envs whose last reset exhausted
  * max_tries; mean / max NR iterations of the last solve */
 int mapdn_stats(mapdn_handle* h, int64_t* reset_failures, double* mean_iters, int32_t* max_iters,

@@ -488,6 +488,19 @@ int mapdn_get_obs_index(const mapdn_handle* h, int32_t* kind, int32_t* index) {
   return MAPDN_OK;
 }
 
+int mapdn_get_flat_factors(const mapdn_handle* h, double* factors, int32_t* bus_of_pos) {
+  if (!h || !factors) return MAPDN_E_INVALID;
+  Schedule S;
+  build_schedule(h->plan, 1, S);                 // one worker: row r of the schedule is one node
+  const int n = h->plan.n;
+  for (int r = 0; r < S.R; ++r) {
+    const StepRec& T = S.steps[(size_t)r];
+    if (T.flags & S_LIVE) std::memcpy(factors + (size_t)T.k * FLAT_N, &S.flat[(size_t)r * FLAT_N], FLAT_N * sizeof(double));
+  }
+  if (bus_of_pos) std::memcpy(bus_of_pos, h->plan.bus_of_pos.data(), (size_t)(n + 1) * sizeof(int32_t));
+  return MAPDN_OK;
+}
+
 int mapdn_get_schedule(const mapdn_handle* h, int32_t W, int32_t* n_rows, int32_t* rows, int32_t* parent) {
   if (!h || !n_rows || W < 1 || W > 16) return MAPDN_E_INVALID;
   Schedule S;

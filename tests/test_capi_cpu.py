@@ -167,3 +167,46 @@ def test_nr_schedule_is_a_valid_tree_elimination(lib, case, W):
     if W == 1:
         assert R == n
     lib.mapdn_destroy(h)
+
+
+@pytest.mark.parametrize("case", ["case33", "case141", "case322"])
+def test_flat_start_factorisation_is_the_first_newton_step(lib, case):
+    """plan.cpp factorises the flat-start Jacobian once per topology (the NR kernel's first iteration only
+    substitutes the right-hand side).  Replaying that substitution on the host with the exported constants
+    must give the oracle's first Newton step dx = -J(V0)^-1 F(V0) for an arbitrary Sbus."""
+    from scipy.sparse.linalg import spsolve
+    from oracle.pp_restated import make_ybus, bus_demand, make_sbus, jacobian, _fx
+    net, prof = make_case(case)
+    rc, h = host_handle(lib, net)
+    assert rc == 0
+    nb, n = net.n_bus, net.n_bus - 1
+    fac = np.zeros((n, 12)); bop = np.zeros(n + 1, np.int32); par = np.zeros(n, np.int32)
+    assert lib.mapdn_get_flat_factors(h, _lib._p(fac, _lib._pd), _lib._p(bop, _lib._pi)) == 0
+    assert lib.mapdn_get_schedule(h, 1, C.byref(C.c_int32()), None, _lib._p(par, _lib._pi)) == 0
+    assert bop[n] == net.ext_grid_bus and sorted(bop.tolist()) == list(range(nb))
+    rng = np.random.default_rng(1)
+    row = int(rng.integers(0, prof.n_rows))
+    pv = prof.pv[row]
+    q = rng.uniform(-0.6, 0.6, net.n_sgen) * np.sqrt(prof.s_max() ** 2 - pv ** 2)
+    sbus = make_sbus(net, *bus_demand(net, prof.load_p[row], prof.load_q[row], pv, q))
+    # ---- oracle: one Newton step from the flat start
+    ybus = make_ybus(net)[0]
+    pq = np.setdiff1d(np.arange(nb), [net.ext_grid_bus])
+    v0 = np.full(nb, net.ext_grid_vm_pu, dtype=np.complex128)
+    dx = -spsolve(jacobian(ybus, v0, pq, pq).tocsc(), _fx(ybus, v0, sbus, pq, pq))
+    dth = np.zeros(nb); dvm = np.zeros(nb)
+    dth[pq] = dx[:n]; dvm[pq] = dx[n:]
+    # ---- host replay of the kernel's flat sweep pair with the exported constants
+    S = fac[:, 0] + 1j * fac[:, 1]
+    Iinv = fac[:, 2:6].reshape(n, 2, 2); apk = fac[:, 6:8]; G = fac[:, 8:12].reshape(n, 2, 2)
+    hvec = np.zeros((n, 2)); acc = np.zeros((n + 1, 2)); x = np.zeros((n + 1, 2))
+    for k in range(n):                                            # children have smaller positions
+        F = S[k] - sbus[bop[k]]
+        hvec[k] = Iinv[k] @ (np.array([F.real, F.imag]) - acc[k])
+        ar, ai = apk[k]
+        acc[par[k]] += (ai * hvec[k, 0] + ar * hvec[k, 1], ai * hvec[k, 1] - ar * hvec[k, 0])
+    for k in range(n - 1, -1, -1):
+        x[k] = hvec[k] - G[k] @ (x[par[k]] if par[k] < n else np.zeros(2))
+    assert np.abs(-x[:n, 0] - dth[bop[:n]]).max() < 1e-10
+    assert np.abs(-x[:n, 1] * abs(v0[0]) - dvm[bop[:n]]).max() < 1e-10
+    lib.mapdn_destroy(h)
