@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 from ._lib import INFO_KEYS, N_INFO
-from .multiagentenv import MultiAgentEnv
+from .marl_env_api import MultiAgentEnv
 from .netspec import NetSpec, Profiles, make_case
 
 

@@ -210,3 +210,20 @@ def test_flat_start_factorisation_is_the_first_newton_step(lib, case):
     assert np.abs(-x[:n, 0] - dth[bop[:n]]).max() < 1e-10
     assert np.abs(-x[:n, 1] * abs(v0[0]) - dvm[bop[:n]]).max() < 1e-10
     lib.mapdn_destroy(h)
+
+
+def test_drop_in_class_covers_the_whole_env_protocol():
+    """every call of the PyMARL env protocol (environments/multiagentenv.py) is implemented by the drop-in
+    class, with the reference's positional arguments"""
+    import inspect
+    from mapdn_amd.env import VoltageControl
+    from mapdn_amd.marl_env_api import PROTOCOL, MultiAgentEnv
+    assert issubclass(VoltageControl, MultiAgentEnv)
+    for name, call in PROTOCOL.items():
+        fn = getattr(VoltageControl, name)
+        if call.required and name not in ("get_stats", "seed", "save_replay"):      # never called by MAPDN, absent in its env too
+            assert fn is not getattr(MultiAgentEnv, name), name
+        params = [p for p in inspect.signature(fn).parameters if p != "self"]
+        assert tuple(params[:len(call.args)]) == call.args or name == "render", (name, params)
+    with pytest.raises(NotImplementedError):
+        MultiAgentEnv().get_stats()
