@@ -227,3 +227,21 @@ def test_drop_in_class_covers_the_whole_env_protocol():
         assert tuple(params[:len(call.args)]) == call.args or name == "render", (name, params)
     with pytest.raises(NotImplementedError):
         MultiAgentEnv().get_stats()
+
+
+def test_header_is_plain_c_and_usable_from_a_c_host(lib, tmp_path):
+    """include/mapdn.h must be consumable by any FFI: compile examples/c_abi_host.c as strict C99 against it,
+    link the shared library and run it (host-only handle: no GPU involved)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_host")
+    libdir = os.path.join(root, "mapdn_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_abi_host.c"), "-o", exe, "-L" + libdir, "-lmapdn_hip",
+                    "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "n_bus 5" in out and "radial 1" in out and "n_agents 2" in out
+    assert "mapdn_reset on a host-only handle -> -4" in out
