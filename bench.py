@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 SCALE = {"case33": 0.8, "case141": 0.6, "case322": 0.8}     # reference train.py:34-42
 HBM_PEAK_GBS = 8000.0                                         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+FP64_PEAK_TFLOPS = 78.6                                       # MI355X f64 vector peak
 
 
 def algorithmic_bytes_per_env_step(env):
@@ -182,6 +183,12 @@ def main():
                          "algorithmic_bytes_per_env_step": bytes_step, "envs_per_launch": B,
                          "kernel_avg_ms": nr_avg_s * 1e3, "kernel_launches_timed": nr_launches},
         }
+        # compute-side view: ~184 * nb f64 flops per NR iteration (SpMV, mismatch, Jacobian,
+        # block-tree solve, update) x (iterations + 1 mismatch evaluation), against the f64 vector peak
+        flops_step = 184.0 * env.n_bus * (stats["mean_nr_iters"] + 1.0)
+        out["compute"] = {"algorithmic_flops_per_env_step": flops_step, "achieved_tflops": flops_step * B / nr_avg_s / 1e12,
+                          "peak_tflops": FP64_PEAK_TFLOPS, "frac": flops_step * B / nr_avg_s / 1e12 / FP64_PEAK_TFLOPS,
+                          "note": "f64 vector (no MFMA: the radial Jacobian is eliminated without fill, there is no dense contraction)"}
         if not a.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.case, a.cpu_seconds)
         print(json.dumps(out), flush=True)
