@@ -670,3 +670,42 @@ def test_convergence_prediction_is_only_a_shortcut(check_dx, monkeypatch):
     for e in (0, 1, 50):
         r = runpp_restated(net, pl[e], ql[e], pv[e], qs[e])
         assert r.iterations == it[e] and np.abs(vm[e] - r.vm_pu).max() < V_TOL
+
+
+def test_tester_records_match_the_oracle_env(tmp_path):
+    """PGTester.run (utilities/tester.py:19-63): same record keys / shapes as the reference, values equal to the
+    oracle env driven by the same greedy policy; batch_run aggregates the 11 info keys."""
+    import pickle
+    from mapdn_amd.learner import DDPGNet, make_alg_args
+    from mapdn_amd.tester import PGTester
+    torch.manual_seed(3)
+    case = "case33"
+    net, prof, env = make(case, 4, episode_limit=12)
+    args = make_alg_args(env.n_agents, env.obs_size, 1, SCALE[case], 0.0, max_steps=12)
+    pol = DDPGNet(args, "iddpg").to("cuda:0")
+    tester = PGTester(args, pol, env)
+    rec = tester.run(2, 11, 5)
+    assert set(rec) == {"pv_active", "pv_reactive", "bus_active", "bus_reactive", "bus_voltage", "line_loss"}
+    # reset leaves steps == 1 (voltage_control_env.py:100), so an episode_limit of 12 ends after 11 steps (:204)
+    assert all(len(v) == 12 for v in rec.values()) and rec["bus_voltage"][0].shape == (net.n_bus,)
+    # oracle env, same start, no noise, the actions the GPU run took (recomputed from the recorded sgen q is
+    # not possible before the clip, so drive the oracle with the same policy on its own observations)
+    o = VoltageControlOracle(net, prof, args_for(case, episode_limit=12), env_id=0, do_reset=False)   # same draw counter as the fresh GPU env
+    obs_list, _ = o.manual_reset(2, 11, 5)
+    hid = pol.init_hidden(1)
+    assert np.abs(o.res.vm_pu - rec["bus_voltage"][0]).max() < V_TOL
+    for t in range(11):
+        ob = torch.tensor(np.array(obs_list), dtype=torch.float32, device="cuda:0").unsqueeze(0)
+        with torch.no_grad():
+            a, _, _, _, hid = pol.get_actions(ob, "test", False, torch.ones(1, env.n_agents, 1, device="cuda:0"), False, hid)
+        actual = (a.squeeze().clamp(-1, 1) * SCALE[case]).cpu().numpy().astype(np.float64)
+        o.step(actual, add_noise=False)
+        obs_list = o.get_obs()
+        assert np.abs(o.res.vm_pu - rec["bus_voltage"][t + 1]).max() < 1e-6          # f32 policy on f32 obs: tiny action differences
+        assert np.abs(o.res.pl_mw - rec["line_loss"][t + 1]).max() < 1e-6
+    PGTester.save_record(rec, tmp_path / "rec.pickle")
+    assert set(pickle.load(open(tmp_path / "rec.pickle", "rb"))) == set(rec)
+    stat = tester.batch_run(8)
+    assert set(stat) == {"mean_test_" + k for k in INFO_KEYS} and all(len(v) == 2 for v in stat.values())
+    assert 0.0 <= stat["mean_test_totally_controllable_ratio"][0] <= 1.0
+    env.close()
