@@ -126,7 +126,9 @@ const char* mapdn_last_error(const mapdn_handle* h);
  *   MAPDN_NR_WAVES (1/2/4/8), MAPDN_NR_LANES (4/8/16/32)   waves and envs per NR workgroup
  *   MAPDN_NR_H_LDS, MAPDN_NR_LINE_LDS (0/1)                keep the h factors / net.line constants in LDS
  *   MAPDN_NR_CHECK_DX (default 1e-7)                       Newton-step size below which the next sweep is
- *                                                          first tried mismatch-only (never changes results) */
+ *                                                          first tried mismatch-only (never changes results)
+ *   MAPDN_NR_CHECK_QUAD (default 1)                        safety factor of the second predictor, ||F||^3/||F_prev||^2 < tol / factor
+ *                                                          ("inf" disables it) */
 int mapdn_create(const mapdn_netspec* net, const mapdn_env_config* cfg, int32_t n_envs,
                  int32_t device, mapdn_handle** out);
 void mapdn_destroy(mapdn_handle* h);

@@ -336,6 +336,8 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   const bool nothing_to_solve = __all(done);      // identical in all waves of the group
 
   bool allok;
+  double fmx;                                      // largest mismatch component seen by this worker in the current sweep
+  double Fprev = 0.0, Fcur = 0.0;                  // per env: ||F||inf of the two most recent accepted sweeps
   double cS0, cS1, cD0, cD1, cD2, cD3, cR0, cR1;   // register carry child -> parent (same worker, next row)
   double x0, x1;                                   // register carry parent -> child in the backward sweep
 
@@ -405,6 +407,7 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     const double sr = (akk_r + aks_r) + akp_r + aS0, si = (akk_i + aks_i) + akp_i + aS1;
     const double Fp = sr - o.sr, Fq = si - o.si;
     allok = allok && (!(fl & S_LIVE) || ((fabs(Fp) < tol) && (fabs(Fq) < tol)));
+    fmx = fmax(fmx, (fl & S_LIVE) ? fmax(fabs(Fp), fabs(Fq)) : 0.0);
     const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) - aD1;
     const double D2 = (sr - akk_r) - aD2, D3 = (si + akk_i) - aD3;
     const double r0 = Fp - aR0, r1 = Fq - aR1;
@@ -456,6 +459,7 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     const double sr = (akk_r + aks_r) + akp_r + aS0, si = (akk_i + aks_i) + akp_i + aS1;
     const double Fp = sr - o.sr, Fq = si - o.si;
     allok = allok && (!(fl & S_LIVE) || ((fabs(Fp) < tol) && (fabs(Fq) < tol)));
+    fmx = fmax(fmx, (fl & S_LIVE) ? fmax(fabs(Fp), fabs(Fq)) : 0.0);
     cS0 = apk_r; cS1 = apk_i;
     double* c = cs + (size_t)(T.slots & 1023u) * (8 * L);
     c[0] = apk_r; c[L] = apk_i;
@@ -480,6 +484,7 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     }
     const double Fp = q.sr - o.sr, Fq = q.si - o.si;
     allok = allok && (!(fl & S_LIVE) || ((fabs(Fp) < tol) && (fabs(Fq) < tol)));
+    fmx = fmax(fmx, (fl & S_LIVE) ? fmax(fabs(Fp), fabs(Fq)) : 0.0);
     const double r0 = Fp - aR0, r1 = Fq - aR1;
     const double h0 = q.i0 * r0 + q.i1 * r1, h1 = q.i2 * r0 + q.i3 * r1;
     const double t0 = q.api * h0 + q.apr * h1, t1 = q.api * h1 - q.apr * h0;
@@ -551,7 +556,7 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   bool first = true, light = false;
   while (!nothing_to_solve) {
     // ------------------------------------------------------------------ forward sweep
-    allok = true;
+    allok = true; fmx = 0.0;
     cS0 = cS1 = cD0 = cD1 = cD2 = cD3 = cR0 = cR1 = 0.0;
     if (first) {
       fwd_sweep_alt(std::integral_constant<int, 2>{});
@@ -584,8 +589,10 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     }
     {                                            // AND of the workers' verdicts, per env
       s_ok[t * L + el] = allok ? 1 : 0;
+      s_dx[(size_t)t * L] = fmx;                 // (free here: the step sizes it holds were consumed before this sweep)
       if (W > 1) lds_barrier();
-      for (unsigned tt = 0; tt < Wt; ++tt) allok = allok && (s_ok[tt * L + el] != 0);
+      fmx = 0.0;
+      for (unsigned tt = 0; tt < Wt; ++tt) { allok = allok && (s_ok[tt * L + el] != 0); fmx = fmax(fmx, s_dx[(size_t)tt * L]); }
     }
     if (light) {
       light = false;
@@ -594,6 +601,7 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
         continue;
       }
     }
+    Fprev = Fcur; Fcur = fmx;                    // this sweep stands (a redone mismatch-only sweep never gets here)
     if (!done) {
       conv = allok;
       if (conv || it == d.max_it) done = true;
@@ -641,7 +649,10 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
       if (W > 1) lds_barrier();
       double dxe = 0.0;
       for (unsigned tt = 0; tt < Wt; ++tt) dxe = fmax(dxe, s_dx[(size_t)tt * L]);
-      light = __all(done || dxe < d.nr_check_dx);
+      // convergence is predicted from a tiny step, or — scale-free — from quadratic convergence of the mismatch:
+      // ||F_next|| ~ ||F||^3 / ||F_prev||^2 (two sweeps of history needed)
+      const bool quad = it >= 2 && Fcur * Fcur * Fcur * d.nr_check_quad < tol * Fprev * Fprev;
+      light = __all(done || dxe < d.nr_check_dx || quad);
     }
   }
   if (t == 0) { d.iters[e] = it; d.conv[e] = conv ? 1 : 0; }

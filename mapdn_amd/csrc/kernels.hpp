@@ -60,6 +60,7 @@ struct Dev {
   // a Newton step whose largest component (|dtheta|, |d|V|/|V||) is below this predicts convergence: the next
   // forward sweep is first run in its mismatch-only form (k_nr_wtree)
   double nr_check_dx;
+  double nr_check_quad;      // safety factor of the quadratic-convergence predictor (inf disables it, tiny = always predict)
 };
 
 void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,

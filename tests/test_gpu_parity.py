@@ -661,6 +661,7 @@ def test_convergence_prediction_is_only_a_shortcut(check_dx, monkeypatch):
     vm0, va0, it0, cv0 = [x.cpu().numpy() for x in ref_env.solve(pl, ql, pv, qs)]
     ref_env.close()
     monkeypatch.setenv("MAPDN_NR_CHECK_DX", check_dx)
+    monkeypatch.setenv("MAPDN_NR_CHECK_QUAD", "1e-300" if check_dx == "1e30" else "inf")   # always / never for the second predictor too
     env = VoltageControlBatch(net, prof, args_for(case), n_envs=B, device="cuda:0")
     vm, va, it, cv = [x.cpu().numpy() for x in env.solve(pl, ql, pv, qs)]
     env.close()
