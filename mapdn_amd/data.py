@@ -34,15 +34,17 @@ def load_profiles_csv(data_path: str, pv_scale: float = 1.0, demand_scale: float
     return Profiles(pv=tabs[0][1], load_p=tabs[1][1], load_q=tabs[2][1], time_delta_min=int(time_delta), days=int(pv_days))
 
 
-def save_profiles_csv(prof: Profiles, data_path: str, start="2012-01-01 00:00:00") -> None:
-    """Write tables in the reference's CSV layout (used by tests and to export synthetic scenarios)."""
+def save_profiles_csv(prof: Profiles, data_path: str, start="2012-01-01 00:00:00", float_format="%.17g") -> None:
+    """Write tables in the reference's CSV layout (used by tests and to export synthetic scenarios).
+    %.17g text round-trips through `float_precision="round_trip"` (load_profiles_csv); pandas' default parser —
+    the one the reference uses (:412) — is exact only for <= 15 significant digits."""
     import pandas as pd
     os.makedirs(data_path, exist_ok=True)
     idx = pd.date_range(start=start, periods=prof.n_rows, freq=f"{prof.time_delta_min}min")
     for name, tab in zip(CSV_NAMES, (prof.pv, prof.load_p, prof.load_q)):
         df = pd.DataFrame(tab, columns=[str(i) for i in range(tab.shape[1])])
         df.insert(0, "time", idx.strftime("%Y-%m-%d %H:%M:%S"))
-        df.to_csv(os.path.join(data_path, name), index=False, float_format="%.17g")
+        df.to_csv(os.path.join(data_path, name), index=False, float_format=float_format)
 
 
 def save_netspec(net: NetSpec, path: str) -> None:

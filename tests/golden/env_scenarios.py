@@ -1,0 +1,44 @@
+"""Scenario list shared by tests/golden/make_env_golden.py (which runs the REFERENCE's own VoltageControl under the
+stub pandapower package of oracle/pp_stub) and by the tests that hold the oracle / the HIP path to its output."""
+import numpy as np
+
+BASE_ARGS = dict(voltage_barrier_type="l1", voltage_weight=1.0, q_weight=0.1, line_weight=None, dq_dv_weight=None,
+                 history=1, pv_scale=1.0, demand_scale=1.0,
+                 state_space=["pv", "demand", "reactive", "vm_pu", "va_degree"], v_upper=1.05, v_lower=0.95,
+                 episode_limit=240, action_scale=0.8, action_bias=0.0, mode="distributed", reset_action=False, seed=0)
+SCALE = {"case33": 0.8, "case141": 0.6, "case322": 0.8}
+
+# name -> (case, arg overrides, (day, hour, interval), n_steps, unsolvable_last_step, noisy)
+SCENARIOS = {
+    "c33_bowl": ("case33", dict(voltage_barrier_type="bowl"), (2, 11, 5), 12, True, False),
+    "c33_l1": ("case33", dict(voltage_barrier_type="l1"), (1, 13, 0), 4, False, False),
+    "c33_l2": ("case33", dict(voltage_barrier_type="l2"), (3, 9, 19), 4, False, False),
+    "c33_cb": ("case33", dict(voltage_barrier_type="courant_beltrami", v_upper=1.02, v_lower=0.99), (4, 12, 7), 4, False, False),
+    "c33_bump": ("case33", dict(voltage_barrier_type="bump"), (0, 0, 0), 4, False, False),
+    "c33_hist3": ("case33", dict(voltage_barrier_type="l1", history=3), (5, 10, 3), 5, False, False),
+    "c33_linew": ("case33", dict(voltage_barrier_type="bowl", line_weight=0.7, voltage_weight=2.5), (2, 15, 11), 4, True, False),
+    "c33_subset": ("case33", dict(voltage_barrier_type="l2", state_space=["pv", "vm_pu"]), (6, 14, 2), 3, False, False),
+    "c33_scaled": ("case33", dict(voltage_barrier_type="bowl", pv_scale=0.8, demand_scale=1.15, action_bias=0.1, action_scale=0.7), (2, 12, 9), 4, False, False),
+    "c33_noisy": ("case33", dict(voltage_barrier_type="bowl", reset_action=True, seed=7), (3, 12, 4), 6, False, True),
+    "c141_bowl": ("case141", dict(voltage_barrier_type="bowl", action_scale=0.6), (4, 12, 10), 8, True, False),
+}
+DIGITS = 12     # profile tables are quantised to this many significant digits so that every CSV parser reads them exactly
+
+
+def quantized_profiles(prof, pv_scale=1.0, demand_scale=1.0):
+    """Profiles whose entries are short decimals (exact under pandas' default CSV float parser, which is what the
+    reference uses at voltage_control_env.py:412), then scaled like :415,426,437."""
+    from mapdn_amd.netspec import Profiles
+
+    def q(a):
+        return np.array([float(f"%.{DIGITS}g" % v) for v in a.ravel()]).reshape(a.shape)
+    return Profiles(pv=q(prof.pv) * pv_scale, load_p=q(prof.load_p) * demand_scale, load_q=q(prof.load_q) * demand_scale,
+                    time_delta_min=prof.time_delta_min, days=prof.days)
+
+
+def actions_for(name, n_sgen, n_steps, unsolvable_last, scale, bias=0.0):
+    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31) if False else sum(map(ord, name)))
+    a = rng.uniform(bias - scale, bias + scale, (n_steps, n_sgen))
+    if unsolvable_last:
+        a[-1] = 60.0          # not clipped by the env (:553): q far beyond any solvable injection
+    return a
