@@ -134,7 +134,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   d.cur_q = d.gbuf + (size_t)r_q * Bp; d.vm = d.gbuf + (size_t)r_vm * Bp; d.va = d.gbuf + (size_t)r_va * Bp;
   d.res_p = d.gbuf + (size_t)r_rp * Bp; d.res_q = d.gbuf + (size_t)r_rq * Bp;
   AL(sum_rewards, 1); AL(steps, 1); AL(start_row, 1); AL(draw, 1); AL(done, 1); AL(pending, 1);
-  AL(active, 1); AL(commit, 1); AL(adv_row, 1); AL(adv_draw, 1); AL(iters, 1); AL(conv, 1);
+  AL(active, 1); AL(commit, 1); AL(bad_start, 1); AL(adv_row, 1); AL(adv_draw, 1); AL(iters, 1); AL(conv, 1);
   {
     std::vector<uint8_t> ones(Bp, 1);
     HIPCHK(h, hipMemcpy(d.done, ones.data(), Bp, hipMemcpyHostToDevice));   // nothing is steppable before reset

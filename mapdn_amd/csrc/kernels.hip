@@ -844,6 +844,11 @@ __global__ void __launch_bounds__(256) k_reset_begin(Dev d, const int64_t* __res
     const int64_t interval = (int64_t)(((uint64_t)x[2] * (uint64_t)d.per_hour) >> 32);   // :389
     start = interval + hour * d.per_hour + day * d.per_day;                              // :445
   }
+  // A start whose episode window leaves the table (the reference slices past the end and raises IndexError on the empty
+  // row, :446-447,473-475) never becomes steppable: not pending, stays done, counted as a reset failure by k_stats.
+  const bool bad = start < 0 || start + (int64_t)d.episode_limit + 1 >= d.T;
+  d.bad_start[e] = bad ? 1 : 0;
+  if (bad) { d.pending[e] = 0; d.start_row[e] = 0; return; }
   d.start_row[e] = start;
   d.adv_row[e] = start + 1;   // t = self.steps == 1 (:100, :473)
   d.adv_draw[e] = dr;
@@ -889,7 +894,7 @@ __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_pr
     return;
   }
   const int64_t row = d.adv_row[e];
-  if (row < 0) return;
+  if (row < 0 || row >= d.T) return;               // never read outside the table
   int b = blockIdx.y;                  // pair index over [pv pairs | load_p pairs | load_q pairs]
   const int npv = (d.ns + 1) >> 1, npl = (d.nl + 1) >> 1;
   int stream, count, col0;
@@ -1004,7 +1009,7 @@ __global__ void __launch_bounds__(256) k_stats(Dev d, long long* out) {
   __shared__ int s_max[256];
   long long pend = 0, sum = 0, cnt = 0; int mx = 0;
   for (int e = threadIdx.x; e < d.B; e += 256) {
-    pend += d.pending[e] ? 1 : 0;
+    pend += (d.pending[e] || d.bad_start[e]) ? 1 : 0;
     if (d.active[e]) { sum += d.iters[e]; cnt += 1; mx = max(mx, d.iters[e]); }
   }
   s_pend[threadIdx.x] = pend; s_sum[threadIdx.x] = sum; s_cnt[threadIdx.x] = cnt; s_max[threadIdx.x] = mx;

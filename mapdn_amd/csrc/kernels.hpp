@@ -48,7 +48,7 @@ struct Dev {
   double *pl;                                         // [n_line][Bp] res_line.pl_mw
   double *sum_rewards;                                // [Bp]
   int32_t* steps; int64_t* start_row; uint32_t* draw;
-  uint8_t *done, *pending, *active, *commit;
+  uint8_t *done, *pending, *active, *commit, *bad_start;
   int64_t* adv_row; uint32_t* adv_draw;
   // ---- NR scratch (see NB_* / VO_*): row offsets of the Sbus and Vout regions
   double* nrbuf; uint32_t nrbuf_bytes; uint32_t r_sbus, r_vout;

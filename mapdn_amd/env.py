@@ -167,17 +167,27 @@ class VoltageControlBatch:
         if start_rows is not None:
             sr = torch.as_tensor(start_rows, dtype=torch.int64, device=self.device).contiguous()
             assert sr.shape == (self.n_envs,)
+            # the episode window start+1 .. start+episode_limit must lie inside the table: the reference slices past the
+            # end and dies with IndexError on the empty row (:446-447, :473-475); the kernels also refuse such rows
+            lo, hi = int(sr.min()), int(sr.max())
+            if lo < 0 or hi + self.episode_limit + 1 >= self.profiles.n_rows:
+                raise IndexError(f"start row {lo if lo < 0 else hi}: the {self.episode_limit}-step episode window leaves the "
+                                 f"{self.profiles.n_rows}-row profile table")
         with torch.cuda.device(self.device):
             _lib.check(self._lib.mapdn_reset(self._h, sr.data_ptr() if sr is not None else None, int(add_noise),
                                              self.max_reset_tries, self._stream()), self._h)
         self._was_reset = True
         if self.history > 1:
-            self._obs_hist = []
+            self._obs_hist = None
         return self.get_obs(), self.get_state()
 
     def manual_reset(self, day, hour, interval):
         """manual_reset (voltage_control_env.py:137-176): same start for every env, no noise."""
-        row = self.profiles.start_row(int(day), int(hour), int(interval))
+        day, hour, interval = int(day), int(hour), int(interval)
+        if not (0 <= hour < 24 and 0 <= interval < self.profiles.intervals_per_hour and day >= 0):
+            raise ValueError(f"manual_reset(day={day}, hour={hour}, interval={interval}): need day >= 0, 0 <= hour < 24, "
+                             f"0 <= interval < {self.profiles.intervals_per_hour}")
+        row = self.profiles.start_row(day, hour, interval)
         return self.reset(start_rows=torch.full((self.n_envs,), row, dtype=torch.int64), add_noise=False)
 
     def step(self, actions, add_noise=True):
@@ -204,14 +214,20 @@ class VoltageControlBatch:
             buf = self._obs[dtype] = torch.empty(self.n_envs, self.n_agents, self._obs_size1, dtype=dtype, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.mapdn_get_obs(self._h, buf.data_ptr(), self._code(dtype), self._stream()), self._h)
-        if self.history > 1:                                        # :303-315
-            hist = self._obs_hist
-            frames = hist[-(self.history - 1):] + [buf.clone()]
-            pad = [torch.zeros_like(buf)] * (self.history - len(frames))
-            out = torch.cat(pad + frames, dim=-1)
-            hist.append(frames[-1])
-            del hist[:-self.history]
-            return out
+        if self.history > 1:                                        # :303-315: [zeros | older frames | newest]
+            o1, key = self._obs_size1, (dtype, "hist")
+            pair = self._obs.get(key)
+            if pair is None:                                        # two preallocated stacked frames, used alternately
+                pair = self._obs[key] = [torch.zeros(self.n_envs, self.n_agents, o1 * self.history, dtype=dtype, device=self.device)
+                                         for _ in range(2)]
+            if self._obs_hist is None:                              # first get_obs of the episode: no history yet
+                pair[0].zero_()
+                self._obs_hist = 0
+            cur, new = pair[self._obs_hist], pair[1 - self._obs_hist]
+            new[..., :-o1].copy_(cur[..., o1:])
+            new[..., -o1:].copy_(buf)
+            self._obs_hist = 1 - self._obs_hist
+            return self._out(new)
         return self._out(buf)
 
     def get_state(self, dtype=None):
@@ -246,17 +262,26 @@ class VoltageControlBatch:
                 "episode_limit": self.episode_limit}
 
     # ---- extras ---------------------------------------------------------------------------------
-    def results(self):
-        """tester getters (voltage_control_env.py:625-647) for the whole batch, float64."""
+    _RESULT_KEYS = ("vm_pu", "va_degree", "p_mw", "q_mvar", "pl_mw", "sgen_p", "sgen_q")
+
+    def results(self, keys=None):
+        """tester getters (voltage_control_env.py:625-647) for the whole batch, float64.  `keys`: subset of
+        vm_pu va_degree p_mw q_mvar pl_mw sgen_p sgen_q (default all); only those are transposed out."""
+        keys = self._RESULT_KEYS if keys is None else tuple(keys)
         B, dv, f64 = self.n_envs, self.device, torch.float64
-        out = dict(vm_pu=torch.empty(B, self.n_bus, dtype=f64, device=dv), va_degree=torch.empty(B, self.n_bus, dtype=f64, device=dv),
-                   p_mw=torch.empty(B, self.n_bus, dtype=f64, device=dv), q_mvar=torch.empty(B, self.n_bus, dtype=f64, device=dv),
-                   pl_mw=torch.empty(B, self.n_line, dtype=f64, device=dv), sgen_p=torch.empty(B, self.n_sgen, dtype=f64, device=dv),
-                   sgen_q=torch.empty(B, self.n_sgen, dtype=f64, device=dv))
+        width = dict(vm_pu=self.n_bus, va_degree=self.n_bus, p_mw=self.n_bus, q_mvar=self.n_bus, pl_mw=self.n_line,
+                     sgen_p=self.n_sgen, sgen_q=self.n_sgen)
+        out = {k: (torch.empty(B, width[k], dtype=f64, device=dv) if self.copy or B > 1 else self._res_buf(k, width[k])) for k in keys}
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.mapdn_get_results(self._h, *[out[k].data_ptr() for k in
-                       ("vm_pu", "va_degree", "p_mw", "q_mvar", "pl_mw", "sgen_p", "sgen_q")], self._stream()), self._h)
+            _lib.check(self._lib.mapdn_get_results(self._h, *[(out[k].data_ptr() if k in out else None) for k in self._RESULT_KEYS],
+                                                   self._stream()), self._h)
         return out
+
+    def _res_buf(self, k, w):
+        b = self._obs.get(("res", k))
+        if b is None:
+            b = self._obs[("res", k)] = torch.empty(self.n_envs, w, dtype=torch.float64, device=self.device)
+        return b
 
     def loads(self):
         lp = torch.empty(self.n_envs, self.n_load, dtype=torch.float64, device=self.device)
@@ -326,6 +351,10 @@ def _resolve_data(args):
     if name not in _SCENARIOS:
         raise FileNotFoundError(f"unknown scenario {name!r}: pass net=/profiles=, a directory with netspec.npz + the three "
                                 f"CSV tables, or a data_path ending in one of {sorted(_SCENARIOS)}")
+    import warnings
+    warnings.warn(f"data_path {dp!r} holds no netspec.npz / model.p: using the SYNTHETIC {_SCENARIOS[name]} feeder of the same shape "
+                  f"(mapdn_amd.netspec.make_case) — results are NOT comparable with runs on the real MAPDN data; pass "
+                  f"net=/profiles= or a scenario directory to silence this", RuntimeWarning, stacklevel=3)
     net, prof = make_case(_SCENARIOS[name], seed=0)
     if ps != 1.0 or ds != 1.0:
         prof = Profiles(pv=prof.pv * ps, load_p=prof.load_p * ds, load_q=prof.load_q * ds,
@@ -369,15 +398,25 @@ class VoltageControl(MultiAgentEnv):
         self.sum_rewards = 0
 
     def reset(self, reset_time=True):
+        """reset (:96-135): the reference re-draws until the start is solvable (`while not solvable`, :108); so does this
+        (the library tries `max_reset_tries` starts per call), giving up loudly after 100 calls instead of spinning forever."""
         self.steps = 1
         self.sum_rewards = 0
-        obs, state = self._b.reset(reset_time=reset_time)
-        return self._obs_list(obs), state[0].cpu().numpy()
+        for _ in range(100):
+            obs, state = self._b.reset(reset_time=reset_time)
+            if self._b.stats()["reset_failures"] == 0:
+                return self._obs_list(obs), state[0].cpu().numpy()
+            if not reset_time:
+                break
+        raise RuntimeError("reset(): no solvable start found (the reference would keep looping at voltage_control_env.py:108)")
 
     def manual_reset(self, day, hour, interval):
         self.steps = 1
         self.sum_rewards = 0
         obs, state = self._b.manual_reset(day, hour, interval)
+        if self._b.stats()["reset_failures"]:
+            # the reference loops forever here (:151-174: same start, no noise => same failure); fail loudly instead
+            raise RuntimeError("manual_reset(): the power flow of this start is not solvable")
         return self._obs_list(obs), state[0].cpu().numpy()
 
     def step(self, actions, add_noise=True):
@@ -428,7 +467,7 @@ class VoltageControl(MultiAgentEnv):
         return self.n_agents
 
     def _res(self, key):
-        return self._b.results()[key][0].cpu().numpy()
+        return self._b.results((key,))[key][0].cpu().numpy()
 
     def _get_voltage(self):
         return self._res("vm_pu")

@@ -438,8 +438,14 @@ class PGTrainer:
                 self.steps += 1
             alive = alive & ~done.bool()
             obs, last_hid = next_obs, hid
-            if t % 16 == 15 and not bool(alive.any()):          # the only host sync: once per 16 steps
-                break
+            if t % 16 == 15:                                    # the only host sync: once per 16 steps
+                flag = alive.any().to(torch.int32)
+                if self._dist is not None:                      # data-parallel ranks must agree: `steps` drives the update
+                    if self._dist.get_backend() != "nccl":      # schedule and every update is a collective
+                        flag = flag.cpu()
+                    self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX)
+                if not bool(flag):
+                    break
         denom = n_alive.clamp(min=1.0)
         for k, v in zip(INFO_KEYS, (info_sum / denom).tolist()):
             stat[prefix + k] = stat.get(prefix + k, 0.0) + v if not train else v

@@ -710,3 +710,49 @@ def test_tester_records_match_the_oracle_env(tmp_path):
     assert set(stat) == {"mean_test_" + k for k in INFO_KEYS} and all(len(v) == 2 for v in stat.values())
     assert 0.0 <= stat["mean_test_totally_controllable_ratio"][0] <= 1.0
     env.close()
+
+
+def test_start_rows_outside_the_table_are_refused():
+    """a late / negative start must not become an out-of-bounds profile read.  The Python class raises
+    (the reference dies with IndexError on the empty slice, :446-447,473-475); through the raw C ABI the kernels leave
+    such envs terminated and count them as reset failures."""
+    from mapdn_amd import _lib
+    net, prof, env = make("case33", 5)
+    T = prof.n_rows
+    for bad in (-1, T - 240, T + 5):
+        with pytest.raises(IndexError):
+            env.reset(start_rows=torch.tensor([100, 200, bad, 300, 400]))
+    with pytest.raises(ValueError):
+        env.manual_reset(1, 24, 0)
+    with pytest.raises(ValueError):
+        env.manual_reset(1, 3, 20)
+    # raw C ABI: no host check in the way
+    sr = torch.tensor([100, T - 100, 300, -7, 2 ** 40], dtype=torch.int64, device="cuda:0")
+    _lib.check(env._lib.mapdn_reset(env._h, sr.data_ptr(), 0, 2, env._stream()), env._h)
+    env._was_reset = True
+    assert env.stats()["reset_failures"] == 3
+    act = torch.zeros(5, net.n_sgen, dtype=torch.float64, device="cuda:0")
+    r, term, info = env.step(act, add_noise=False)
+    assert term.cpu().tolist() == [False, True, False, True, True] and r[1].item() == 0.0 and r[3].item() == 0.0
+    o = VoltageControlOracle(net, prof, args_for("case33", reset_action=True), env_id=0, do_reset=False)
+    assert np.isfinite(env.get_obs().cpu().numpy()).all()
+    env.close()
+
+
+def test_history_frames_do_not_allocate_and_match_oracle():
+    net, prof, env = make("case33", 3, history=3, voltage_barrier_type="l1")
+    o = VoltageControlOracle(net, prof, args_for("case33", history=3, voltage_barrier_type="l1"), env_id=1, do_reset=False)
+    obs, _ = env.manual_reset(2, 10, 1)
+    oo, _ = o.manual_reset(2, 10, 1)
+    assert np.abs(np.array(oo) - obs[1].cpu().numpy()).max() < 1e-9
+    ptrs = set()
+    rng = np.random.default_rng(5)
+    for t in range(6):
+        a = rng.uniform(-0.8, 0.8, net.n_sgen)
+        env.step(torch.as_tensor(np.tile(a, (3, 1)), device="cuda:0"), add_noise=False)
+        o.step(a, add_noise=False)
+        ob = env.get_obs()
+        ptrs.add(ob.data_ptr())
+        assert np.abs(np.array(o.get_obs()) - ob[1].cpu().numpy()).max() < 1e-9
+    assert len(ptrs) <= 2                         # two preallocated stacked frames, no per-call allocation
+    env.close()
