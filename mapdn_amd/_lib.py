@@ -98,7 +98,7 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} not found and could not be built ({exc}); build it with "
                 "`python -m mapdn_amd.build` (hipcc --offload-arch=gfx950); there is no CPU fallback") from exc
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(os.environ.get("MAPDN_LIB_PATH", LIB_PATH))      # override: A/B experiments with debug builds only
     vp = C.c_void_p
     lib.mapdn_last_error.restype = C.c_char_p
     lib.mapdn_last_error.argtypes = [vp]

@@ -26,6 +26,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = LIB + f".tmp{os.getpid()}"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-o", tmp]
+    cmd += os.environ.get("MAPDN_EXTRA_FLAGS", "").split()        # debug builds only (e.g. -DMAPDN_NR_STAMPS)
     # .cpp host files are compiled as plain C++ by hipcc; .hip as HIP
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

@@ -22,6 +22,7 @@ struct mapdn_handle {
   std::string err;
   std::vector<void*> allocs;
   bool have_profiles = false, was_reset = false, host_only = false;
+  size_t lds_bytes = 0;
   int32_t *obs_rows = nullptr, *state_rows = nullptr, *iota_idx = nullptr, *vm_row = nullptr, *va_row = nullptr;
   int32_t *obs_xptr = nullptr, *obs_xrow = nullptr;
   double *obs_scale = nullptr, *state_scale = nullptr;
@@ -193,22 +194,29 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   choose_nr_geometry(d.Bp, P.n, W, L);
   if (const char* s = getenv("MAPDN_NR_WAVES")) W = atoi(s);
   if (const char* s = getenv("MAPDN_NR_LANES")) L = atoi(s);
-  if (!(W == 1 || W == 2 || W == 4 || W == 8) || !(L == 32 || L == 16 || L == 8 || L == 4)) {
-    h->err = "MAPDN_NR_WAVES must be 1/2/4/8 and MAPDN_NR_LANES 32/16/8/4"; return MAPDN_E_INVALID; }
+  if (!(W == 1 || W == 2 || W == 4 || W == 8) || !(L == 32 || L == 16 || L == 8)) {
+    h->err = "MAPDN_NR_WAVES must be 1/2/4/8 and MAPDN_NR_LANES 32/16/8"; return MAPDN_E_INVALID; }
+  if (P.n + 1 > 0xffff) { h->err = "networks with more than 65534 buses are not supported (16-bit node positions in the NR step records)"; return MAPDN_E_INVALID; }
   const int Wt = W * (64 / L);
-  build_schedule(P, Wt, h->sched, nr_min_cslots(W, L));
+  build_schedule(P, Wt, h->sched, nr_min_cslots(W, L), 64 / L);
   if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
   const int ncl = (int)h->sched.clist.size();
-  // h factors in LDS too when the workgroup still fits in one CU's 160 KB (then only G goes to global scratch)
-  // optional LDS residents, in order of benefit: the net.line constants of the fused res_line epilogue, then the h factors
-  auto lds_for = [&](int hl, int ll) { return nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, h->sched.R, ncl, hl, ll ? P.n_line : 0); };
-  int line_lds = (P.n_line > 0 && lds_for(0, 1) <= 160 * 1024) ? 1 : 0;
-  if (const char* s = getenv("MAPDN_NR_LINE_LDS")) line_lds = (atoi(s) && P.n_line > 0) ? 1 : 0;
-  int h_lds = lds_for(1, line_lds) <= 160 * 1024 ? 1 : 0;
+  if (ncl > 4095) { h->err = "NR schedule: more than 4095 overflow children (junctions with > 3 non-chain children)"; return MAPDN_E_INVALID; }
+  // Optional LDS residents, in order of benefit: the h factors, the net.line constants of the fused res_line epilogue,
+  // then the G factors (with all three the solve state never leaves the chip; what does not fit goes to L2-resident
+  // global scratch, read back by the worker that wrote it)
+  auto lds_for = [&](int hl, int gl, int ll) { return nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, ncl, hl, gl, ll ? P.n_line : 0); };
+  const size_t LDS_MAX = 160 * 1024;
+  int h_lds = lds_for(1, 0, 0) <= LDS_MAX ? 1 : 0;
   if (const char* s = getenv("MAPDN_NR_H_LDS")) h_lds = atoi(s) ? 1 : 0;
-  const size_t lds_need = lds_for(h_lds, line_lds);
-  if (lds_need > 160 * 1024) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
-  d.nr_waves = W; d.nr_lanes = L; d.nr_h_lds = h_lds; d.nr_line_lds = line_lds;
+  int line_lds = (P.n_line > 0 && lds_for(h_lds, 0, 1) <= LDS_MAX) ? 1 : 0;
+  if (const char* s = getenv("MAPDN_NR_LINE_LDS")) line_lds = (atoi(s) && P.n_line > 0) ? 1 : 0;
+  int g_lds = (h_lds && lds_for(1, 1, line_lds) <= LDS_MAX) ? 1 : 0;
+  if (const char* s = getenv("MAPDN_NR_G_LDS")) g_lds = (atoi(s) && h_lds) ? 1 : 0;
+  const size_t lds_need = lds_for(h_lds, g_lds, line_lds);
+  if (lds_need > LDS_MAX) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
+  d.nr_waves = W; d.nr_lanes = L; d.nr_h_lds = h_lds; d.nr_g_lds = g_lds; d.nr_line_lds = line_lds;
+  h->lds_bytes = lds_need;
   // 1e-7: with quadratic convergence the mismatch after such a step is ~|Y| dx^2 << tol, so a wrong prediction
   // (which costs one extra mismatch-only sweep for that workgroup) practically never happens
   d.nr_check_dx = 1e-7;
@@ -221,20 +229,26 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   {
     // the attribute is per kernel function, not per handle: always raise it to the full 160 KB so that
     // handles with different LDS needs can share an instantiation
-    const int lr = nr_set_lds_limit(W, L, h_lds, 160 * 1024);
+    const int lr = nr_set_lds_limit(W, L, h_lds, g_lds, LDS_MAX);
     if (lr == -2) { h->err = "this (MAPDN_NR_WAVES, MAPDN_NR_LANES) combination is not compiled in"; return MAPDN_E_INVALID; }
     if (lr != 0) { h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return MAPDN_E_HIP; }
   }
-  UP(sched, h->sched.steps); UP(clist, h->sched.clist);
+  UP(sched, h->sched.steps); d.sched_bytes = (uint32_t)(h->sched.steps.size() * sizeof(StepRec));
+  UP(clist, h->sched.clist);
   UP(flat, h->sched.flat); d.flat_bytes = (uint32_t)(h->sched.flat.size() * sizeof(double));
-  {  // NR scratch: factor blocks (one per (worker,row) step) | Sbus | Vout; a single buffer resource addresses it
-    const int nblk = Wt * h->sched.R;
-    d.r_sbus = (uint32_t)nblk * NBF;
-    d.r_vout = d.r_sbus + 2u * (uint32_t)P.n;
-    const size_t rows = (size_t)d.r_vout + (size_t)VOF * (P.n + 1), bytes = rows * Bp * sizeof(double);
+  {  // NR scratch: factor blocks (one per (worker,row) step) | Sbus (schedule order) | Vout; a single buffer resource addresses it
+    const size_t nblk = (size_t)Wt * h->sched.R;
+    const size_t fb_rows = (h_lds && g_lds) ? 0 : nblk * NBP;                 // pair rows of Bp x 16 bytes
+    const size_t sb_off = fb_rows * Bp * 16;
+    const size_t vout_off = sb_off + nblk * Bp * 16;
+    const size_t bytes = vout_off + (size_t)VOF * (P.n + 1) * Bp * sizeof(double);
     if (bytes >= (size_t)0xFFFFFFFFu) { h->err = "env batch too large: NR scratch exceeds the 4 GiB one buffer resource addresses; use fewer envs per handle"; return MAPDN_E_INVALID; }
-    rc = dalloc(h, &d.nrbuf, rows * Bp); if (rc) return rc;
+    rc = dalloc(h, &d.nrbuf, bytes / sizeof(double)); if (rc) return rc;
     d.nrbuf_bytes = (uint32_t)bytes;
+    d.sb_off = (uint32_t)sb_off;
+    d.r_vout = (uint32_t)(vout_off / (Bp * sizeof(double)));
+    std::vector<int32_t> sbi(h->sched.step_of_node.begin(), h->sched.step_of_node.begin() + P.n);
+    UP(sb_index, sbi);
     std::vector<double> row(Bp, d.vroot);   // slack entry of Vout: V = vroot + 0j (angle 0 from the memset)
     double* rootv = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * P.n) * Bp;
     HIPCHK(h, hipMemcpy(rootv + (size_t)VO_E * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
@@ -499,7 +513,7 @@ int mapdn_get_flat_factors(const mapdn_handle* h, double* factors, int32_t* bus_
   const int n = h->plan.n;
   for (int r = 0; r < S.R; ++r) {
     const StepRec& T = S.steps[(size_t)r];
-    if (T.flags & S_LIVE) std::memcpy(factors + (size_t)T.k * FLAT_N, &S.flat[(size_t)r * FLAT_N], FLAT_N * sizeof(double));
+    if (T.flags & S_LIVE) std::memcpy(factors + (size_t)(T.kp & 0xffffu) * FLAT_N, &S.flat[(size_t)r * FLAT_N], FLAT_N * sizeof(double));
   }
   if (bus_of_pos) std::memcpy(bus_of_pos, h->plan.bus_of_pos.data(), (size_t)(n + 1) * sizeof(int32_t));
   return MAPDN_OK;
@@ -510,7 +524,7 @@ int mapdn_get_schedule(const mapdn_handle* h, int32_t W, int32_t* n_rows, int32_
   Schedule S;
   build_schedule(h->plan, W, S);
   *n_rows = S.R;
-  if (rows) for (size_t i = 0; i < S.steps.size(); ++i) rows[i] = (S.steps[i].flags & S_LIVE) ? S.steps[i].k : -1;
+  if (rows) for (size_t i = 0; i < S.steps.size(); ++i) rows[i] = (S.steps[i].flags & S_LIVE) ? (int32_t)(S.steps[i].kp & 0xffffu) : -1;
   if (parent) std::memcpy(parent, h->plan.par.data(), h->plan.par.size() * sizeof(int32_t));
   return MAPDN_OK;
 }

@@ -95,10 +95,9 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
     }
     P -= p; Q -= q;
   }
-  if (k < d.n) {
-    double* sb = d.nrbuf + ((size_t)d.r_sbus + 2 * (size_t)k) * d.Bp + e;
-    sb[0] = -P / d.sn;
-    sb[d.Bp] = -Q / d.sn;
+  if (k < d.n) {   // scheduled injection as an (re, im) pair, stored in the order the NR workers consume it
+    double2* sb = (double2*)((char*)d.nrbuf + d.sb_off) + (size_t)d.sb_index[k] * d.Bp + e;
+    *sb = make_double2(-P / d.sn, -Q / d.sn);
   }
 }
 
@@ -167,11 +166,31 @@ __device__ __forceinline__ double barrier(int type, double v) {
   }
 }
 
-struct FwdOps { double ek, fk, ep, fp, sr, si; };
-struct BwdOps { double h0, h1, g0, g1, g2, g3; };
-struct FlatOps { double sr, si, i0, i1, i2, i3, apr, api; };   // first eight fields of a Schedule::flat step
+#ifdef MAPDN_NR_STAMPS
+// debug build only (-DMAPDN_NR_STAMPS): cycle stamps of workgroup 0 / wave 0 at phase and row boundaries
+__device__ unsigned long long g_stamps[4096];
+#define STAMP(id) do { if (stamp_on && ns < 4095) g_stamps[++ns] = ((unsigned long long)(id) << 48) | (__builtin_readcyclecounter() & 0xffffffffffffull); } while (0)
+#ifdef MAPDN_NR_STAMPS_FINE
+#define STAMP2(id) STAMP(id)
+#else
+#define STAMP2(id) do { } while (0)
+#endif
+#else
+#define STAMP(id) do { } while (0)
+#define STAMP2(id) do { } while (0)
+#endif
 
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef MAPDN_EXP
+#define MAPDN_EXP 0      // debug experiments only (timing A/B builds); 0 in the product
+#endif
 __device__ __forceinline__ void lds_barrier() {
+#if (MAPDN_EXP & 4)
+  return;
+#endif
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -209,23 +228,29 @@ __device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
   *c = fma(pc, z, 1.0);
 }
 
-// buffer_load_dwordx2 v, v_lane_field, s[rsrc], s_block offen : zero VALU address math
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+// buffer_load/store_dwordx4 v, v_lane_offset, s[rsrc], s_row_offset offen : zero VALU address math
+__device__ __forceinline__ d2 bld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-__device__ __forceinline__ void bst(double x, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, voff, soff, 0);
+__device__ __forceinline__ u32x4 bldu4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+__device__ __forceinline__ void bst2(d2 x, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), r, voff, soff, 0);
 }
 
-template <int W, int L, bool HL>   // HL: the h factors live in LDS as well (when they fit), only G goes to global scratch
+struct Rec { u32x4 ix; d2 ykk, ykp, ypk, cks, sb; };    // per-(worker,row) constants + the env's scheduled injection
+struct RecF { u32x4 ix; d2 s, i01, i23, ap, sb; };      // flat-start form: host-factorised constants (Schedule::flat)
+struct BwdF { d2 h, g01, g23; };                        // factors of one step when they come from global memory
+
+template <int W, int L, bool HL, bool GL>   // HL / GL: the h / G factors live in LDS (when they fit) instead of global scratch
 __global__ void __launch_bounds__(64 * W)
-k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ terminated, double* __restrict__ info) {
-  extern __shared__ double lds[];
+k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ terminated, double* __restrict__ info) {
+  extern __shared__ d2 lds2[];
   // worker = (wave w, lane group s): S = 64/L sub-workers per wave, each serving the same L envs of
-  // this workgroup but eliminating a DIFFERENT node per row.  Per-lane step records; the step body
-  // is branch-free (zero / trash slots instead of predicated LDS traffic), so one wave instruction
-  // does S nodes' worth of work and the compiler can issue every LDS read of a row up front.
+  // this workgroup but eliminating a DIFFERENT node per row.  The step body is branch-free per lane (zero / trash
+  // slots instead of predicated LDS traffic); whole groups of LDS instructions that would only move zeros or
+  // trash for every worker of the wave are skipped on the wave-uniform hints the host put into the records.
   constexpr unsigned S = 64u / L, Wt = (unsigned)W * S;
   const unsigned lane = threadIdx.x & 63u;
   const unsigned w = threadIdx.x >> 6;
@@ -236,65 +261,39 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   const unsigned n = (unsigned)d.n;
   const double vroot = d.vroot, tol = d.tol;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d.nrbuf, 0, d.nrbuf_bytes, 0x00020000);
-  const unsigned rb = (unsigned)d.Bp * 8u;       // bytes per row
-  const unsigned bb = (unsigned)NBF * rb;        // bytes per factor block
   const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(d.flat), 0, d.flat_bytes, 0x00020000);
-  constexpr unsigned FB = (unsigned)FLAT_N * 8u; // bytes per flat-start step
-  const unsigned voF = t * (unsigned)R * FB;     // this worker's flat-start steps (same address for its L lanes)
-  unsigned vo[NBF];                              // env + field + worker offsets (loop-invariant VGPRs)
-#pragma unroll
-  for (int f = 0; f < NBF; ++f) vo[f] = e * 8u + (unsigned)f * rb + t * (unsigned)R * bb;
-  // LDS map (doubles, each x L envs): [V (n+2) x 2][Sbus (n+2) x 2][contribution slots x 8][x slots x 2][h (n+2) x 2 if HL]
-  //          then [verdict bytes 64*W][step sizes 64*W doubles][schedule Wt*R*96 B][overflow child list][net.line constants];
-  //          node n = slack, n+1 = trash
-  double* sV = lds + el;                                    // sV[(2k + c)*L]
-  double* sS = sV + (size_t)2 * (n + 2) * L;                // sS[(2k + c)*L]
-  double* cs = sS + (size_t)2 * (n + 2) * L;                // cs[(slot*8 + item)*L]
-  double* xs = cs + (size_t)d.nr_cslots * 8 * L;            // xs[(slot*2 + item)*L]
-  double* sH = xs + (size_t)d.nr_xslots * 2 * L;            // sH[(2k + c)*L]  (HL only; n+2 nodes)
-  uint8_t* s_ok = (uint8_t*)(sH - el + (HL ? (size_t)2 * (n + 2) * L : 0));   // [Wt][L], Wt*L = 64*W
-  double* s_dx = (double*)(s_ok + 64 * W) + el;             // step-size partials: s_dx[worker*L], 64*W doubles
-  double* s_epi = cs;                                       // epilogue partials s_epi[(q*Wt + worker)*L], 10*64*W doubles: they re-use the
-                                                            // contribution slots, dead once the solve is over (host: cslots >= nr_min_cslots)
-  StepRec* s_sched = (StepRec*)(s_ok + 64 * W + 64 * W * sizeof(double));   // 16-byte aligned: all sizes above are multiples of 64
-  int32_t* s_clist = (int32_t*)(s_sched + (size_t)Wt * R);
+  const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<StepRec*>(d.sched), 0, d.sched_bytes, 0x00020000);
+  const unsigned pb = (unsigned)d.Bp * 16u;      // bytes per pair row (one d2 per env)
+  constexpr unsigned TB = (unsigned)sizeof(StepRec);        // bytes per step record
+  constexpr unsigned FB = (unsigned)FLAT_N * 8u;            // bytes per flat-start step
+  const unsigned bb = (unsigned)NBP * pb;        // bytes per factor block
+  const unsigned voT = t * (unsigned)R * TB;     // this worker's records (same address for its L lanes)
+  const unsigned voF = t * (unsigned)R * FB;     // this worker's flat-start steps
+  const unsigned voB = e * 16u + t * (unsigned)R * bb;                 // factor blocks: + field * pb, scalar row offset
+  const unsigned voS = d.sb_off + e * 16u + t * (unsigned)R * pb;      // scheduled injection, in schedule order: scalar row offset
+  // LDS map, in pair rows (L x 16 bytes: one d2 per env; a worker's 16 lanes read 256 contiguous bytes with one
+  // conflict-free ds_read_b128):  V [n+2] | h [n+2] if HL | G [2(n+2)] if GL | contribution slots x 4 | x slots x 1
+  //   then verdict bytes [64 W], step sizes [64 W doubles], overflow child list, net.line constants (when they fit)
+  // node n = slack, n+1 = trash
+  d2* sV = lds2 + el;                                        // sV[k*L] = (e, f)
+  d2* sH = sV + (size_t)(n + 2) * L;                         // sH[k*L] = (h0, h1)
+  d2* sG = sH + (HL ? (size_t)(n + 2) * L : 0);              // sG[(2k+j)*L] = (G0,G1), (G2,G3)
+  d2* cs = sG + (GL ? (size_t)2 * (n + 2) * L : 0);          // cs[(slot*4 + j)*L] = (S0,S1) (D0,D1) (D2,D3) (R0,R1)
+  d2* xs = cs + (size_t)d.nr_cslots * 4 * L;                 // xs[slot*L] = (x0, x1)
+  uint8_t* s_ok = (uint8_t*)(xs - el + (size_t)d.nr_xslots * L);   // [Wt][L], Wt*L = 64*W
+  double* s_dx = (double*)(s_ok + 64 * W) + el;              // step-size partials: s_dx[worker*L], 64*W doubles
+  double* s_epi = (double*)(cs - el) + el;                   // epilogue partials s_epi[(q*Wt + worker)*L], 10*64*W doubles: they re-use the
+                                                             // contribution slots, dead once the solve is over (host: cslots >= nr_min_cslots)
+  int32_t* s_clist = (int32_t*)(s_ok + 64 * W + 64 * W * sizeof(double));
   double* s_lines = (double*)(s_clist + ((d.nr_nclist + 3) & ~3));   // LineFlow rows of net.line (9 doubles each) when d.nr_line_lds
-  {  // stage the step records (and the overflow child list) in LDS
-    // Global -> LDS staging in batches: the loads of a batch are unconditional (index clamped) and issued
-    // back to back, only the LDS stores are predicated — a load-per-iteration loop would pay the full
-    // memory latency once per element with one or two waves per SIMD.
-    const uint4* src = (const uint4*)d.sched;
-    uint4* dst = (uint4*)s_sched;
-    const unsigned n4 = 6u * Wt * (unsigned)R, n2 = 2u * n;
-    // Sbus of this workgroup's envs -> LDS; flat start (runpp init="auto": every bus at the slack set-point)
-    const double* gS = d.nrbuf + (size_t)d.r_sbus * d.Bp + e;
-    constexpr unsigned RC = 8, SC = 20;
-    {                                            // first batch of both streams in flight together
-      double sv[SC];
-      const unsigned q = threadIdx.x, qs = 64u * W;   // named registers: an indexed uint4 array is not promoted out of scratch
-      const uint4 r0 = src[min(q, n4 - 1)], r1 = src[min(q + qs, n4 - 1)], r2 = src[min(q + 2 * qs, n4 - 1)],
-                  r3 = src[min(q + 3 * qs, n4 - 1)], r4 = src[min(q + 4 * qs, n4 - 1)], r5 = src[min(q + 5 * qs, n4 - 1)],
-                  r6 = src[min(q + 6 * qs, n4 - 1)], r7 = src[min(q + 7 * qs, n4 - 1)];
+  {  // LDS init: flat start (runpp init="auto": every bus at the slack set-point), ZERO slots, small tables
+    const d2 v0 = {vroot, 0.0}, z2 = {0.0, 0.0};
+    for (unsigned k = t; k < n + 2; k += Wt) sV[(size_t)k * L] = v0;
+    for (unsigned i = threadIdx.x; i < (unsigned)d.nr_nclist; i += 64u * W) s_clist[i] = d.clist[i];
+    if (t == 0) {                                // the ZERO slots (second-to-last of each kind) read as 0 forever
 #pragma unroll
-      for (unsigned j = 0; j < SC; ++j) sv[j] = gS[(size_t)min(t + j * Wt, n2 - 1) * d.Bp];
-      for (unsigned i = threadIdx.x; i < (unsigned)d.nr_nclist; i += 64u * W) s_clist[i] = d.clist[i];
-      for (unsigned k = t; k < n + 2; k += Wt) { sV[(size_t)(2 * k) * L] = vroot; sV[(size_t)(2 * k + 1) * L] = 0.0; }
-      for (unsigned i = n2 + t; i < 2u * (n + 2); i += Wt) sS[(size_t)i * L] = 0.0;
-      if (q < n4) dst[q] = r0;
-      if (q + qs < n4) dst[q + qs] = r1;
-      if (q + 2 * qs < n4) dst[q + 2 * qs] = r2;
-      if (q + 3 * qs < n4) dst[q + 3 * qs] = r3;
-      if (q + 4 * qs < n4) dst[q + 4 * qs] = r4;
-      if (q + 5 * qs < n4) dst[q + 5 * qs] = r5;
-      if (q + 6 * qs < n4) dst[q + 6 * qs] = r6;
-      if (q + 7 * qs < n4) dst[q + 7 * qs] = r7;
-#pragma unroll
-      for (unsigned j = 0; j < SC; ++j) if (t + j * Wt < n2) sS[(size_t)(t + j * Wt) * L] = sv[j];
-    }
-    for (unsigned base = threadIdx.x + RC * 64u * W; base < n4; base += 2 * 64u * W) {      // long schedules: the rest, two at a time
-      const uint4 r0 = src[base], r1 = src[min(base + 64u * W, n4 - 1)];
-      dst[base] = r0;
-      if (base + 64u * W < n4) dst[base + 64u * W] = r1;
+      for (int i = 0; i < 4; ++i) cs[((size_t)(d.nr_cslots - 2) * 4 + i) * L] = z2;
+      xs[(size_t)(d.nr_xslots - 2) * L] = z2;
     }
     if (d.nr_line_lds) {                         // res_line constants for the epilogue (uniform branch)
       const uint4* ls = (const uint4*)d.lines;
@@ -309,27 +308,19 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
         if (base + 3 * 64u * W < nl4) ld[base + 3 * 64u * W] = a3;
       }
     }
-    for (unsigned base = t + SC * Wt; base < n2; base += SC * Wt) {
-      double sv[SC];
-#pragma unroll
-      for (unsigned j = 0; j < SC; ++j) sv[j] = gS[(size_t)min(base + j * Wt, n2 - 1) * d.Bp];
-#pragma unroll
-      for (unsigned j = 0; j < SC; ++j) if (base + j * Wt < n2) sS[(size_t)(base + j * Wt) * L] = sv[j];
-    }
-    if (t == 0) {                                // the ZERO slots (second-to-last of each kind) read as 0 forever
-#pragma unroll
-      for (int i = 0; i < 8; ++i) cs[((size_t)(d.nr_cslots - 2) * 8 + i) * L] = 0.0;
-      xs[((size_t)(d.nr_xslots - 2) * 2) * L] = 0.0; xs[((size_t)(d.nr_xslots - 2) * 2 + 1) * L] = 0.0;
-    }
   }
-  __syncthreads();
-  const StepRec* seq = s_sched + (size_t)t * R;  // per lane: this worker's records
-
+#ifdef MAPDN_NR_STAMPS
+  const bool stamp_on = blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned ns = 0;
+#endif
+  STAMP(1);
   const bool act = d.active[e] != 0;              // this env takes part in the solve (same for all its workers)
   // step() bookkeeping inputs, fetched now so that their latency is not paid at the very end
   const int bk_steps = d.steps[e];
   const uint32_t bk_draw = d.draw[e];
   const double bk_sum = d.sum_rewards[e];
+  __syncthreads();
+  STAMP(2);
   bool done = !act;
   bool conv = false;
   int it = 0;
@@ -341,212 +332,300 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   double cS0, cS1, cD0, cD1, cD2, cD3, cR0, cR1;   // register carry child -> parent (same worker, next row)
   double x0, x1;                                   // register carry parent -> child in the backward sweep
 
-  auto load_ops = [&](const StepRec& T, FwdOps& o) {     // LDS operand reads (V is constant during a forward sweep)
-    const unsigned k = (unsigned)T.k, p = (unsigned)T.p;
-    o.ek = sV[(size_t)(2 * k) * L]; o.fk = sV[(size_t)(2 * k + 1) * L];
-    o.ep = sV[(size_t)(2 * p) * L]; o.fp = sV[(size_t)(2 * p + 1) * L];
-    o.sr = sS[(size_t)(2 * k) * L]; o.si = sS[(size_t)(2 * k + 1) * L];
+  // ---- per-row constants: all addressed by (worker, row) only, so they are fetched PF rows ahead with no dependent
+  // address; the scalar row offset is the only thing that changes (prefetches past the ends are clamped, never
+  // skipped: every step issues the same VMEM instructions and the compiler's s_waitcnt counts stay exact)
+  auto row_s = [&](int row, unsigned stride) { return __builtin_amdgcn_readfirstlane((unsigned)row * stride); };
+  auto load_rec = [&](int row, Rec& o) {
+    const unsigned st = row_s(row, TB);
+    o.ix = bldu4(rsT, voT, st);
+    o.ykk = bld2(rsT, voT + 16u, st); o.ykp = bld2(rsT, voT + 32u, st); o.ypk = bld2(rsT, voT + 48u, st); o.cks = bld2(rsT, voT + 64u, st);
+    o.sb = bld2(rs, voS, row_s(row, pb));
   };
-  // backward-sweep operands of row `row`: h of this env from its factor block; G from the factor block or,
-  // in the first iteration, from the flat-start table (rsG / voG / strideG select the source without a branch)
-  auto load_bwd = [&](unsigned row, __amdgpu_buffer_rsrc_t rsG, const unsigned (&voG)[4], unsigned strideG, BwdOps& o) {
-    const unsigned sb = __builtin_amdgcn_readfirstlane(row * bb), sg = __builtin_amdgcn_readfirstlane(row * strideG);
-    if (!HL) { o.h0 = bld(rs, vo[NB_H0], sb); o.h1 = bld(rs, vo[NB_H1], sb); }
-    o.g0 = bld(rsG, voG[0], sg); o.g1 = bld(rsG, voG[1], sg); o.g2 = bld(rsG, voG[2], sg); o.g3 = bld(rsG, voG[3], sg);
+  auto load_recf = [&](int row, RecF& o) {
+    const unsigned sf = row_s(row, FB);
+    o.ix = bldu4(rsT, voT, row_s(row, TB));
+    o.s = bld2(rsF, voF + FL_SR * 8u, sf); o.i01 = bld2(rsF, voF + FL_I0 * 8u, sf); o.i23 = bld2(rsF, voF + FL_I2 * 8u, sf);
+    o.ap = bld2(rsF, voF + FL_APR * 8u, sf);
+    o.sb = bld2(rs, voS, row_s(row, pb));
   };
-  auto load_flat = [&](unsigned row, FlatOps& o) {
-    const unsigned sf = __builtin_amdgcn_readfirstlane(row * FB);
-    o.sr = bld(rsF, voF + FL_SR * 8u, sf); o.si = bld(rsF, voF + FL_SI * 8u, sf);
-    o.i0 = bld(rsF, voF + FL_I0 * 8u, sf); o.i1 = bld(rsF, voF + FL_I1 * 8u, sf);
-    o.i2 = bld(rsF, voF + FL_I2 * 8u, sf); o.i3 = bld(rsF, voF + FL_I3 * 8u, sf);
-    o.apr = bld(rsF, voF + FL_APR * 8u, sf); o.api = bld(rsF, voF + FL_API * 8u, sf);
-  };
+  auto uni = [&](unsigned x) { return __builtin_amdgcn_readfirstlane(x); };
 
-  // Every step issues EXACTLY the same memory instructions whatever its flags (fwd: 16 gather reads,
-  // 8 contribution writes, 6 factor stores; bwd: 2 x reads, 2 x writes, 2 V writes, 6 factor loads):
-  // absent children / parents are the ZERO slot, unread outputs go to the TRASH slot / node.
-  // `prefetch` issues the next rows' record / operand reads: it runs right AFTER this step's gathers so that
-  // those — the head of the row's dependency chain — are first in the in-order LDS queue
-  auto fwd_step = [&](const StepRec& T, const FwdOps& o, unsigned sb, auto&& prefetch) {
-    const uint32_t fl = T.flags;
-    // (1) the gathers first: they depend on the previous row's writes and head the critical path
-    const double* c0 = cs + (size_t)(T.chs & 1023u) * (8 * L);
-    const double* c1 = cs + (size_t)((T.chs >> 10) & 1023u) * (8 * L);
-    double g0[8], g1[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { g0[i] = c0[i * L]; g1[i] = c1[i * L]; }
-    prefetch();
-    // (2) child-independent part: A_kp = V_k conj(Y_kp V_p), A_pk = V_p conj(Y_pk V_k), A_kk = |V_k|^2 conj(Y_kk)
-    const double gkk = T.ykk[0], bkk = T.ykk[1], gkp = T.ykp[0], bkp = T.ykp[1], gpk = T.ypk[0], bpk = T.ypk[1];
-    const double ek = o.ek, fk = o.fk, ep = o.ep, fp = o.fp;
-    const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
-    const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
-    const double ur = gpk * ek - bpk * fk, ui = gpk * fk + bpk * ek;
-    const double apk_r = ep * ur + fp * ui, apk_i = fp * ur - ep * ui;
-    const double v2 = ek * ek + fk * fk;
-    const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
-    // slack link: A_ks = V_k conj(Y_k,slack V_slack) — a constant-voltage neighbour only feeds S_k
-    const double aks_r = ek * T.cks[0] + fk * T.cks[1], aks_i = fk * T.cks[0] - ek * T.cks[1];
-    // (3) children: register carry (same worker, previous row) + LDS slots, canonical order
-    const bool cin = (fl & S_CARRY_IN) != 0;
-    double aS0 = (cin ? cS0 : 0.0) + g0[0], aS1 = (cin ? cS1 : 0.0) + g0[1], aD0 = (cin ? cD0 : 0.0) + g0[2],
-           aD1 = (cin ? cD1 : 0.0) + g0[3], aD2 = (cin ? cD2 : 0.0) + g0[4], aD3 = (cin ? cD3 : 0.0) + g0[5],
-           aR0 = (cin ? cR0 : 0.0) + g0[6], aR1 = (cin ? cR1 : 0.0) + g0[7];
-    aS0 += g1[0]; aS1 += g1[1]; aD0 += g1[2]; aD1 += g1[3]; aD2 += g1[4]; aD3 += g1[5]; aR0 += g1[6]; aR1 += g1[7];
-    const int nch = (int)(fl >> 16);
-    if (nch > 2) {                               // rare: junctions with more than two slot children
-      auto gather = [&](unsigned slot) {
-        const double* c = cs + (size_t)slot * (8 * L);
-        aS0 += c[0]; aS1 += c[L]; aD0 += c[2 * L]; aD1 += c[3 * L]; aD2 += c[4 * L]; aD3 += c[5 * L];
-        aR0 += c[6 * L]; aR1 += c[7 * L];
-      };
-      gather((T.chs >> 20) & 1023u);
-      for (int j = 3; j < nch; ++j) gather((unsigned)s_clist[T.cptr + j - 3]);
-    }
-    // S_k = V_k conj(sum_j Y_kj V_j), mismatch F_k = S_k - Sbus_k
-    const double sr = (akk_r + aks_r) + akp_r + aS0, si = (akk_i + aks_i) + akp_i + aS1;
-    const double Fp = sr - o.sr, Fq = si - o.si;
-    allok = allok && (!(fl & S_LIVE) || ((fabs(Fp) < tol) && (fabs(Fq) < tol)));
-    fmx = fmax(fmx, (fl & S_LIVE) ? fmax(fabs(Fp), fabs(Fq)) : 0.0);
-    const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) - aD1;
-    const double D2 = (sr - akk_r) - aD2, D3 = (si + akk_i) - aD3;
-    const double r0 = Fp - aR0, r1 = Fq - aR1;
-    const double idet = rcp_nr(D0 * D3 - D1 * D2);
-    const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
-    const double h0 = I0 * r0 + I1 * r1, h1 = I2 * r0 + I3 * r1;
-    // U = J'(k,p) = [[Im A_kp, Re A_kp], [-Re A_kp, Im A_kp]],  L = J'(p,k) likewise from A_pk
-    const double G0 = I0 * akp_i - I1 * akp_r, G1 = I0 * akp_r + I1 * akp_i;
-    const double G2 = I2 * akp_i - I3 * akp_r, G3 = I2 * akp_r + I3 * akp_i;
-    const double s0 = apk_i * G0 + apk_r * G2, s1 = apk_i * G1 + apk_r * G3;
-    const double s2 = apk_i * G2 - apk_r * G0, s3 = apk_i * G3 - apk_r * G1;
-    const double t0 = apk_i * h0 + apk_r * h1, t1 = apk_i * h1 - apk_r * h0;
-    // contribution to the parent: registers (consumed only if the next step has S_CARRY_IN) and the
-    // LDS slot (TRASH unless S_SCRATCH_OUT)
-    cS0 = apk_r; cS1 = apk_i; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
-    double* c = cs + (size_t)(T.slots & 1023u) * (8 * L);
-    c[0] = apk_r; c[L] = apk_i; c[2 * L] = s0; c[3 * L] = s1; c[4 * L] = s2; c[5 * L] = s3; c[6 * L] = t0; c[7 * L] = t1;
-    if (HL) { const unsigned k = (unsigned)T.k; sH[(size_t)(2 * k) * L] = h0; sH[(size_t)(2 * k + 1) * L] = h1; }
-    else { bst(h0, rs, vo[NB_H0], sb); bst(h1, rs, vo[NB_H1], sb); }
-    bst(G0, rs, vo[NB_G0], sb); bst(G1, rs, vo[NB_G1], sb); bst(G2, rs, vo[NB_G2], sb); bst(G3, rs, vo[NB_G3], sb);
+  // ---------------------------------------------------------------------------------------------------------------
+  // Row anatomy.  With 16 envs per CU a SIMD runs ONE wave, so nothing hides latency but the order of the wave's own
+  // instructions.  Every row is therefore laid out by hand (sched_barrier fences keep the compiler from undoing it):
+  //   (1) issue the LDS reads that depend on the previous row (children's contributions / parent's x) and the prefetches
+  //   (2) SHADOW: work that does not depend on them — this row's child-independent Jacobian terms, the convergence
+  //       bookkeeping / voltage update DEFERRED from the previous row — runs while those reads are in flight
+  //   (3) the dependent chain (sums -> pivot -> factors -> contribution) and its LDS write, then the row barrier
+  // Only (3) sits between two barriers of the inter-row dependency chain.
+  // Absent children / parents are the ZERO slot, unread outputs go to the TRASH slot / node; whole groups of LDS
+  // instructions that would only move zeros or trash for every worker of the wave are skipped on the wave-uniform hints.
+  // ---------------------------------------------------------------------------------------------------------------
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // mismatch bookkeeping of one step (deferred into the next row's shadow)
+  auto note_mismatch = [&](double Fp, double Fq, bool live) {
+    allok = allok && (!live || ((fabs(Fp) < tol) && (fabs(Fq) < tol)));
+    fmx = fmax(fmx, live ? fmax(fabs(Fp), fabs(Fq)) : 0.0);
   };
-  // Mismatch-only form of the forward step (no Jacobian, no elimination, no factor stores): only the S
-  // part of the contributions (items 0, 1) travels.  Same expressions, same order as fwd_step, so the
-  // verdict is the one the full step would reach.
-  auto fwd_step_light = [&](const StepRec& T, const FwdOps& o, auto&& prefetch) {
-    const uint32_t fl = T.flags;
-    const double* c0 = cs + (size_t)(T.chs & 1023u) * (8 * L);
-    const double* c1 = cs + (size_t)((T.chs >> 10) & 1023u) * (8 * L);
-    const double g00 = c0[0], g01 = c0[L], g10 = c1[0], g11 = c1[L];
-    prefetch();
-    const double gkk = T.ykk[0], bkk = T.ykk[1], gkp = T.ykp[0], bkp = T.ykp[1], gpk = T.ypk[0], bpk = T.ypk[1];
-    const double ek = o.ek, fk = o.fk, ep = o.ep, fp = o.fp;
-    const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
-    const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
-    const double ur = gpk * ek - bpk * fk, ui = gpk * fk + bpk * ek;
-    const double apk_r = ep * ur + fp * ui, apk_i = fp * ur - ep * ui;
-    const double v2 = ek * ek + fk * fk;
-    const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
-    const double aks_r = ek * T.cks[0] + fk * T.cks[1], aks_i = fk * T.cks[0] - ek * T.cks[1];
-    const bool cin = (fl & S_CARRY_IN) != 0;
-    double aS0 = (cin ? cS0 : 0.0) + g00, aS1 = (cin ? cS1 : 0.0) + g01;
-    aS0 += g10; aS1 += g11;
-    const int nch = (int)(fl >> 16);
-    if (nch > 2) {
-      auto gather = [&](unsigned slot) { const double* c = cs + (size_t)slot * (8 * L); aS0 += c[0]; aS1 += c[L]; };
-      gather((T.chs >> 20) & 1023u);
-      for (int j = 3; j < nch; ++j) gather((unsigned)s_clist[T.cptr + j - 3]);
-    }
-    const double sr = (akk_r + aks_r) + akp_r + aS0, si = (akk_i + aks_i) + akp_i + aS1;
-    const double Fp = sr - o.sr, Fq = si - o.si;
-    allok = allok && (!(fl & S_LIVE) || ((fabs(Fp) < tol) && (fabs(Fq) < tol)));
-    fmx = fmax(fmx, (fl & S_LIVE) ? fmax(fabs(Fp), fabs(Fq)) : 0.0);
-    cS0 = apk_r; cS1 = apk_i;
-    double* c = cs + (size_t)(T.slots & 1023u) * (8 * L);
-    c[0] = apk_r; c[L] = apk_i;
-  };
-  // First iteration: every V is the flat start, so D^-1 (I), G and the link terms are the host-made
-  // constants of Schedule::flat; per env there is only the forward substitution of the right-hand side
-  // r = F - sum of the children's t (items 6, 7 of the contribution slots), h = I r, t = L h.
-  auto fwd_step_flat = [&](const StepRec& T, const FwdOps& o, const FlatOps& q, unsigned sb, auto&& prefetch) {
-    const uint32_t fl = T.flags;
-    const double* c0 = cs + (size_t)(T.chs & 1023u) * (8 * L);
-    const double* c1 = cs + (size_t)((T.chs >> 10) & 1023u) * (8 * L);
-    const double g06 = c0[6 * L], g07 = c0[7 * L], g16 = c1[6 * L], g17 = c1[7 * L];
-    prefetch();
-    const bool cin = (fl & S_CARRY_IN) != 0;
-    double aR0 = (cin ? cR0 : 0.0) + g06, aR1 = (cin ? cR1 : 0.0) + g07;
-    aR0 += g16; aR1 += g17;
-    const int nch = (int)(fl >> 16);
-    if (nch > 2) {
-      auto gather = [&](unsigned slot) { const double* c = cs + (size_t)slot * (8 * L); aR0 += c[6 * L]; aR1 += c[7 * L]; };
-      gather((T.chs >> 20) & 1023u);
-      for (int j = 3; j < nch; ++j) gather((unsigned)s_clist[T.cptr + j - 3]);
-    }
-    const double Fp = q.sr - o.sr, Fq = q.si - o.si;
-    allok = allok && (!(fl & S_LIVE) || ((fabs(Fp) < tol) && (fabs(Fq) < tol)));
-    fmx = fmax(fmx, (fl & S_LIVE) ? fmax(fabs(Fp), fabs(Fq)) : 0.0);
-    const double r0 = Fp - aR0, r1 = Fq - aR1;
-    const double h0 = q.i0 * r0 + q.i1 * r1, h1 = q.i2 * r0 + q.i3 * r1;
-    const double t0 = q.api * h0 + q.apr * h1, t1 = q.api * h1 - q.apr * h0;
-    cR0 = t0; cR1 = t1;
-    double* c = cs + (size_t)(T.slots & 1023u) * (8 * L);
-    c[6 * L] = t0; c[7 * L] = t1;
-    if (HL) { const unsigned k = (unsigned)T.k; sH[(size_t)(2 * k) * L] = h0; sH[(size_t)(2 * k + 1) * L] = h1; }
-    else { bst(h0, rs, vo[NB_H0], sb); bst(h1, rs, vo[NB_H1], sb); }
-  };
-  // the row loop of those two forms: record two rows, operands one row (flat constants two rows) ahead
-  auto fwd_sweep_alt = [&](auto kind) {
-    constexpr int K = decltype(kind)::value;       // 1: mismatch only, 2: flat start
-    StepRec Tq[3]; FwdOps oq[3]; FlatOps fq[3];
-    Tq[0] = seq[0]; Tq[1] = seq[min(1, R - 1)];
-    load_ops(Tq[0], oq[0]);
-    if constexpr (K == 2) { load_flat(0u, fq[0]); load_flat((unsigned)min(1, R - 1), fq[1]); }
+  auto clist_ptr = [&](uint32_t fl, uint32_t slots, uint32_t chs) { return (fl >> 24) | ((slots >> 30) << 8) | ((chs >> 30) << 10); };
+
+  // forward sweep.  K 0: full (mismatch + Jacobian + block elimination), 1: mismatch only (no Jacobian, no elimination, no
+  // factor stores; only the S part of the contributions, pair 0, travels — same expressions, same order as the full
+  // step, so the verdict is the one the full step would reach).  Records PF rows ahead (global), own / parent voltage
+  // one row ahead (LDS: V is constant during a forward sweep); unrolled by 3 so that ring indices are compile-time.
+  auto fwd_sweep = [&](auto kind) {
+    constexpr int K = decltype(kind)::value;
+    Rec Tq[3]; d2 vkq[3], vpq[3];
+    load_rec(0, Tq[0]); load_rec(min(1, R - 1), Tq[1]);
+    { const unsigned kp = Tq[0].ix.w; vkq[0] = sV[(size_t)(kp & 0xffffu) * L]; vpq[0] = sV[(size_t)(kp >> 16) * L]; }
+    double pFp = 0.0, pFq = 0.0; bool pLive = false;       // deferred mismatch bookkeeping of the previous row
     int r = 0;
     while (r < R) {
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         if (r >= R) break;
-        auto pf = [&]() { Tq[(u + 2) % 3] = seq[min(r + 2, R - 1)]; load_ops(Tq[(u + 1) % 3], oq[(u + 1) % 3]); };
-        if constexpr (K == 2) {
-          load_flat((unsigned)min(r + 2, R - 1), fq[(u + 2) % 3]);
-          fwd_step_flat(Tq[u % 3], oq[u % 3], fq[u % 3], __builtin_amdgcn_readfirstlane((unsigned)r * bb), pf);
+        const Rec& T = Tq[u % 3];
+        const d2 vk = vkq[u % 3], vp = vpq[u % 3];
+        const uint32_t fl = T.ix.x, slots = T.ix.y, chs = T.ix.z, kp = T.ix.w;
+        const unsigned gmax = uni((fl >> SU_GMAX_SHIFT) & 3u);
+        // (1) gathers first: they depend on the previous row's writes and head the critical path
+        d2 g0[4], g1[4];                           // loaded iff gmax >= 1 / 2 (never read otherwise)
+        constexpr int NP = K == 0 ? 4 : 1;         // pairs that travel
+        if (gmax >= 1u) {
+          const d2* c0 = cs + (size_t)(chs & 1023u) * (4 * L);
+#pragma unroll
+          for (int i = 0; i < NP; ++i) g0[i] = c0[i * L];
+        }
+        if (gmax >= 2u) {
+          const d2* c1 = cs + (size_t)((chs >> 10) & 1023u) * (4 * L);
+#pragma unroll
+          for (int i = 0; i < NP; ++i) g1[i] = c1[i * L];
+        }
+        {                                          // next row's operands (LDS) and the record two rows ahead (global)
+          const unsigned kpn = Tq[(u + 1) % 3].ix.w;
+          vkq[(u + 1) % 3] = sV[(size_t)(kpn & 0xffffu) * L]; vpq[(u + 1) % 3] = sV[(size_t)(kpn >> 16) * L];
+          load_rec(min(r + 2, R - 1), Tq[(u + 2) % 3]);
+        }
+        SCHED_FENCE();
+        // (2) shadow: previous row's bookkeeping; this row's child-independent part
+        //     A_kp = V_k conj(Y_kp V_p), A_pk = V_p conj(Y_pk V_k), A_kk = |V_k|^2 conj(Y_kk), A_ks = V_k conj(Y_k,slack V_slack)
+        note_mismatch(pFp, pFq, pLive);
+        const double gkk = T.ykk.x, bkk = T.ykk.y, gkp = T.ykp.x, bkp = T.ykp.y, gpk = T.ypk.x, bpk = T.ypk.y;
+        const double ek = vk.x, fk = vk.y, ep = vp.x, fp = vp.y;
+        const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
+        const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
+        const double ur = gpk * ek - bpk * fk, ui = gpk * fk + bpk * ek;
+        const double apk_r = ep * ur + fp * ui, apk_i = fp * ur - ep * ui;
+        const double v2 = ek * ek + fk * fk;
+        const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
+        double aks_r = 0.0, aks_i = 0.0;           // a constant-voltage neighbour only feeds S_k
+        if (uni(fl & SU_SLACK_ANY)) { aks_r = ek * T.cks.x + fk * T.cks.y; aks_i = fk * T.cks.x - ek * T.cks.y; }
+        const double base_r = (akk_r + aks_r) + akp_r, base_i = (akk_i + aks_i) + akp_i;
+        const double m = (fl & S_CARRY_IN) ? 1.0 : 0.0;    // register carry (same worker, previous row) masked by a 0/1 factor
+        SCHED_FENCE();
+        // (3) the dependent chain: children (carry + LDS slots, canonical order) -> S, mismatch -> pivot -> factors -> contribution
+        double aS0, aS1, aD0 = 0.0, aD1 = 0.0, aD2 = 0.0, aD3 = 0.0, aR0 = 0.0, aR1 = 0.0;
+        if (gmax == 0u) {
+          aS0 = m * cS0; aS1 = m * cS1;
+          if constexpr (K == 0) { aD0 = m * cD0; aD1 = m * cD1; aD2 = m * cD2; aD3 = m * cD3; aR0 = m * cR0; aR1 = m * cR1; }
         } else {
-          fwd_step_light(Tq[u % 3], oq[u % 3], pf);
+          aS0 = fma(m, cS0, g0[0].x); aS1 = fma(m, cS1, g0[0].y);
+          if constexpr (K == 0) {
+            aD0 = fma(m, cD0, g0[1].x); aD1 = fma(m, cD1, g0[1].y); aD2 = fma(m, cD2, g0[2].x); aD3 = fma(m, cD3, g0[2].y);
+            aR0 = fma(m, cR0, g0[3].x); aR1 = fma(m, cR1, g0[3].y);
+          }
+          if (gmax >= 2u) {
+            aS0 += g1[0].x; aS1 += g1[0].y;
+            if constexpr (K == 0) { aD0 += g1[1].x; aD1 += g1[1].y; aD2 += g1[2].x; aD3 += g1[2].y; aR0 += g1[3].x; aR1 += g1[3].y; }
+          }
+          if (gmax >= 3u) {                        // rare: junctions with more than two slot children
+            const int nch = (int)((fl >> 16) & 255u);
+            if (nch > 2) {
+              auto gather = [&](unsigned slot) {
+                const d2* c = cs + (size_t)slot * (4 * L);
+                const d2 a = c[0];
+                aS0 += a.x; aS1 += a.y;
+                if constexpr (K == 0) {
+                  const d2 b = c[L], cc = c[2 * L], dd = c[3 * L];
+                  aD0 += b.x; aD1 += b.y; aD2 += cc.x; aD3 += cc.y; aR0 += dd.x; aR1 += dd.y;
+                }
+              };
+              gather((chs >> 20) & 1023u);
+              const unsigned cptr = clist_ptr(fl, slots, chs);
+              for (int j = 3; j < nch; ++j) gather((unsigned)s_clist[cptr + j - 3]);
+            }
+          }
+        }
+        // S_k = V_k conj(sum_j Y_kj V_j), mismatch F_k = S_k - Sbus_k
+        const double sr = base_r + aS0, si = base_i + aS1;
+        const double Fp = sr - T.sb.x, Fq = si - T.sb.y;
+        pFp = Fp; pFq = Fq; pLive = (fl & S_LIVE) != 0;
+        if constexpr (K == 0) {
+          const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) - aD1;
+          const double D2 = (sr - akk_r) - aD2, D3 = (si + akk_i) - aD3;
+          const double r0 = Fp - aR0, r1 = Fq - aR1;
+          const double idet = rcp_nr(D0 * D3 - D1 * D2);
+          const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
+          const double h0 = I0 * r0 + I1 * r1, h1 = I2 * r0 + I3 * r1;
+          // U = J'(k,p) = [[Im A_kp, Re A_kp], [-Re A_kp, Im A_kp]],  L = J'(p,k) likewise from A_pk
+          const double G0 = I0 * akp_i - I1 * akp_r, G1 = I0 * akp_r + I1 * akp_i;
+          const double G2 = I2 * akp_i - I3 * akp_r, G3 = I2 * akp_r + I3 * akp_i;
+          const double s0 = apk_i * G0 + apk_r * G2, s1 = apk_i * G1 + apk_r * G3;
+          const double s2 = apk_i * G2 - apk_r * G0, s3 = apk_i * G3 - apk_r * G1;
+          const double t0 = apk_i * h0 + apk_r * h1, t1 = apk_i * h1 - apk_r * h0;
+          // contribution to the parent: registers (consumed only if the next step has S_CARRY_IN) and the
+          // LDS slot (TRASH unless S_SCRATCH_OUT; skipped when no worker of the wave has a real slot)
+          cS0 = apk_r; cS1 = apk_i; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
+          if (uni(fl & SU_W_ANY)) {
+            d2* c = cs + (size_t)(slots & 1023u) * (4 * L);
+            c[0] = d2{apk_r, apk_i}; c[L] = d2{s0, s1}; c[2 * L] = d2{s2, s3}; c[3 * L] = d2{t0, t1};
+          }
+          SCHED_FENCE();                           // the factors leave after the contribution is on its way
+          const unsigned k = kp & 0xffffu, sbF = row_s(r, bb);
+          if (HL) sH[(size_t)k * L] = d2{h0, h1}; else bst2(d2{h0, h1}, rs, voB + NB_H * pb, sbF);
+          if (GL) { sG[(size_t)(2 * k) * L] = d2{G0, G1}; sG[(size_t)(2 * k + 1) * L] = d2{G2, G3}; }
+          else { bst2(d2{G0, G1}, rs, voB + NB_G01 * pb, sbF); bst2(d2{G2, G3}, rs, voB + NB_G23 * pb, sbF); }
+        } else {
+          cS0 = apk_r; cS1 = apk_i;
+          if (uni(fl & SU_W_ANY)) cs[(size_t)(slots & 1023u) * (4 * L)] = d2{apk_r, apk_i};
         }
         if (W > 1) lds_barrier();
+        STAMP(100 + K);
+        ++r;
+      }
+    }
+    note_mismatch(pFp, pFq, pLive);
+  };
+  // First iteration: every V is the flat start, so D^-1 (I), G and the link terms are the host-made
+  // constants of Schedule::flat; per env there is only the forward substitution of the right-hand side
+  // r = F - sum of the children's t (pair 3 of the contribution slots), h = I r, t = L h.
+  auto fwd_sweep_flat = [&]() {
+    RecF Tq[3];
+    load_recf(0, Tq[0]); load_recf(min(1, R - 1), Tq[1]);
+    int r = 0;
+    while (r < R) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (r >= R) break;
+        const RecF& T = Tq[u % 3];
+        const uint32_t fl = T.ix.x, slots = T.ix.y, chs = T.ix.z, kp = T.ix.w;
+        const unsigned gmax = uni((fl >> SU_GMAX_SHIFT) & 3u);
+        d2 g0, g1;
+        if (gmax >= 1u) g0 = cs[((size_t)(chs & 1023u) * 4 + 3) * L];
+        if (gmax >= 2u) g1 = cs[((size_t)((chs >> 10) & 1023u) * 4 + 3) * L];
+        load_recf(min(r + 2, R - 1), Tq[(u + 2) % 3]);
+        SCHED_FENCE();
+        const double Fp = T.s.x - T.sb.x, Fq = T.s.y - T.sb.y;       // shadow: the flat-start mismatch does not depend on children
+        note_mismatch(Fp, Fq, (fl & S_LIVE) != 0);
+        const double m = (fl & S_CARRY_IN) ? 1.0 : 0.0;
+        SCHED_FENCE();
+        double aR0, aR1;
+        if (gmax == 0u) { aR0 = m * cR0; aR1 = m * cR1; }
+        else {
+          aR0 = fma(m, cR0, g0.x); aR1 = fma(m, cR1, g0.y);
+          if (gmax >= 2u) { aR0 += g1.x; aR1 += g1.y; }
+          if (gmax >= 3u) {
+            const int nch = (int)((fl >> 16) & 255u);
+            if (nch > 2) {
+              auto gather = [&](unsigned slot) { const d2 a = cs[((size_t)slot * 4 + 3) * L]; aR0 += a.x; aR1 += a.y; };
+              gather((chs >> 20) & 1023u);
+              const unsigned cptr = clist_ptr(fl, slots, chs);
+              for (int j = 3; j < nch; ++j) gather((unsigned)s_clist[cptr + j - 3]);
+            }
+          }
+        }
+        const double r0 = Fp - aR0, r1 = Fq - aR1;
+        const double h0 = T.i01.x * r0 + T.i01.y * r1, h1 = T.i23.x * r0 + T.i23.y * r1;
+        const double t0 = T.ap.y * h0 + T.ap.x * h1, t1 = T.ap.y * h1 - T.ap.x * h0;
+        cR0 = t0; cR1 = t1;
+        if (uni(fl & SU_W_ANY)) cs[((size_t)(slots & 1023u) * 4 + 3) * L] = d2{t0, t1};
+        SCHED_FENCE();
+        const unsigned k = kp & 0xffffu;
+        if (HL) sH[(size_t)k * L] = d2{h0, h1}; else bst2(d2{h0, h1}, rs, voB + NB_H * pb, row_s(r, bb));
+        if (W > 1) lds_barrier();
+        STAMP(102);
         ++r;
       }
     }
   };
   double dxm = 0.0;                                // largest Newton step component of this worker's nodes, per env
-  // ek/fk: this node's voltage, read from LDS one row ahead (only its own step ever writes it)
-  auto bwd_step = [&](const StepRec& T, const BwdOps& o, double ek, double fk, auto&& prefetch) {
-    const uint32_t fl = T.flags;
-    const uint32_t slots = T.slots;
-    const double* xp = xs + (size_t)(slots >> 20) * (2 * L);       // parent's x slot (ZERO slot for slack parents)
-    const double q0 = xp[0], q1 = xp[L];
-    prefetch();
-    const bool cout = (fl & S_CARRY_OUT) != 0;
-    const double p0 = cout ? x0 : q0, p1 = cout ? x1 : q1;
-    const double hh0 = HL ? sH[(size_t)(2 * (unsigned)T.k) * L] : o.h0, hh1 = HL ? sH[(size_t)(2 * (unsigned)T.k + 1) * L] : o.h1;
-    const double y0 = hh0 - (o.g0 * p0 + o.g1 * p1);
-    const double y1 = hh1 - (o.g2 * p0 + o.g3 * p1);
-    x0 = y0; x1 = y1;
-    dxm = fmax(dxm, (fl & S_LIVE) ? fmax(fabs(y0), fabs(y1)) : 0.0);
-    double* xo = xs + (size_t)((slots >> 10) & 1023u) * (2 * L);   // TRASH unless S_X_OUT
-    xo[0] = y0; xo[L] = y1;
-    // newtonpf update: Va += dx_a, Vm += dx_m, V = Vm e^{jVa}, with dx_a = -y0, dx_m = -|V| y1
-    //   =>  V <- V (1 - y1) e^{-j y0}   (rotation by the small step; |V|, angle are formed at the end)
+  // newtonpf update of one node, DEFERRED into the shadow of the next backward row (only the x chain is between the row
+  // barriers): Va += dx_a, Vm += dx_m, V = Vm e^{jVa}, with dx_a = -y0, dx_m = -|V| y1
+  //   =>  V <- V (1 - y1) e^{-j y0}   (rotation by the small step; |V|, angle are formed at the end)
+  auto apply_update = [&](double y0, double y1, d2 vk, unsigned k, bool live) {
+    dxm = fmax(dxm, live ? fmax(fabs(y0), fabs(y1)) : 0.0);
+#if (MAPDN_EXP & 2)
+    return;
+#endif
     double s, c;
     const double dth = -y0;
     sincos_small(dth, &s, &c);
-    if (__any((fl & S_LIVE) && !(fabs(dth) <= 0.5))) sincos(dth, &s, &c);   // wave-uniform, only when a lane diverges
+#if !(MAPDN_EXP & 1)
+    if (__any(live && !(fabs(dth) <= 0.5))) sincos(dth, &s, &c);   // wave-uniform, only when a lane diverges
+#endif
     const double sc = 1.0 - y1;
-    const double en = sc * (ek * c - fk * s), fn = sc * (ek * s + fk * c);
-    const unsigned k = (unsigned)T.k;
-    sV[(size_t)(2 * k) * L] = done ? ek : en;                        // converged envs keep their state; idle steps hit the trash node
-    sV[(size_t)(2 * k + 1) * L] = done ? fk : fn;
+    const double en = sc * (vk.x * c - vk.y * s), fn = sc * (vk.x * s + vk.y * c);
+    sV[(size_t)k * L] = done ? vk : d2{en, fn};     // converged envs keep their state; idle steps hit the trash node
   };
+  // backward sweep.  SRC 0: first iteration, G from the flat-start table; 1: G (and h) from LDS where they live there;
+  // factors that live in global scratch are prefetched two rows ahead through a static register ring like the records.
+  auto bwd_sweep = [&](auto src) {
+    constexpr int SRC = decltype(src)::value;
+    constexpr bool gG = (SRC == 0) || !GL;         // G comes from global memory (flat table or factor block)
+    constexpr bool gH = !HL;
+    u32x4 ixq[3]; BwdF fq[3];
+    auto load_b = [&](int row, u32x4& ix, BwdF& f) {
+      ix = bldu4(rsT, voT, row_s(row, TB));
+      if (gH) f.h = bld2(rs, voB + NB_H * pb, row_s(row, bb));
+      if (gG) {
+        if (SRC == 0) { const unsigned sf = row_s(row, FB); f.g01 = bld2(rsF, voF + FL_G0 * 8u, sf); f.g23 = bld2(rsF, voF + FL_G2 * 8u, sf); }
+        else { const unsigned sb = row_s(row, bb); f.g01 = bld2(rs, voB + NB_G01 * pb, sb); f.g23 = bld2(rs, voB + NB_G23 * pb, sb); }
+      }
+    };
+    load_b(R - 1, ixq[0], fq[0]); load_b(max(R - 2, 0), ixq[1], fq[1]);
+    double py0 = 0.0, py1 = 0.0; d2 pvk = sV[(size_t)(n + 1) * L]; unsigned pk = n + 1; bool pLive = false;   // deferred update of the previous row
+    int r = R - 1;
+    while (r >= 0) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (r < 0) break;
+        const u32x4 ix = ixq[u % 3];
+        const uint32_t fl = ix.x, slots = ix.y;
+        const unsigned k = ix.w & 0xffffu;
+        // (1) the parent's x (ZERO slot for slack parents), this node's factors and voltage
+        d2 q;
+        const bool xr = uni(fl & SU_XR_ANY) != 0;
+        if (xr) q = xs[(size_t)((slots >> 20) & 1023u) * L];
+        const d2 hh = gH ? fq[u % 3].h : sH[(size_t)k * L];
+        const d2 g01 = gG ? fq[u % 3].g01 : sG[(size_t)(2 * k) * L];
+        const d2 g23 = gG ? fq[u % 3].g23 : sG[(size_t)(2 * k + 1) * L];
+        const d2 vk = sV[(size_t)k * L];           // (only this node's own deferred update ever writes it)
+#if (MAPDN_EXP & 8)
+        ixq[(u + 2) % 3] = ixq[u % 3]; fq[(u + 2) % 3] = fq[u % 3];
+#else
+        load_b(max(r - 2, 0), ixq[(u + 2) % 3], fq[(u + 2) % 3]);
+#endif
+        SCHED_FENCE();
+        // (2) shadow: the previous row's voltage update
+        apply_update(py0, py1, pvk, pk, pLive);
+        SCHED_FENCE();
+        // (3) x_k = h_k - G_k x_parent
+        const bool cout = (fl & S_CARRY_OUT) != 0;
+        const double p0 = cout ? x0 : (xr ? q.x : 0.0), p1 = cout ? x1 : (xr ? q.y : 0.0);
+        const double y0 = hh.x - (g01.x * p0 + g01.y * p1);
+        const double y1 = hh.y - (g23.x * p0 + g23.y * p1);
+        x0 = y0; x1 = y1;
+        if (uni(fl & SU_XW_ANY)) xs[(size_t)((slots >> 10) & 1023u) * L] = d2{y0, y1};   // TRASH unless S_X_OUT
+        py0 = y0; py1 = y1; pvk = vk; pk = k; pLive = (fl & S_LIVE) != 0;
+        if (W > 1) lds_barrier();
+        STAMP(110 + SRC);
+        --r;
+      }
+    }
+    apply_update(py0, py1, pvk, pk, pLive);
+  };
+#undef SCHED_FENCE
 
   // Sweep forms.  `first`: the flat-start iteration (host-factorised constants).  `light`: the previous Newton
   // step of every unfinished env of this workgroup was tiny, so convergence is expected and the sweep is
@@ -558,35 +637,10 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     // ------------------------------------------------------------------ forward sweep
     allok = true; fmx = 0.0;
     cS0 = cS1 = cD0 = cD1 = cD2 = cD3 = cR0 = cR1 = 0.0;
-    if (first) {
-      fwd_sweep_alt(std::integral_constant<int, 2>{});
-    } else if (light) {
-      fwd_sweep_alt(std::integral_constant<int, 1>{});
-    } else {
-      // three rotating record / operand sets (loop unrolled by 3 so the rotation is static): while
-      // row r computes, record r+2 and the LDS operands of row r+1 are already on their way
-      StepRec T0 = seq[0], T1 = seq[R > 1 ? 1 : 0], T2;
-      FwdOps o0, o1, o2;
-      load_ops(T0, o0);
-      unsigned sb = 0;
-      int r = 0;
-      // prefetches past the last row are clamped to it instead of skipped: every pass through the loop body
-      // issues the same LDS / VMEM instructions, so the compiler's s_waitcnt counts stay exact (a
-      // conditional load makes it fall back to waiting for everything in flight)
-      for (; r + 2 < R; r += 3) {
-        fwd_step(T0, o0, sb, [&]() { T2 = seq[r + 2]; load_ops(T1, o1); });
-        if (W > 1) lds_barrier();
-        fwd_step(T1, o1, sb + bb, [&]() { T0 = seq[min(r + 3, R - 1)]; load_ops(T2, o2); });
-        if (W > 1) lds_barrier();
-        fwd_step(T2, o2, sb + 2 * bb, [&]() { T1 = seq[min(r + 4, R - 1)]; load_ops(T0, o0); });
-        if (W > 1) lds_barrier();
-        sb += 3 * bb;
-      }
-      if (r < R) {
-        fwd_step(T0, o0, sb, [&]() { if (r + 1 < R) load_ops(T1, o1); }); if (W > 1) lds_barrier();
-      }
-      if (r + 1 < R) { fwd_step(T1, o1, sb + bb, []() {}); if (W > 1) lds_barrier(); }
-    }
+    STAMP(10);
+    if (first) fwd_sweep_flat();
+    else if (light) fwd_sweep(std::integral_constant<int, 1>{});
+    else fwd_sweep(std::integral_constant<int, 0>{});
     {                                            // AND of the workers' verdicts, per env
       s_ok[t * L + el] = allok ? 1 : 0;
       s_dx[(size_t)t * L] = fmx;                 // (free here: the step sizes it holds were consumed before this sweep)
@@ -601,6 +655,7 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
         continue;
       }
     }
+    STAMP(11);
     Fprev = Fcur; Fcur = fmx;                    // this sweep stands (a redone mismatch-only sweep never gets here)
     if (!done) {
       conv = allok;
@@ -608,40 +663,10 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     }
     if (__all(done)) break;                      // same envs, same values in every wave of the group
     // ------------------------------------------------------------------ backward sweep + update
-    // factor loads (global scratch) PF rows ahead through a static register ring, record two rows and
-    // own voltage (LDS) one row ahead.  The loop is unrolled by PF + 1 (a multiple of 3) so every ring
-    // index is a compile-time constant; prefetches below row 0 are clamped to it, never skipped (see above)
     x0 = x1 = 0.0;
     dxm = 0.0;
-    {
-      constexpr int PF = MAPDN_NR_PF, U = PF + 1;
-      const __amdgpu_buffer_rsrc_t rsG = first ? rsF : rs;
-      const unsigned voG[4] = {first ? voF + FL_G0 * 8u : vo[NB_G0], first ? voF + FL_G1 * 8u : vo[NB_G1],
-                               first ? voF + FL_G2 * 8u : vo[NB_G2], first ? voF + FL_G3 * 8u : vo[NB_G3]};
-      const unsigned strideG = first ? FB : bb;
-      BwdOps fo[U];
-      StepRec Tq[3];
-      double eq[3], fq[3];
-#pragma unroll
-      for (int j = 0; j < PF; ++j) load_bwd((unsigned)max(R - 1 - j, 0), rsG, voG, strideG, fo[j]);
-      Tq[0] = seq[R - 1]; Tq[1] = seq[max(R - 2, 0)];
-      eq[0] = sV[(size_t)(2 * (unsigned)Tq[0].k) * L]; fq[0] = sV[(size_t)(2 * (unsigned)Tq[0].k + 1) * L];
-      int r = R - 1;
-      while (r >= 0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (r < 0) break;
-          load_bwd((unsigned)max(r - PF, 0), rsG, voG, strideG, fo[(u + PF) % U]);
-          bwd_step(Tq[u % 3], fo[u % U], eq[u % 3], fq[u % 3], [&]() {
-            Tq[(u + 2) % 3] = seq[max(r - 2, 0)];
-            eq[(u + 1) % 3] = sV[(size_t)(2 * (unsigned)Tq[(u + 1) % 3].k) * L];
-            fq[(u + 1) % 3] = sV[(size_t)(2 * (unsigned)Tq[(u + 1) % 3].k + 1) * L];
-          });
-          if (W > 1) lds_barrier();
-          --r;
-        }
-      }
-    }
+    STAMP(12);
+    if (first) bwd_sweep(std::integral_constant<int, 0>{}); else bwd_sweep(std::integral_constant<int, 1>{});
     first = false;
     if (!done) ++it;
     {                                            // size of the step just taken, per env: max over the workers
@@ -655,6 +680,10 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
       light = __all(done || dxe < d.nr_check_dx || quad);
     }
   }
+  STAMP(20);
+#ifdef MAPDN_NR_STAMPS
+  if (stamp_on) g_stamps[0] = ns;
+#endif
   if (t == 0) { d.iters[e] = it; d.conv[e] = conv ? 1 : 0; }
   // =================================================================== fused epilogue
   // The workgroup still holds the solution of its L envs in LDS, so the rest of the env step happens
@@ -668,7 +697,8 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   if (mode == MODE_SOLVE) {                      // mapdn_solve_only: just the solution
     double* gV = d.nrbuf + (size_t)d.r_vout * SB + e;
     for (unsigned k = t; k < n; k += Wt) {
-      const double ek = sV[(size_t)(2 * k) * L], fk = sV[(size_t)(2 * k + 1) * L];
+      const d2 vv = sV[(size_t)k * L];
+      const double ek = vv.x, fk = vv.y;
       double* o = gV + (size_t)(VOF * k) * SB;
       o[(size_t)VO_E * SB] = ek; o[(size_t)VO_F * SB] = fk;
       o[(size_t)VO_VM * SB] = sqrt(ek * ek + fk * fk);            // Vm = |V|
@@ -698,7 +728,8 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     constexpr int BT = decltype(type_tag)::value;
 #pragma unroll 4
     for (unsigned k = t; k < n; k += Wt) {
-      const double ek = sV[(size_t)(2 * k) * L], fk = sV[(size_t)(2 * k + 1) * L];
+      const d2 vv = sV[(size_t)k * L];
+      const double ek = vv.x, fk = vv.y;
       const double v = sqrt(ek * ek + fk * fk);                      // res_bus.vm_pu = |V|
       if (commitf) { gV[((size_t)VOF * k + VO_E) * SB] = ek; gV[((size_t)VOF * k + VO_F) * SB] = fk; }
       n_lo += (v < vlo) ? 1.0 : 0.0; n_hi += (v > vhi) ? 1.0 : 0.0;
@@ -733,7 +764,8 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
       const double ab = Lc[0];
       const unsigned a = (unsigned)__double2loint(ab), b = (unsigned)__double2hiint(ab);
       const double yffr = Lc[1], yffi = Lc[2], yftr = Lc[3], yfti = Lc[4], ytfr = Lc[5], ytfi = Lc[6], yttr = Lc[7], ytti = Lc[8];
-      const double ef = sV[(size_t)(2 * a) * L], ff = sV[(size_t)(2 * a + 1) * L], et = sV[(size_t)(2 * b) * L], ft = sV[(size_t)(2 * b + 1) * L];
+      const d2 vf = sV[(size_t)a * L], vt = sV[(size_t)b * L];
+      const double ef = vf.x, ff = vf.y, et = vt.x, ft = vt.y;
       const double ifr = yffr * ef - yffi * ff + yftr * et - yfti * ft;
       const double ifi = yffr * ff + yffi * ef + yftr * ft + yfti * et;
       const double itr = ytfr * ef - ytfi * ff + yttr * et - ytti * ft;
@@ -775,6 +807,10 @@ k_nr_wtree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
     }
     return;
   }
+  STAMP(21);
+#ifdef MAPDN_NR_STAMPS
+  if (stamp_on) g_stamps[0] = ns;
+#endif
   // ---- combine the workers' partials through LDS, fixed order
   double* sm = s_epi;                             // sm[(q*Wt + worker)*L]
   const double part[10] = {n_lo, n_hi, dev, vsum, mdrop, mrise, bar, line_loss, q_loss, q_fail};
@@ -874,11 +910,11 @@ __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_pr
     double v, P, Q;
     if (k < d.n) {
       const double* vo = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * k) * S + e;
-      const double* sb = d.nrbuf + ((size_t)d.r_sbus + 2 * (size_t)k) * S + e;
+      const double2 sb = ((const double2*)((const char*)d.nrbuf + d.sb_off))[(size_t)d.sb_index[k] * S + e];
       const double ek = vo[(size_t)VO_E * S], fk = vo[(size_t)VO_F * S];
       v = sqrt(ek * ek + fk * fk);
       d.va[o] = atan2(fk, ek);
-      P = -sb[0] * d.sn; Q = -sb[S] * d.sn;
+      P = -sb.x * d.sn; Q = -sb.y * d.sn;
     } else {
       v = d.vroot; d.va[o] = 0.0;
       double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;     // I = Y_rr V_r + sum_neighbours Y_rk V_k
@@ -1028,6 +1064,12 @@ __global__ void __launch_bounds__(256) k_stats(Dev d, long long* out) {
 // launchers (host)
 // =================================================================================================
 
+#ifdef MAPDN_NR_STAMPS
+extern "C" int mapdn_debug_stamps(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
 void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,
                    const double* pv, const double* q, hipStream_t st) {
   const dim3 grid((d.Bp + 255) / 256, d.nb);
@@ -1035,20 +1077,21 @@ void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const
   else hipLaunchKernelGGL(k_inject<double>, grid, dim3(256), 0, st, d, mode, (const double*)actions, pl, ql, pv, q);
 }
 // (W, L) instantiations of k_nr_wtree
-#define NR_FOR_EACH(X) X(1, 4) X(1, 8) X(1, 16) X(1, 32) X(2, 4) X(2, 8) X(2, 16) X(2, 32) X(4, 8) X(4, 16) X(4, 32) X(8, 16) X(8, 32)
+#define NR_FOR_EACH(X) X(1, 8) X(1, 16) X(1, 32) X(2, 8) X(2, 16) X(2, 32) X(4, 8) X(4, 16) X(4, 32) X(8, 16)
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
   const dim3 grid(d.Bp / d.nr_lanes);
-  const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.n, d.nr_cslots, d.nr_xslots, d.nr_rows, d.nr_nclist, d.nr_h_lds,
+  const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.n, d.nr_cslots, d.nr_xslots, d.nr_nclist, d.nr_h_lds, d.nr_g_lds,
                                   d.nr_line_lds ? d.n_line : 0);
 #define X(w, l) if (d.nr_waves == w && d.nr_lanes == l) { \
-    if (d.nr_h_lds) hipLaunchKernelGGL((k_nr_wtree<w, l, true>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
-    else hipLaunchKernelGGL((k_nr_wtree<w, l, false>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
+    if (d.nr_h_lds && d.nr_g_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, true>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
+    else if (d.nr_h_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, false>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
+    else hipLaunchKernelGGL((k_nr_tree<w, l, false, false>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
     return; }
   NR_FOR_EACH(X)
 #undef X
 }
-int nr_set_lds_limit(int waves, int lanes, int h_lds, size_t bytes) {
-#define X(w, l) if (waves == w && lanes == l) return hipFuncSetAttribute(h_lds ? (const void*)k_nr_wtree<w, l, true> : (const void*)k_nr_wtree<w, l, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
+int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, size_t bytes) {
+#define X(w, l) if (waves == w && lanes == l) return hipFuncSetAttribute(h_lds && g_lds ? (const void*)k_nr_tree<w, l, true, true> : h_lds ? (const void*)k_nr_tree<w, l, true, false> : (const void*)k_nr_tree<w, l, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
   NR_FOR_EACH(X)
 #undef X
   return -2;   // unsupported geometry

@@ -10,13 +10,15 @@ namespace mapdn {
 enum { MODE_STEP = 0, MODE_RESET = 1, MODE_SOLVE = 2 };
 enum { STREAM_PV = 0, STREAM_LOAD_P = 1, STREAM_LOAD_Q = 2, STREAM_ACTION = 3, STREAM_START = 4 };
 
-// NR global scratch `nrbuf` ("rows" of Bp doubles, env-minor), three regions:
-//   factor blocks  [nblk][NBF]   one block per (worker,row) step: the LU factors h0 h1 G0..G3 written in
-//                                the forward sweep and read back in the backward sweep by the same worker
-//   Sbus           [n][2]        per elimination position: Re/Im of the scheduled injection (k_inject)
-//   Vout           [n+1][4]      per position (n == slack): e f |V| angle — the solution (k_nr_wtree)
-// Voltages, Sbus and everything that crosses workers live in LDS during the solve.
-enum { NB_H0 = 0, NB_H1, NB_G0, NB_G1, NB_G2, NB_G3, NBF };
+// NR global scratch `nrbuf` (env-minor), three regions:
+//   factor blocks  [nblk][NBP] pair rows (Bp x 16 bytes)  one block per (worker,row) step: the LU factors (G0,G1)
+//                                (G2,G3) (h0,h1) written in the forward sweep and read back in the backward sweep by the
+//                                same worker — only for the factors that do not fit in LDS (nr_h_lds / nr_g_lds)
+//   Sbus           [nblk] pair rows   (Re, Im) of the scheduled injection, stored in SCHEDULE order (k_inject writes
+//                                entry sb_index[k]; the NR workers prefetch theirs by (worker,row)); idle steps stay 0
+//   Vout           [n+1][4] rows of Bp doubles   per position (n == slack): e f |V| angle — the solution (k_nr_tree)
+// Voltages and everything that crosses workers live in LDS during the solve.
+enum { NB_G01 = 0, NB_G23, NB_H, NBP };
 enum { VO_E = 0, VO_F, VO_VM, VO_VA, VOF };
 
 // Everything a kernel needs, passed by value (kernarg segment -> scalar loads).
@@ -51,11 +53,12 @@ struct Dev {
   uint8_t *done, *pending, *active, *commit, *bad_start;
   int64_t* adv_row; uint32_t* adv_draw;
   // ---- NR scratch (see NB_* / VO_*): row offsets of the Sbus and Vout regions
-  double* nrbuf; uint32_t nrbuf_bytes; uint32_t r_sbus, r_vout;
+  double* nrbuf; uint32_t nrbuf_bytes; uint32_t sb_off, r_vout;   // sb_off: byte offset of the Sbus region
+  const int32_t* sb_index;                                           // [n] Sbus entry (schedule step) of elimination position k
   int32_t* iters; uint8_t* conv;
   // ---- NR schedule (k_nr_wtree): W waves per workgroup, L envs per workgroup (64/L lane-group workers per wave), R rows
-  int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots, nr_nclist, nr_h_lds, nr_line_lds;
-  const StepRec* sched; const int32_t* clist;
+  int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots, nr_nclist, nr_h_lds, nr_g_lds, nr_line_lds;
+  const StepRec* sched; uint32_t sched_bytes; const int32_t* clist;
   const double* flat; uint32_t flat_bytes;   // Schedule::flat, [Wt][R][FLAT_N]
   // a Newton step whose largest component (|dtheta|, |d|V|/|V||) is below this predicts convergence: the next
   // forward sweep is first run in its mismatch-only form (k_nr_wtree)
@@ -66,18 +69,17 @@ struct Dev {
 void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,
                    const double* pv, const double* q, hipStream_t st);
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
-int nr_set_lds_limit(int waves, int lanes, int h_lds, size_t bytes);   // -2: (waves, lanes) not instantiated
-// dynamic LDS of k_nr_wtree (W waves, L envs per workgroup => Wt = W*64/L workers): node voltages and
-// Sbus (2 + 2 doubles x (n+2): nodes, slack, trash) per env, contribution slots (8 doubles/env), x slots (2 doubles/env),
-// verdict bytes, step-size partials (64*W doubles), the Wt*R step records, overflow child list (padded to
+int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, size_t bytes);   // -2: (waves, lanes) not instantiated
+// dynamic LDS of k_nr_tree (W waves, L envs per workgroup => Wt = W*64/L workers), in pair rows of L x 16 bytes:
+// node voltages (n+2: nodes, slack, trash), h (n+2) and G (2(n+2)) when resident, contribution slots (4 rows each),
+// x slots (1 row each); then verdict bytes, step-size partials (64*W doubles), overflow child list (padded to
 // 16 bytes), and — when they fit — the LineFlow constants of net.line for the fused res_line epilogue
 __host__ __device__ static inline size_t nr_line_bytes(int n_line) { return ((size_t)n_line * sizeof(LineFlow) + 15) & ~(size_t)15; }
 // The epilogue's partial sums (10 x 64*W doubles) re-use the contribution slots, so cslots >= nr_min_cslots(W, L).
 static inline int nr_min_cslots(int W, int L) { return (10 * 64 * W + 8 * L - 1) / (8 * L); }
-static inline size_t nr_lds_bytes(int W, int L, int n, int cslots, int xslots, int R, int nclist, int h_lds, int n_line_lds) {
-  const size_t Wt = (size_t)W * (64 / L);
-  return ((size_t)((h_lds ? 6 : 4) * (n + 2)) + (size_t)cslots * 8 + (size_t)xslots * 2) * (size_t)L * sizeof(double) + (size_t)W * 64 +
-         (size_t)64 * W * sizeof(double) + Wt * R * sizeof(StepRec) + (size_t)((nclist + 3) & ~3) * sizeof(int32_t) +
+static inline size_t nr_lds_bytes(int W, int L, int n, int cslots, int xslots, int nclist, int h_lds, int g_lds, int n_line_lds) {
+  const size_t rows = (size_t)(n + 2) * (1 + (h_lds ? 1 : 0) + (g_lds ? 2 : 0)) + (size_t)cslots * 4 + (size_t)xslots;
+  return rows * (size_t)L * 16 + (size_t)W * 64 + (size_t)64 * W * sizeof(double) + (size_t)((nclist + 3) & ~3) * sizeof(int32_t) +
          nr_line_bytes(n_line_lds);
 }
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);

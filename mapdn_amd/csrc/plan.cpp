@@ -252,9 +252,10 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   return MAPDN_OK;
 }
 
-void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots) {
+void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw) {
   const int n = P.n;
-  S.W = W; S.steps.clear(); S.clist.clear();
+  if (Sw < 1 || W % Sw) Sw = 1;
+  S.W = W; S.S = Sw; S.steps.clear(); S.clist.clear();
   std::vector<std::vector<int>> children(n + 1);
   for (int k = 0; k < n; ++k) children[P.par[k]].push_back(k);     // ascending k
   std::vector<int> depth(n + 1, 0);
@@ -349,20 +350,26 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots) {
   // zero + trash slots
   const uint32_t c_zero = (uint32_t)S.n_cslots, c_trash = c_zero + 1; S.n_cslots += 2;
   const uint32_t x_zero = (uint32_t)S.n_xslots, x_trash = x_zero + 1; S.n_xslots += 2;
+  S.step_of_node.assign(n + 1, -1);
   for (int w = 0; w < W; ++w)
     for (int r = 0; r < R; ++r) {
       StepRec& T = S.steps[(size_t)w * R + r];
       const int k = rows[r][w];
       T = StepRec{};
-      T.k = n + 1; T.p = n;                       // idle: trash node, slack parent
+      T.kp = (uint32_t)(n + 1) | ((uint32_t)n << 16);   // idle: trash node, slack parent
       T.slots = c_trash | (x_trash << 10) | (x_zero << 20);
       T.chs = c_zero | (c_zero << 10) | (c_zero << 20);
+      // An idle step works on the trash node as if it hung off the slack by a line of admittance 1 - 1j with no load:
+      // mismatch exactly 0, a regular 2x2 pivot, Newton step exactly 0 — every value it leaves in the carry registers
+      // is finite (the kernel masks carries by a 0/1 factor, and 0 * NaN would poison the next live step)
+      T.ykk[0] = 1.0; T.ykk[1] = -1.0; T.ykp[0] = -1.0; T.ykp[1] = 1.0; T.ypk[0] = -1.0; T.ypk[1] = 1.0;
       if (k < 0) continue;
+      S.step_of_node[k] = w * R + r;
       const double* c = &P.yc[(size_t)k * 8];
       T.ykk[0] = c[0]; T.ykk[1] = c[1]; T.ykp[0] = c[2]; T.ykp[1] = c[3]; T.ypk[0] = c[4]; T.ypk[1] = c[5];
       T.cks[0] = c[6]; T.cks[1] = c[7];
       const int p = P.par[k];
-      T.k = k; T.p = p;
+      T.kp = (uint32_t)k | ((uint32_t)p << 16);
       uint32_t f = S_LIVE, os = c_trash, xsl = x_trash, pxs = x_zero;
       if (p == n) f |= S_PARENT_ROOT;
       else if (carry_out[k]) f |= S_CARRY_OUT;
@@ -373,12 +380,27 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots) {
       for (int ch : children[k]) if (ch != cc) kids.push_back(oslot[ch]);
       uint32_t ch3[3] = {c_zero, c_zero, c_zero};
       for (size_t j = 0; j < kids.size() && j < 3; ++j) ch3[j] = (uint32_t)kids[j];
-      T.chs = ch3[0] | (ch3[1] << 10) | (ch3[2] << 20);
-      T.cptr = (int32_t)S.clist.size();
+      const uint32_t cptr = (uint32_t)S.clist.size();
       for (size_t j = 3; j < kids.size(); ++j) S.clist.push_back(kids[j]);
       if (xslot[k] >= 0) { f |= S_X_OUT; xsl = (uint32_t)xslot[k]; }
-      T.slots = os | (xsl << 10) | (pxs << 20);
-      T.flags = f | ((uint32_t)kids.size() << 16);
+      T.slots = os | (xsl << 10) | (pxs << 20) | (((cptr >> 8) & 3u) << 30);
+      T.chs = ch3[0] | (ch3[1] << 10) | (ch3[2] << 20) | (((cptr >> 10) & 3u) << 30);
+      T.flags = f | ((uint32_t)std::min<size_t>(kids.size(), 255) << 16) | ((cptr & 255u) << 24);
+    }
+  // wave-uniform hints: OR / max over the Sw workers that share a wavefront, per row
+  for (int w0 = 0; w0 < W; w0 += Sw)
+    for (int r = 0; r < R; ++r) {
+      uint32_t gmax = 0, any = 0;
+      for (int w = w0; w < w0 + Sw; ++w) {
+        const StepRec& T = S.steps[(size_t)w * R + r];
+        if (!(T.flags & S_LIVE)) continue;
+        gmax = std::max(gmax, std::min<uint32_t>((T.flags >> 16) & 255u, 3u));
+        if (T.flags & S_SCRATCH_OUT) any |= SU_W_ANY;
+        if (T.flags & S_X_OUT) any |= SU_XW_ANY;
+        if ((T.flags & S_SCRATCH_OUT)) any |= SU_XR_ANY;       // a non-carried child of a real parent reads the parent's x slot
+        if (T.cks[0] != 0.0 || T.cks[1] != 0.0) any |= SU_SLACK_ANY;
+      }
+      for (int w = w0; w < w0 + Sw; ++w) S.steps[(size_t)w * R + r].flags |= (gmax << SU_GMAX_SHIFT) | any;
     }
   if (S.clist.empty()) S.clist.push_back(0);
   // ---- flat-start factorisation (same formulas as k_nr_wtree's forward step with V == vroot everywhere)

@@ -32,21 +32,21 @@ enum : int32_t {
   G_P = 7, G_Q = 8, G_VA_DEG = 9, G_NKIND = 10
 };
 
-// One step of one NR worker: 96 bytes, staged in LDS by the kernel and read per lane (6 x
-// ds_read_b128).  Every slot / node index is always valid: the host substitutes a ZERO slot for
-// absent children / parents and a TRASH slot or node for outputs nobody reads, so the kernel's
-// step body is branch-free.  flags: S_* in the low 16 bits, number of children in the high 16.
+// One step of one NR worker: 80 bytes in global memory, addressed by (worker, row) alone and therefore prefetched
+// by the kernel two rows ahead with no dependent address (5 x buffer_load_dwordx4, the 16 lanes of a worker read the
+// same record).  Every slot / node index is always valid: the host substitutes a ZERO slot for absent children /
+// parents and a TRASH slot or node for outputs nobody reads, so the kernel's step body is branch-free per lane.
+//   flags : S_* bits 0-5 | wave-uniform hints bits 6-10 (see SU_*) | number of slot children << 16 | cptr bits 0-7 << 24
+//   slots : oslot | xslot << 10 | pxslot << 20 (contribution / x slots this node writes, parent's x slot) | cptr bits 8-9 << 30
+//   chs   : ch0 | ch1 << 10 | ch2 << 20 (contribution slots of the first three slot children, canonical order) | cptr bits 10-11 << 30
+//   kp    : node position | parent position << 16   (idle step: trash node n+1; no parent: slack position n with Y = 0)
+// cptr = start of the overflow child list (slot children 3..) in Schedule::clist.
 struct StepRec {
+  uint32_t flags, slots, chs, kp;
   double ykk[2], ykp[2], ypk[2];   // Y_kk, Y_k,parent, Y_parent,k (elimination parent; 0 for elimination roots)
   double cks[2];                   // Y_k,slack * V_slack (0 unless k neighbours the slack)
-  uint32_t flags;
-  uint32_t slots;   // oslot | xslot << 10 | pxslot << 20 : contribution / x slots this node writes, parent's x slot
-  uint32_t chs;     // ch0 | ch1 << 10 | ch2 << 20 : contribution slots of the first three children (canonical order)
-  int32_t cptr;     // overflow list (children 3..) in Schedule::clist
-  int32_t k, p;     // node / parent position (idle step: trash node n+1; no parent: slack position n with Y = 0)
-  int32_t pad[2];
 };
-static_assert(sizeof(StepRec) == 96, "StepRec must be 96 bytes (6 x ds_read_b128)");
+static_assert(sizeof(StepRec) == 80, "StepRec must be 80 bytes (5 x dwordx4)");
 
 // schedule-step flags
 enum : uint32_t {
@@ -56,13 +56,24 @@ enum : uint32_t {
   S_SCRATCH_OUT = 8u,    // own contribution goes to a real LDS slot (parent gathers it)
   S_X_OUT = 16u,         // backward sweep: x_k goes to a real LDS slot (some child reads it)
   S_LIVE = 32u,          // not an idle step
+  // wave-uniform hints: the same value in the records of all workers of one wavefront in one row, so the kernel can
+  // skip LDS traffic that would only move zeros / trash (it reads them with readfirstlane)
+  SU_GMAX_SHIFT = 6u,    // bits 6-7: max number of slot children over the wave's workers, saturated at 3
+  SU_W_ANY = 256u,       // some worker of the wave writes a real contribution slot
+  SU_XW_ANY = 512u,      // backward: some worker writes a real x slot
+  SU_XR_ANY = 1024u,     // backward: some worker reads its parent's x from a slot
+  SU_SLACK_ANY = 2048u,  // some worker's node neighbours the slack (cks != 0)
 };
 
 struct Schedule {
-  int32_t W = 1, R = 0;             // waves per env group, rows
+  int32_t W = 1, R = 0;             // workers per env group, rows
+  int32_t S = 1;                    // workers per wavefront (64 / envs per workgroup): granularity of the SU_* hints
   std::vector<StepRec> steps;       // [W][R]
+  std::vector<int32_t> step_of_node;  // [n + 1]: index w * R + r of the step that eliminates node k (slack: -1); the
+                                      // scheduled injection Sbus is stored in this order (k_inject writes, the NR kernel
+                                      // prefetches it by (worker, row) like the records)
   std::vector<int32_t> clist;       // LDS slots of the children to gather (canonical order: chain child first, then ascending)
-  // LDS slots (reused by interval colouring): 8 resp. 2 doubles per env each; the last two of each kind
+  // LDS slots (reused by interval colouring): 4 resp. 1 pairs of doubles per env each; the last two of each kind
   // are the ZERO slot (n-2) and the TRASH slot (n-1)
   int32_t n_cslots = 0, n_xslots = 0;
   // Flat-start constants, [W][R][FLAT_N] doubles: at the flat start every voltage equals the slack set-point, so
@@ -114,6 +125,7 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& out,
 // the same wave and receives the contribution through registers.  The sum order of children is
 // canonical (chain child first, then ascending position) and therefore independent of W.
 // min_cslots: lower bound on the number of contribution slots (the kernel's epilogue re-uses that LDS region)
-void build_schedule(const Plan& P, int W, Schedule& out, int min_cslots = 0);
+// S: workers per wavefront (only sets the granularity of the wave-uniform SU_* hints).
+void build_schedule(const Plan& P, int W, Schedule& out, int min_cslots = 0, int S = 1);
 
 }  // namespace mapdn
