@@ -264,7 +264,7 @@ def main():
     torch.cuda.synchronize(dev)
     nr_ms, nr_launches = env.nr_time_ms()
     env.nr_timing(False)
-    kname = env.nr_kernel_name() if hasattr(env, "nr_kernel_name") else "k_nr_wtree"
+    kname = "k_nr_tree"
 
     if rank == 0:
         n_gpus = world

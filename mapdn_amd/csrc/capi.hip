@@ -70,14 +70,20 @@ static int dupload(mapdn_handle* h, const T** p, const std::vector<T>& v) {
   return MAPDN_OK;
 }
 
-// NR launch geometry for a padded batch of Bp envs on a net with n non-slack buses (MI355X: 256 CUs
-// x 4 SIMDs).  Tuned on case33/141/322 (tools/sweep_nr.sh): ~8 workers per env is the knee of the
-// Hu schedule for feeders of 100-300 buses; keep >= ~512 workgroups while envs per workgroup <= 64.
-static void choose_nr_geometry(int Bp, int n, int& W, int& L) {
-  (void)Bp;
-  if (n < 48) { W = 1; L = 16; }        // small feeders: 4 workers are enough
-  else if (n < 200) { W = 2; L = 16; }  // 8 workers
-  else { W = 2; L = 8; }                // 16 workers, LDS holds 8 envs of a ~320-bus feeder
+// NR launch geometry for a padded batch of Bp envs on a net with n non-slack buses (MI355X: 256 CUs x 4 SIMDs, one
+// wave per SIMD is all a 16-env workgroup can offer).  Measured on case33/141/322 (tools/r02_nr_sweep.sh,
+// profiles/r02_nr_geometry_*.txt):
+//   * a batch that gives every CU at most one workgroup is latency-bound: spread each env over 16 workers on all four
+//     SIMDs (W = 4) and keep everything the solve touches in LDS ("fat");
+//   * a bigger batch is throughput-bound: 8 workers (W = 2) and only the voltages + hand-off slots in LDS ("lean",
+//     ~55 KB), so that two or three workgroups share a CU and hide each other's latency (1.5x the env rate of fat).
+static void choose_nr_geometry(int Bp, int n, int n_cu, int& W, int& L, int& lean) {
+  lean = 0;
+  if (n < 48) { W = 1; L = 16; }                  // small feeders: 4 workers are enough
+  else if (n < 200) {
+    L = 16;
+    if (Bp / L > n_cu) { W = 2; lean = 1; } else W = 4;
+  } else { W = 4; L = 8; }                        // 32 workers; LDS holds 8 envs of a ~320-bus feeder
 }
 
 extern "C" {
@@ -190,8 +196,13 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   // workers, so Wt = W*64/L workers eliminate independent subtrees of every env concurrently.
   // Small batches get few envs per workgroup (many workgroups, all lanes busy with intra-env
   // parallelism); big batches get L = 64 (pure env parallelism).  Override: MAPDN_NR_WAVES / MAPDN_NR_LANES.
-  int W, L;
-  choose_nr_geometry(d.Bp, P.n, W, L);
+  int W, L, lean;
+  {
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, device));
+    choose_nr_geometry(d.Bp, P.n, prop.multiProcessorCount, W, L, lean);
+  }
+  if (const char* s = getenv("MAPDN_NR_LEAN")) lean = atoi(s) ? 1 : 0;
   if (const char* s = getenv("MAPDN_NR_WAVES")) W = atoi(s);
   if (const char* s = getenv("MAPDN_NR_LANES")) L = atoi(s);
   if (!(W == 1 || W == 2 || W == 4 || W == 8) || !(L == 32 || L == 16 || L == 8)) {
@@ -202,20 +213,23 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
   const int ncl = (int)h->sched.clist.size();
   if (ncl > 4095) { h->err = "NR schedule: more than 4095 overflow children (junctions with > 3 non-chain children)"; return MAPDN_E_INVALID; }
-  // Optional LDS residents, in order of benefit: the h factors, the net.line constants of the fused res_line epilogue,
-  // then the G factors (with all three the solve state never leaves the chip; what does not fit goes to L2-resident
-  // global scratch, read back by the worker that wrote it)
-  auto lds_for = [&](int hl, int gl, int ll) { return nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, ncl, hl, gl, ll ? P.n_line : 0); };
+  // Optional LDS residents, in order of benefit: the h factors, the step records, the flat-start constants, the net.line
+  // constants of the fused res_line epilogue, then the G factors (with everything resident the solve state never leaves
+  // the chip; what does not fit stays in / goes to L2-resident global memory).  In lean mode (big batches, see
+  // choose_nr_geometry) only the voltages and hand-off slots are resident, so that several workgroups share a CU.
+  const int R_ = h->sched.R;
+  auto lds_for = [&](int hl, int gl, int ll, int rl, int fl) {
+    return nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, ncl, hl, gl, ll ? P.n_line : 0, rl ? R_ : 0, fl ? R_ : 0); };
   const size_t LDS_MAX = 160 * 1024;
-  int h_lds = lds_for(1, 0, 0) <= LDS_MAX ? 1 : 0;
-  if (const char* s = getenv("MAPDN_NR_H_LDS")) h_lds = atoi(s) ? 1 : 0;
-  int line_lds = (P.n_line > 0 && lds_for(h_lds, 0, 1) <= LDS_MAX) ? 1 : 0;
-  if (const char* s = getenv("MAPDN_NR_LINE_LDS")) line_lds = (atoi(s) && P.n_line > 0) ? 1 : 0;
-  int g_lds = (h_lds && lds_for(1, 1, line_lds) <= LDS_MAX) ? 1 : 0;
-  if (const char* s = getenv("MAPDN_NR_G_LDS")) g_lds = (atoi(s) && h_lds) ? 1 : 0;
-  const size_t lds_need = lds_for(h_lds, g_lds, line_lds);
+  auto opt = [&](const char* name, int dflt) { const char* s = getenv(name); return s ? (atoi(s) ? 1 : 0) : dflt; };
+  int h_lds = opt("MAPDN_NR_H_LDS", !lean && lds_for(1, 0, 0, 0, 0) <= LDS_MAX);
+  int rec_lds = opt("MAPDN_NR_REC_LDS", !lean && lds_for(h_lds, 0, 0, 1, 0) <= LDS_MAX);
+  int flat_lds = opt("MAPDN_NR_FLAT_LDS", !lean && lds_for(h_lds, 0, 0, rec_lds, 1) <= LDS_MAX);
+  int line_lds = opt("MAPDN_NR_LINE_LDS", !lean && P.n_line > 0 && lds_for(h_lds, 0, 1, rec_lds, flat_lds) <= LDS_MAX) && P.n_line > 0;
+  int g_lds = opt("MAPDN_NR_G_LDS", !lean && h_lds && lds_for(1, 1, line_lds, rec_lds, flat_lds) <= LDS_MAX) && h_lds;
+  const size_t lds_need = lds_for(h_lds, g_lds, line_lds, rec_lds, flat_lds);
   if (lds_need > LDS_MAX) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
-  d.nr_waves = W; d.nr_lanes = L; d.nr_h_lds = h_lds; d.nr_g_lds = g_lds; d.nr_line_lds = line_lds;
+  d.nr_waves = W; d.nr_lanes = L; d.nr_h_lds = h_lds; d.nr_g_lds = g_lds; d.nr_line_lds = line_lds; d.nr_rec_lds = rec_lds; d.nr_flat_lds = flat_lds;
   h->lds_bytes = lds_need;
   // 1e-7: with quadratic convergence the mismatch after such a step is ~|Y| dx^2 << tol, so a wrong prediction
   // (which costs one extra mismatch-only sweep for that workgroup) practically never happens

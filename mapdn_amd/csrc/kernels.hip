@@ -286,6 +286,10 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
                                                              // contribution slots, dead once the solve is over (host: cslots >= nr_min_cslots)
   int32_t* s_clist = (int32_t*)(s_ok + 64 * W + 64 * W * sizeof(double));
   double* s_lines = (double*)(s_clist + ((d.nr_nclist + 3) & ~3));   // LineFlow rows of net.line (9 doubles each) when d.nr_line_lds
+  // step records (80 B) and flat-start constants (96 B) of all workers, when they fit (d.nr_rec_lds / d.nr_flat_lds): a
+  // worker's 16 lanes read the same 16 bytes (LDS broadcast)
+  char* s_rec = (char*)s_lines + (d.nr_line_lds ? nr_line_bytes(d.n_line) : 0);
+  char* s_flat = s_rec + (d.nr_rec_lds ? (size_t)Wt * R * sizeof(StepRec) : 0);
   {  // LDS init: flat start (runpp init="auto": every bus at the slack set-point), ZERO slots, small tables
     const d2 v0 = {vroot, 0.0}, z2 = {0.0, 0.0};
     for (unsigned k = t; k < n + 2; k += Wt) sV[(size_t)k * L] = v0;
@@ -308,6 +312,28 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         if (base + 3 * 64u * W < nl4) ld[base + 3 * 64u * W] = a3;
       }
     }
+    // Global -> LDS staging in batches: the loads of a batch are unconditional (index clamped) and issued back to back,
+    // only the LDS stores are predicated — a load-per-iteration loop would pay the full memory latency once per element
+    auto stage = [&](const void* src_, char* dst_, unsigned n16) {
+      const uint4* src = (const uint4*)src_;
+      uint4* dst = (uint4*)dst_;
+      constexpr unsigned NT = 64u * W;
+      for (unsigned base = threadIdx.x; base < n16; base += 8 * NT) {
+        const uint4 r0 = src[base], r1 = src[min(base + NT, n16 - 1)], r2 = src[min(base + 2 * NT, n16 - 1)], r3 = src[min(base + 3 * NT, n16 - 1)],
+                    r4 = src[min(base + 4 * NT, n16 - 1)], r5 = src[min(base + 5 * NT, n16 - 1)], r6 = src[min(base + 6 * NT, n16 - 1)],
+                    r7 = src[min(base + 7 * NT, n16 - 1)];
+        dst[base] = r0;
+        if (base + NT < n16) dst[base + NT] = r1;
+        if (base + 2 * NT < n16) dst[base + 2 * NT] = r2;
+        if (base + 3 * NT < n16) dst[base + 3 * NT] = r3;
+        if (base + 4 * NT < n16) dst[base + 4 * NT] = r4;
+        if (base + 5 * NT < n16) dst[base + 5 * NT] = r5;
+        if (base + 6 * NT < n16) dst[base + 6 * NT] = r6;
+        if (base + 7 * NT < n16) dst[base + 7 * NT] = r7;
+      }
+    };
+    if (d.nr_rec_lds) stage(d.sched, s_rec, Wt * (unsigned)R * (unsigned)(sizeof(StepRec) / 16));
+    if (d.nr_flat_lds) stage(d.flat, s_flat, Wt * (unsigned)R * (unsigned)(FLAT_N * 8 / 16));
   }
 #ifdef MAPDN_NR_STAMPS
   const bool stamp_on = blockIdx.x == 0 && threadIdx.x == 0;
@@ -336,17 +362,35 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // address; the scalar row offset is the only thing that changes (prefetches past the ends are clamped, never
   // skipped: every step issues the same VMEM instructions and the compiler's s_waitcnt counts stay exact)
   auto row_s = [&](int row, unsigned stride) { return __builtin_amdgcn_readfirstlane((unsigned)row * stride); };
+  const bool recL = d.nr_rec_lds != 0, flatL = d.nr_flat_lds != 0;     // wave-uniform
+  const char* recT = s_rec + voT;                  // this worker's records / flat steps in LDS
+  const char* flatT = s_flat + voF;
+  auto load_ix = [&](int row) -> u32x4 {
+    if (recL) return *(const u32x4*)(recT + (unsigned)row * TB);
+    return bldu4(rsT, voT, row_s(row, TB));
+  };
   auto load_rec = [&](int row, Rec& o) {
-    const unsigned st = row_s(row, TB);
-    o.ix = bldu4(rsT, voT, st);
-    o.ykk = bld2(rsT, voT + 16u, st); o.ykp = bld2(rsT, voT + 32u, st); o.ypk = bld2(rsT, voT + 48u, st); o.cks = bld2(rsT, voT + 64u, st);
+    if (recL) {
+      const char* p = recT + (unsigned)row * TB;
+      o.ix = *(const u32x4*)p;
+      o.ykk = *(const d2*)(p + 16); o.ykp = *(const d2*)(p + 32); o.ypk = *(const d2*)(p + 48); o.cks = *(const d2*)(p + 64);
+    } else {
+      const unsigned st = row_s(row, TB);
+      o.ix = bldu4(rsT, voT, st);
+      o.ykk = bld2(rsT, voT + 16u, st); o.ykp = bld2(rsT, voT + 32u, st); o.ypk = bld2(rsT, voT + 48u, st); o.cks = bld2(rsT, voT + 64u, st);
+    }
     o.sb = bld2(rs, voS, row_s(row, pb));
   };
   auto load_recf = [&](int row, RecF& o) {
-    const unsigned sf = row_s(row, FB);
-    o.ix = bldu4(rsT, voT, row_s(row, TB));
-    o.s = bld2(rsF, voF + FL_SR * 8u, sf); o.i01 = bld2(rsF, voF + FL_I0 * 8u, sf); o.i23 = bld2(rsF, voF + FL_I2 * 8u, sf);
-    o.ap = bld2(rsF, voF + FL_APR * 8u, sf);
+    o.ix = load_ix(row);
+    if (flatL) {
+      const char* p = flatT + (unsigned)row * FB;
+      o.s = *(const d2*)(p + FL_SR * 8); o.i01 = *(const d2*)(p + FL_I0 * 8); o.i23 = *(const d2*)(p + FL_I2 * 8); o.ap = *(const d2*)(p + FL_APR * 8);
+    } else {
+      const unsigned sf = row_s(row, FB);
+      o.s = bld2(rsF, voF + FL_SR * 8u, sf); o.i01 = bld2(rsF, voF + FL_I0 * 8u, sf); o.i23 = bld2(rsF, voF + FL_I2 * 8u, sf);
+      o.ap = bld2(rsF, voF + FL_APR * 8u, sf);
+    }
     o.sb = bld2(rs, voS, row_s(row, pb));
   };
   auto uni = [&](unsigned x) { return __builtin_amdgcn_readfirstlane(x); };
@@ -388,7 +432,8 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const Rec& T = Tq[u % 3];
         const d2 vk = vkq[u % 3], vp = vpq[u % 3];
         const uint32_t fl = T.ix.x, slots = T.ix.y, chs = T.ix.z, kp = T.ix.w;
-        const unsigned gmax = uni((fl >> SU_GMAX_SHIFT) & 3u);
+        const uint32_t flu = uni(fl);              // the wave-uniform hints, once per row on the scalar unit
+        const unsigned gmax = (flu >> SU_GMAX_SHIFT) & 3u;
         // (1) gathers first: they depend on the previous row's writes and head the critical path
         d2 g0[4], g1[4];                           // loaded iff gmax >= 1 / 2 (never read otherwise)
         constexpr int NP = K == 0 ? 4 : 1;         // pairs that travel
@@ -420,7 +465,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const double v2 = ek * ek + fk * fk;
         const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
         double aks_r = 0.0, aks_i = 0.0;           // a constant-voltage neighbour only feeds S_k
-        if (uni(fl & SU_SLACK_ANY)) { aks_r = ek * T.cks.x + fk * T.cks.y; aks_i = fk * T.cks.x - ek * T.cks.y; }
+        if (flu & SU_SLACK_ANY) { aks_r = ek * T.cks.x + fk * T.cks.y; aks_i = fk * T.cks.x - ek * T.cks.y; }
         const double base_r = (akk_r + aks_r) + akp_r, base_i = (akk_i + aks_i) + akp_i;
         const double m = (fl & S_CARRY_IN) ? 1.0 : 0.0;    // register carry (same worker, previous row) masked by a 0/1 factor
         SCHED_FENCE();
@@ -477,7 +522,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
           // contribution to the parent: registers (consumed only if the next step has S_CARRY_IN) and the
           // LDS slot (TRASH unless S_SCRATCH_OUT; skipped when no worker of the wave has a real slot)
           cS0 = apk_r; cS1 = apk_i; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
-          if (uni(fl & SU_W_ANY)) {
+          if (flu & SU_W_ANY) {
             d2* c = cs + (size_t)(slots & 1023u) * (4 * L);
             c[0] = d2{apk_r, apk_i}; c[L] = d2{s0, s1}; c[2 * L] = d2{s2, s3}; c[3 * L] = d2{t0, t1};
           }
@@ -488,7 +533,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
           else { bst2(d2{G0, G1}, rs, voB + NB_G01 * pb, sbF); bst2(d2{G2, G3}, rs, voB + NB_G23 * pb, sbF); }
         } else {
           cS0 = apk_r; cS1 = apk_i;
-          if (uni(fl & SU_W_ANY)) cs[(size_t)(slots & 1023u) * (4 * L)] = d2{apk_r, apk_i};
+          if (flu & SU_W_ANY) cs[(size_t)(slots & 1023u) * (4 * L)] = d2{apk_r, apk_i};
         }
         if (W > 1) lds_barrier();
         STAMP(100 + K);
@@ -510,7 +555,8 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         if (r >= R) break;
         const RecF& T = Tq[u % 3];
         const uint32_t fl = T.ix.x, slots = T.ix.y, chs = T.ix.z, kp = T.ix.w;
-        const unsigned gmax = uni((fl >> SU_GMAX_SHIFT) & 3u);
+        const uint32_t flu = uni(fl);
+        const unsigned gmax = (flu >> SU_GMAX_SHIFT) & 3u;
         d2 g0, g1;
         if (gmax >= 1u) g0 = cs[((size_t)(chs & 1023u) * 4 + 3) * L];
         if (gmax >= 2u) g1 = cs[((size_t)((chs >> 10) & 1023u) * 4 + 3) * L];
@@ -539,7 +585,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const double h0 = T.i01.x * r0 + T.i01.y * r1, h1 = T.i23.x * r0 + T.i23.y * r1;
         const double t0 = T.ap.y * h0 + T.ap.x * h1, t1 = T.ap.y * h1 - T.ap.x * h0;
         cR0 = t0; cR1 = t1;
-        if (uni(fl & SU_W_ANY)) cs[((size_t)(slots & 1023u) * 4 + 3) * L] = d2{t0, t1};
+        if (flu & SU_W_ANY) cs[((size_t)(slots & 1023u) * 4 + 3) * L] = d2{t0, t1};
         SCHED_FENCE();
         const unsigned k = kp & 0xffffu;
         if (HL) sH[(size_t)k * L] = d2{h0, h1}; else bst2(d2{h0, h1}, rs, voB + NB_H * pb, row_s(r, bb));
@@ -576,10 +622,13 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     constexpr bool gH = !HL;
     u32x4 ixq[3]; BwdF fq[3];
     auto load_b = [&](int row, u32x4& ix, BwdF& f) {
-      ix = bldu4(rsT, voT, row_s(row, TB));
+      ix = load_ix(row);
       if (gH) f.h = bld2(rs, voB + NB_H * pb, row_s(row, bb));
       if (gG) {
-        if (SRC == 0) { const unsigned sf = row_s(row, FB); f.g01 = bld2(rsF, voF + FL_G0 * 8u, sf); f.g23 = bld2(rsF, voF + FL_G2 * 8u, sf); }
+        if (SRC == 0) {
+          if (flatL) { const char* p = flatT + (unsigned)row * FB; f.g01 = *(const d2*)(p + FL_G0 * 8); f.g23 = *(const d2*)(p + FL_G2 * 8); }
+          else { const unsigned sf = row_s(row, FB); f.g01 = bld2(rsF, voF + FL_G0 * 8u, sf); f.g23 = bld2(rsF, voF + FL_G2 * 8u, sf); }
+        }
         else { const unsigned sb = row_s(row, bb); f.g01 = bld2(rs, voB + NB_G01 * pb, sb); f.g23 = bld2(rs, voB + NB_G23 * pb, sb); }
       }
     };
@@ -592,10 +641,11 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         if (r < 0) break;
         const u32x4 ix = ixq[u % 3];
         const uint32_t fl = ix.x, slots = ix.y;
+        const uint32_t flu = uni(fl);
         const unsigned k = ix.w & 0xffffu;
         // (1) the parent's x (ZERO slot for slack parents), this node's factors and voltage
         d2 q;
-        const bool xr = uni(fl & SU_XR_ANY) != 0;
+        const bool xr = (flu & SU_XR_ANY) != 0;
         if (xr) q = xs[(size_t)((slots >> 20) & 1023u) * L];
         const d2 hh = gH ? fq[u % 3].h : sH[(size_t)k * L];
         const d2 g01 = gG ? fq[u % 3].g01 : sG[(size_t)(2 * k) * L];
@@ -616,7 +666,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const double y0 = hh.x - (g01.x * p0 + g01.y * p1);
         const double y1 = hh.y - (g23.x * p0 + g23.y * p1);
         x0 = y0; x1 = y1;
-        if (uni(fl & SU_XW_ANY)) xs[(size_t)((slots >> 10) & 1023u) * L] = d2{y0, y1};   // TRASH unless S_X_OUT
+        if (flu & SU_XW_ANY) xs[(size_t)((slots >> 10) & 1023u) * L] = d2{y0, y1};   // TRASH unless S_X_OUT
         py0 = y0; py1 = y1; pvk = vk; pk = k; pLive = (fl & S_LIVE) != 0;
         if (W > 1) lds_barrier();
         STAMP(110 + SRC);
@@ -1081,7 +1131,7 @@ void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
   const dim3 grid(d.Bp / d.nr_lanes);
   const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.n, d.nr_cslots, d.nr_xslots, d.nr_nclist, d.nr_h_lds, d.nr_g_lds,
-                                  d.nr_line_lds ? d.n_line : 0);
+                                  d.nr_line_lds ? d.n_line : 0, d.nr_rec_lds ? d.nr_rows : 0, d.nr_flat_lds ? d.nr_rows : 0);
 #define X(w, l) if (d.nr_waves == w && d.nr_lanes == l) { \
     if (d.nr_h_lds && d.nr_g_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, true>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
     else if (d.nr_h_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, false>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \

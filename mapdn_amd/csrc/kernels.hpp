@@ -57,7 +57,7 @@ struct Dev {
   const int32_t* sb_index;                                           // [n] Sbus entry (schedule step) of elimination position k
   int32_t* iters; uint8_t* conv;
   // ---- NR schedule (k_nr_wtree): W waves per workgroup, L envs per workgroup (64/L lane-group workers per wave), R rows
-  int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots, nr_nclist, nr_h_lds, nr_g_lds, nr_line_lds;
+  int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots, nr_nclist, nr_h_lds, nr_g_lds, nr_line_lds, nr_rec_lds, nr_flat_lds;
   const StepRec* sched; uint32_t sched_bytes; const int32_t* clist;
   const double* flat; uint32_t flat_bytes;   // Schedule::flat, [Wt][R][FLAT_N]
   // a Newton step whose largest component (|dtheta|, |d|V|/|V||) is below this predicts convergence: the next
@@ -77,10 +77,13 @@ int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, size_t bytes); 
 __host__ __device__ static inline size_t nr_line_bytes(int n_line) { return ((size_t)n_line * sizeof(LineFlow) + 15) & ~(size_t)15; }
 // The epilogue's partial sums (10 x 64*W doubles) re-use the contribution slots, so cslots >= nr_min_cslots(W, L).
 static inline int nr_min_cslots(int W, int L) { return (10 * 64 * W + 8 * L - 1) / (8 * L); }
-static inline size_t nr_lds_bytes(int W, int L, int n, int cslots, int xslots, int nclist, int h_lds, int g_lds, int n_line_lds) {
+// rec_rows / flat_rows: R when the step records / flat-start constants of all Wt workers are staged in LDS, else 0
+static inline size_t nr_lds_bytes(int W, int L, int n, int cslots, int xslots, int nclist, int h_lds, int g_lds, int n_line_lds,
+                                  int rec_rows, int flat_rows) {
   const size_t rows = (size_t)(n + 2) * (1 + (h_lds ? 1 : 0) + (g_lds ? 2 : 0)) + (size_t)cslots * 4 + (size_t)xslots;
+  const size_t Wt = (size_t)W * (64 / L);
   return rows * (size_t)L * 16 + (size_t)W * 64 + (size_t)64 * W * sizeof(double) + (size_t)((nclist + 3) & ~3) * sizeof(int32_t) +
-         nr_line_bytes(n_line_lds);
+         nr_line_bytes(n_line_lds) + Wt * rec_rows * sizeof(StepRec) + Wt * flat_rows * FLAT_N * sizeof(double);
 }
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);
 void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, hipStream_t st);
