@@ -105,6 +105,13 @@ typedef struct mapdn_env_config {
   int32_t state_space;              /* MAPDN_SS_* mask                                     */
   uint64_t seed;
   int64_t env_id_offset;            /* global id of local env 0 (multi-GPU sharding)       */
+  int32_t auto_reset;               /* 0: a terminated env stays frozen (reward 0, terminated 1) until mapdn_reset — the
+                                       batch analogue of "the caller resets" (models/model.py:204); 1: a terminated env
+                                       starts its next episode by itself on the FOLLOWING mapdn_step call: that call
+                                       ignores its action, performs reset() for it (sampled start, first profile row,
+                                       random initial action; voltage_control_env.py:96-135) and reports reward 0,
+                                       terminated 0, info 0 and mapdn_get_auto_reset_mask() == 1; `terminated` is
+                                       therefore reported exactly once per episode                                  */
 } mapdn_env_config;
 
 typedef struct mapdn_dims_t {
@@ -169,6 +176,9 @@ int mapdn_get_loads(mapdn_handle* h, double* load_p, double* load_q, void* strea
 int mapdn_get_start_rows(mapdn_handle* h, int64_t* start_rows, void* stream);
 
 /* sum_rewards of the running episode (voltage_control_env.py:203) for every env: device f64 [B] */
+/* uint8 [n_envs]: 1 for the envs that the last mapdn_step call (re)started (auto_reset == 1), else 0. */
+int mapdn_get_auto_reset_mask(mapdn_handle* h, uint8_t* mask, void* stream);
+
 int mapdn_get_returns(mapdn_handle* h, double* returns, void* stream);
 
 /* Pure power flow == pp.runpp(net) (voltage_control_env.py:557) on explicit element powers:

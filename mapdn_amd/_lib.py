@@ -30,7 +30,7 @@ EXPORTS = (
     "mapdn_last_error", "mapdn_create", "mapdn_destroy", "mapdn_dims", "mapdn_set_profiles", "mapdn_reset",
     "mapdn_step", "mapdn_get_start_rows", "mapdn_get_returns", "mapdn_get_obs", "mapdn_get_state", "mapdn_get_results", "mapdn_get_loads",
     "mapdn_solve_only", "mapdn_get_ybus_dense", "mapdn_get_obs_index", "mapdn_get_schedule", "mapdn_get_flat_factors", "mapdn_stats", "mapdn_nr_timing",
-    "mapdn_nr_time_ms",
+    "mapdn_nr_time_ms", "mapdn_get_auto_reset_mask",
 )
 
 _pd = C.POINTER(C.c_double)
@@ -59,7 +59,7 @@ class CEnvConfig(C.Structure):
         ("line_weight", C.c_double), ("use_line_weight", C.c_int32), ("use_q_weight", C.c_int32),
         ("v_lower", C.c_double), ("v_upper", C.c_double), ("episode_limit", C.c_int32),
         ("action_low", C.c_double), ("action_high", C.c_double), ("reset_action", C.c_int32),
-        ("state_space", C.c_int32), ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
+        ("state_space", C.c_int32), ("seed", C.c_uint64), ("env_id_offset", C.c_int64), ("auto_reset", C.c_int32),
     ]
 
 
@@ -111,6 +111,7 @@ def load():
     lib.mapdn_step.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.mapdn_get_start_rows.argtypes = [vp, vp, vp]
     lib.mapdn_get_returns.argtypes = [vp, vp, vp]
+    lib.mapdn_get_auto_reset_mask.argtypes = [vp, vp, vp]
     lib.mapdn_get_obs.argtypes = [vp, vp, C.c_int32, vp]
     lib.mapdn_get_state.argtypes = [vp, vp, C.c_int32, vp]
     lib.mapdn_get_results.argtypes = [vp] + [vp] * 7 + [vp]
@@ -203,4 +204,5 @@ def make_cconfig(args: dict, env_id_offset: int = 0) -> CEnvConfig:
     c.state_space = sum(SS_BITS[k] for k in set(ss) if k in SS_BITS)
     c.seed = int(args.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF
     c.env_id_offset = int(env_id_offset)
+    c.auto_reset = int(bool(args.get("auto_reset", False)))
     return c

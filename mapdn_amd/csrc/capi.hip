@@ -115,7 +115,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   d.vroot = P.vroot; d.sn = P.sn_mva; d.tol = P.tol; d.max_it = 10;   // runpp max_iteration="auto" -> 10
   d.yrr0 = P.yrr[0]; d.yrr1 = P.yrr[1];
   d.barrier_type = cfg->barrier_type; d.use_line_weight = cfg->use_line_weight; d.episode_limit = cfg->episode_limit;
-  d.reset_action = cfg->reset_action; d.voltage_weight = cfg->voltage_weight; d.q_weight = cfg->q_weight;
+  d.reset_action = cfg->reset_action; d.auto_reset = cfg->auto_reset ? 1 : 0; d.voltage_weight = cfg->voltage_weight; d.q_weight = cfg->q_weight;
   d.line_weight = cfg->line_weight; d.v_lower = cfg->v_lower; d.v_upper = cfg->v_upper;
   d.action_low = cfg->action_low; d.action_high = cfg->action_high;
   d.seed_lo = (uint32_t)(cfg->seed & 0xffffffffull); d.seed_hi = (uint32_t)(cfg->seed >> 32);
@@ -141,7 +141,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   d.cur_q = d.gbuf + (size_t)r_q * Bp; d.vm = d.gbuf + (size_t)r_vm * Bp; d.va = d.gbuf + (size_t)r_va * Bp;
   d.res_p = d.gbuf + (size_t)r_rp * Bp; d.res_q = d.gbuf + (size_t)r_rq * Bp;
   AL(sum_rewards, 1); AL(steps, 1); AL(start_row, 1); AL(draw, 1); AL(done, 1); AL(pending, 1);
-  AL(active, 1); AL(commit, 1); AL(bad_start, 1); AL(adv_row, 1); AL(adv_draw, 1); AL(iters, 1); AL(conv, 1);
+  AL(active, 1); AL(commit, 1); AL(bad_start, 1); AL(resetting, 1); AL(adv_row, 1); AL(adv_draw, 1); AL(iters, 1); AL(conv, 1);
   {
     std::vector<uint8_t> ones(Bp, 1);
     HIPCHK(h, hipMemcpy(d.done, ones.data(), Bp, hipMemcpyHostToDevice));   // nothing is steppable before reset
@@ -381,7 +381,7 @@ int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, i
   for (int t = 0; t < max_tries; ++t) {
     launch_reset_begin(d, start_rows, t == 0, st);
     launch_advance(d, add_noise, 1, 0, st);
-    launch_inject(d, MODE_RESET, nullptr, MAPDN_F64, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, st);
+    launch_inject(d, MODE_RESET, nullptr, MAPDN_F64, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, add_noise, st);
     nr_launch(h, MODE_RESET, nullptr, nullptr, nullptr, st);
     launch_advance(d, 0, 0, 1, st);              // res_bus commit of the envs that found a solvable start
   }
@@ -400,7 +400,7 @@ int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int3
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   const Dev& d = h->d;
-  launch_inject(d, MODE_STEP, actions, actions_dtype, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, st);
+  launch_inject(d, MODE_STEP, actions, actions_dtype, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, add_noise, st);
   // (Running the profile advance on a side stream beside the NR kernel was measured: the fork/join events
   // cost more than the ~6 us they hide, 29.5 M vs 31.5 M env-steps/s, so the step stays on one stream.)
   nr_launch(h, MODE_STEP, reward, terminated, info, st);
@@ -474,6 +474,14 @@ int mapdn_get_start_rows(mapdn_handle* h, int64_t* start_rows, void* stream) {
   return MAPDN_OK;
 }
 
+int mapdn_get_auto_reset_mask(mapdn_handle* h, uint8_t* mask, void* stream) {
+  if (!h || !mask) return MAPDN_E_INVALID;
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(mask, h->d.resetting, (size_t)h->d.B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MAPDN_OK;
+}
+
 int mapdn_get_returns(mapdn_handle* h, double* returns, void* stream) {
   if (!h || !returns) return MAPDN_E_INVALID;
   NEEDDEV(h);
@@ -496,7 +504,7 @@ int mapdn_solve_only(mapdn_handle* h, const double* p_load, const double* q_load
   launch_to_envminor(d, q_sgen, h->t_q, d.ns, st);
   HIPCHK(h, hipMemsetAsync(d.active, 1, d.B, st));
   if (d.Bp > d.B) HIPCHK(h, hipMemsetAsync(d.active + d.B, 0, d.Bp - d.B, st));
-  launch_inject(d, MODE_SOLVE, nullptr, MAPDN_F64, h->t_pl, h->t_ql, h->t_pv, h->t_q, st);
+  launch_inject(d, MODE_SOLVE, nullptr, MAPDN_F64, h->t_pl, h->t_ql, h->t_pv, h->t_q, 0, st);
   nr_launch(h, MODE_SOLVE, nullptr, nullptr, nullptr, st);
   if (vm_pu) transpose_out(h, d.nrbuf, 1.0, h->vm_row, vm_pu, d.nb, st);
   if (va_degree) transpose_out(h, d.nrbuf, 180.0 / M_PI, h->va_row, va_degree, d.nb, st);

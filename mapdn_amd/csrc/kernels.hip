@@ -52,42 +52,97 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
 //     the q of the sgens on that bus, so q_new is written exactly once.  MODE_SOLVE takes all four
 //     element-power arrays as given (mapdn_solve_only).
 // =================================================================================================
+// episode start row of reset(): hour, day, interval sampled in the order of voltage_control_env.py:111-113 from the
+// env's Philox stream (mapping in oracle/philox.py)
+__device__ __forceinline__ int64_t sample_start_row(const Dev& d, int e, uint32_t draw) {
+  uint32_t x[4];
+  philox4x32_10((uint32_t)(d.env_id_offset + e), draw, STREAM_START, 0u, d.seed_lo, d.seed_hi, x);
+  const int64_t hour = (int64_t)(((uint64_t)x[0] * 24u) >> 32);                        // :384
+  const int64_t day = (int64_t)(((uint64_t)x[1] * (uint64_t)d.n_start_days) >> 32);    // :398
+  const int64_t interval = (int64_t)(((uint64_t)x[2] * (uint64_t)d.per_hour) >> 32);   // :389
+  return interval + hour * d.per_hour + day * d.per_day;                                // :445
+}
+// one column of _set_demand_and_pv (:491-513): table value + std/100 * |N(0,1)|; column j of a stream takes the cosine
+// (even j) or sine (odd j) Box-Muller branch of Philox block j >> 1 — the same numbers k_advance produces pairwise
+__device__ __forceinline__ double profile_value(const Dev& d, int e, int64_t row, uint32_t draw, int stream, int j, int col0, int add_noise) {
+  double v = d.table[(size_t)row * d.ncol + col0 + j];
+  if (add_noise) {
+    uint32_t x[4];
+    philox4x32_10((uint32_t)(d.env_id_offset + e), draw, (uint32_t)stream, (uint32_t)(j >> 1), d.seed_lo, d.seed_hi, x);
+    const double u1 = (u53(x[0], x[1]) + 0.5) * (1.0 / 9007199254740992.0);
+    const double u2 = u53(x[2], x[3]) * (1.0 / 9007199254740992.0);
+    const double r = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincos(2.0 * M_PI * u2, &sn, &cs);
+    v += d.stdv[col0 + j] * fabs(r * ((j & 1) ? sn : cs));
+  }
+  return v;
+}
+
 template <typename AT>
 __global__ void __launch_bounds__(256)
 k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restrict__ pl, const double* __restrict__ ql,
-         const double* __restrict__ pv, const double* __restrict__ qin) {
+         const double* __restrict__ pv, const double* __restrict__ qin, int add_noise) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;                      // 0..n (n == slack: only its sgens' q, no Sbus row)
   if (e >= d.Bp) return;
   bool act = true;
+  // auto_reset: an env that terminated in an earlier call starts its next episode in this one (reset(), :96-135, for
+  // this env alone): new start row, first profile row of the window (+ noise), random initial action — computed here
+  // element by element by the thread of the element's bus, so that every cur_* entry still has exactly one writer
+  bool ar = false;
+  int64_t ar_row = 0;
+  uint32_t draw = 0;
   if (mode != MODE_SOLVE) {
     if (e >= d.B) act = false;
-    else if (mode == MODE_STEP) act = !d.done[e];
-    else act = d.pending[e] != 0;
-    if (k == 0) d.active[e] = act ? 1 : 0;
-    // step(): the next profile row is row `steps` (before the increment, :199 vs :202) of the episode window and
-    // uses the env's current draw counter; queued here, before the solve (frozen envs do not advance)
-    if (k == 0 && mode == MODE_STEP) { d.adv_row[e] = act ? d.start_row[e] + d.steps[e] : -1; d.adv_draw[e] = d.draw[e]; }
+    else if (mode == MODE_STEP) {
+      const bool dn = d.done[e] != 0;
+      ar = dn && d.auto_reset;
+      act = !dn || ar;
+    } else act = d.pending[e] != 0;
+    draw = mode == MODE_STEP ? d.draw[e] : d.adv_draw[e];
+    if (ar) {
+      const int64_t start = sample_start_row(d, e, draw);
+      ar_row = start + 1;                        // t = self.steps == 1 (:100, :473)
+      if (k == 0) d.start_row[e] = start;
+    }
+    if (k == 0) {
+      d.active[e] = act ? 1 : 0;
+      if (mode == MODE_STEP) {
+        d.resetting[e] = ar ? 1 : 0;
+        // step(): the next profile row is row `steps` (before the increment, :199 vs :202) of the episode window and
+        // uses the env's current draw counter; queued here, before the solve (frozen / restarting envs do not advance)
+        d.adv_row[e] = (act && !ar) ? d.start_row[e] + d.steps[e] : -1; d.adv_draw[e] = draw;
+      }
+    }
   }
   double P = 0.0, Q = 0.0;
   for (int i = d.load_ptr[k]; i < d.load_ptr[k + 1]; ++i) {
-    const size_t o = (size_t)d.load_idx[i] * d.Bp + e;
-    P += pl[o]; Q += ql[o];
+    const int li = d.load_idx[i];
+    const size_t o = (size_t)li * d.Bp + e;
+    if (ar) {
+      const double p = profile_value(d, e, ar_row, draw, STREAM_LOAD_P, li, d.ns, add_noise);
+      const double q = profile_value(d, e, ar_row, draw, STREAM_LOAD_Q, li, d.ns + d.nl, add_noise);
+      d.cur_pl[o] = p; d.cur_ql[o] = q;
+      P += p; Q += q;
+    } else { P += pl[o]; Q += ql[o]; }
   }
   for (int i = d.sgen_ptr[k]; i < d.sgen_ptr[k + 1]; ++i) {
     const int j = d.sgen_idx[i];
     const size_t o = (size_t)j * d.Bp + e;
-    const double p = pv[o];
+    double p;
+    if (ar) { p = profile_value(d, e, ar_row, draw, STREAM_PV, j, 0, add_noise); d.cur_pv[o] = p; d.cur_q[o] = 0.0; }
+    else p = pv[o];
     double q;
     if (mode == MODE_SOLVE) q = qin[o];
     else if (!act) q = d.q_new[o];
     else {
       const double sm = d.smax[j];
       const double lim = sqrt(sm * sm - p * p);
-      if (mode == MODE_STEP) q = lim * (double)actions[(size_t)e * d.ns + j];
+      if (mode == MODE_STEP && !ar) q = lim * (double)actions[(size_t)e * d.ns + j];
       else if (d.reset_action) {
         uint32_t x[4];
-        philox4x32_10((uint32_t)(d.env_id_offset + e), d.adv_draw[e], STREAM_ACTION, (uint32_t)(j >> 1), d.seed_lo, d.seed_hi, x);
+        philox4x32_10((uint32_t)(d.env_id_offset + e), draw, STREAM_ACTION, (uint32_t)(j >> 1), d.seed_lo, d.seed_hi, x);
         const double u = ((j & 1) ? u53(x[2], x[3]) : u53(x[0], x[1])) * (1.0 / 9007199254740992.0);
         q = lim * (d.action_low + (d.action_high - d.action_low) * u);
       } else q = 0.0;                            // base-net q_mvar (deepcopy of base_powergrid, :106)
@@ -873,6 +928,13 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     for (int c = 0; c < MAPDN_N_INFO; ++c) info[(size_t)e * MAPDN_N_INFO + c] = 0.0;
     return;
   }
+  if (d.resetting[e]) {                           // auto_reset: this call was the env's reset(); no transition to report
+    reward[e] = 0.0; terminated[e] = 0;
+    for (int c = 0; c < MAPDN_N_INFO; ++c) info[(size_t)e * MAPDN_N_INFO + c] = 0.0;
+    d.draw[e] = bk_draw + 1;                      // (a start that does not solve is re-drawn by the next call, :108)
+    if (conv) { d.steps[e] = 1; d.sum_rewards[e] = 0.0; d.done[e] = 0; }
+    return;
+  }
   double tot[10];
 #pragma unroll
   for (int q = 0; q < 10; ++q) {
@@ -922,14 +984,7 @@ __global__ void __launch_bounds__(256) k_reset_begin(Dev d, const int64_t* __res
   d.draw[e] = dr + 1;
   int64_t start;
   if (start_rows) start = start_rows[e];
-  else {
-    uint32_t x[4];
-    philox4x32_10((uint32_t)(d.env_id_offset + e), dr, STREAM_START, 0u, d.seed_lo, d.seed_hi, x);
-    const int64_t hour = (int64_t)(((uint64_t)x[0] * 24u) >> 32);                        // :384
-    const int64_t day = (int64_t)(((uint64_t)x[1] * (uint64_t)d.n_start_days) >> 32);    // :398
-    const int64_t interval = (int64_t)(((uint64_t)x[2] * (uint64_t)d.per_hour) >> 32);   // :389
-    start = interval + hour * d.per_hour + day * d.per_day;                              // :445
-  }
+  else start = sample_start_row(d, e, dr);
   // A start whose episode window leaves the table (the reference slices past the end and raises IndexError on the empty
   // row, :446-447,473-475) never becomes steppable: not pending, stays done, counted as a reset failure by k_stats.
   const bool bad = start < 0 || start + (int64_t)d.episode_limit + 1 >= d.T;
@@ -1121,10 +1176,10 @@ extern "C" int mapdn_debug_stamps(unsigned long long* out, int n) {
 #endif
 
 void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,
-                   const double* pv, const double* q, hipStream_t st) {
+                   const double* pv, const double* q, int add_noise, hipStream_t st) {
   const dim3 grid((d.Bp + 255) / 256, d.nb);
-  if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_inject<float>, grid, dim3(256), 0, st, d, mode, (const float*)actions, pl, ql, pv, q);
-  else hipLaunchKernelGGL(k_inject<double>, grid, dim3(256), 0, st, d, mode, (const double*)actions, pl, ql, pv, q);
+  if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_inject<float>, grid, dim3(256), 0, st, d, mode, (const float*)actions, pl, ql, pv, q, add_noise);
+  else hipLaunchKernelGGL(k_inject<double>, grid, dim3(256), 0, st, d, mode, (const double*)actions, pl, ql, pv, q, add_noise);
 }
 // (W, L) instantiations of k_nr_wtree
 #define NR_FOR_EACH(X) X(1, 8) X(1, 16) X(1, 32) X(2, 8) X(2, 16) X(2, 32) X(4, 8) X(4, 16) X(4, 32) X(8, 16)

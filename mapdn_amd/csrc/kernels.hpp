@@ -38,7 +38,7 @@ struct Dev {
   const double* table; const double* stdv; const double* smax;
   int64_t T; int32_t n_start_days, per_hour, per_day;
   // ---- config
-  int32_t barrier_type, use_line_weight, episode_limit, reset_action;
+  int32_t barrier_type, use_line_weight, episode_limit, reset_action, auto_reset;
   double voltage_weight, q_weight, line_weight, v_lower, v_upper, action_low, action_high;
   uint32_t seed_lo, seed_hi; int64_t env_id_offset;
   // ---- env state
@@ -50,7 +50,7 @@ struct Dev {
   double *pl;                                         // [n_line][Bp] res_line.pl_mw
   double *sum_rewards;                                // [Bp]
   int32_t* steps; int64_t* start_row; uint32_t* draw;
-  uint8_t *done, *pending, *active, *commit, *bad_start;
+  uint8_t *done, *pending, *active, *commit, *bad_start, *resetting;   // resetting: (re)started by this step call (auto_reset)
   int64_t* adv_row; uint32_t* adv_draw;
   // ---- NR scratch (see NB_* / VO_*): row offsets of the Sbus and Vout regions
   double* nrbuf; uint32_t nrbuf_bytes; uint32_t sb_off, r_vout;   // sb_off: byte offset of the Sbus region
@@ -67,7 +67,7 @@ struct Dev {
 };
 
 void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,
-                   const double* pv, const double* q, hipStream_t st);
+                   const double* pv, const double* q, int add_noise, hipStream_t st);
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
 int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, size_t bytes);   // -2: (waves, lanes) not instantiated
 // dynamic LDS of k_nr_tree (W waves, L envs per workgroup => Wt = W*64/L workers), in pair rows of L x 16 bytes:

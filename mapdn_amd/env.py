@@ -41,6 +41,7 @@ DEFAULT_ARGS = dict(  # args/env_args/var_voltage_control.yaml:3-20
     state_space=["pv", "demand", "reactive", "vm_pu", "va_degree"],
     v_upper=1.05, v_lower=0.95, episode_limit=240, action_scale=0.8, action_bias=0.0,
     mode="distributed", reset_action=True, seed=0,
+    auto_reset=False,     # not a reference key: per-env automatic restart of terminated envs (include/mapdn.h, mapdn_env_config)
 )
 
 _SCENARIOS = {"case33_3min_final": "case33", "case141_3min_final": "case141", "case322_3min_final": "case322",
@@ -116,6 +117,7 @@ class VoltageControlBatch:
         self._state = {}
         self._obs_hist = None
         self._was_reset = False
+        self._stepped = False
 
     # ---- plumbing -------------------------------------------------------------------------------
     def _stream(self):
@@ -151,6 +153,14 @@ class VoltageControlBatch:
             _lib.check(self._lib.mapdn_get_start_rows(self._h, out.data_ptr(), self._stream()), self._h)
         return out
 
+    def auto_reset_mask(self):
+        """bool [B]: envs that the last step() call (re)started (args['auto_reset']); their reward / terminated / info of
+        that call are 0 and the obs that follows is the first obs of the new episode"""
+        out = torch.empty(self.n_envs, dtype=torch.bool, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.mapdn_get_auto_reset_mask(self._h, out.data_ptr(), self._stream()), self._h)
+        return out
+
     def episode_returns(self):
         """sum_rewards of the running episode (voltage_control_env.py:203), float64 [B]"""
         out = torch.empty(self.n_envs, dtype=torch.float64, device=self.device)
@@ -177,6 +187,7 @@ class VoltageControlBatch:
             _lib.check(self._lib.mapdn_reset(self._h, sr.data_ptr() if sr is not None else None, int(add_noise),
                                              self.max_reset_tries, self._stream()), self._h)
         self._was_reset = True
+        self._stepped = False
         if self.history > 1:
             self._obs_hist = None
         return self.get_obs(), self.get_state()
@@ -205,6 +216,7 @@ class VoltageControlBatch:
             _lib.check(self._lib.mapdn_step(self._h, a.data_ptr(), self._code(a.dtype), int(add_noise),
                                             self._reward.data_ptr(), self._term.data_ptr(), self._info.data_ptr(),
                                             self._stream()), self._h)
+        self._stepped = True
         return self._out(self._reward), self._out(self._term), self._out(self._info)
 
     def get_obs(self, dtype=None):
@@ -226,6 +238,8 @@ class VoltageControlBatch:
             cur, new = pair[self._obs_hist], pair[1 - self._obs_hist]
             new[..., :-o1].copy_(cur[..., o1:])
             new[..., -o1:].copy_(buf)
+            if self.args.get("auto_reset") and self._stepped:          # a restarted env begins with an empty history (:103-104)
+                new[..., :-o1].masked_fill_(self.auto_reset_mask().view(-1, 1, 1), 0)
             self._obs_hist = 1 - self._obs_hist
             return self._out(new)
         return self._out(buf)

@@ -223,12 +223,27 @@ def test_full_size_case141_properties():
     """BASELINE config: case141 at 4096 envs — size-independent properties + sampled oracle check"""
     case, B = "case141", 4096
     net, prof, env = make(case, B)
-    env.reset()
+    obs0, _ = env.reset()
     assert env.stats()["reset_failures"] == 0
+    # 64 of the 4096 envs (every 64th: one per workgroup row of lanes) replayed on the oracle, noise included
+    watch = list(range(5, B, 64))
+    assert len(watch) == 64
+    oracles = {e: VoltageControlOracle(net, prof, args_for(case), env_id=e, do_reset=False) for e in watch}
+    for e, o in oracles.items():
+        oo, _ = o.reset()
+        assert np.abs(np.array(oo) - obs0[e].cpu().numpy()).max() < 1e-9
     gen = torch.Generator(device="cuda:0"); gen.manual_seed(1)
     for t in range(3):
         act = (torch.rand(B, net.n_sgen, device="cuda:0", generator=gen, dtype=torch.float64) * 2 - 1) * 0.6
         r, term, info = env.step(act)
+        obs = env.get_obs().cpu().numpy(); vmw = env.results(("vm_pu",))["vm_pu"].cpu().numpy()
+        acpu, rcpu, icpu = act.cpu().numpy(), r.cpu().numpy(), info.cpu().numpy()
+        for e, o in oracles.items():
+            ro, to, io = o.step(acpu[e])
+            assert abs(ro - rcpu[e]) < 1e-9 and not to
+            assert max(abs(io[k] - icpu[e, c]) for c, k in enumerate(INFO_KEYS)) < 1e-9
+            assert np.abs(vmw[e] - o.res.vm_pu).max() < V_TOL
+            assert np.abs(np.array(o.get_obs()) - obs[e]).max() < 1e-9
     st = env.stats()
     assert st["max_nr_iters"] <= 6 and 2.5 < st["mean_nr_iters"] < 5.5
     assert torch.isfinite(r).all() and not term.any() and (info[:, 10] == 0).all()
@@ -755,4 +770,51 @@ def test_history_frames_do_not_allocate_and_match_oracle():
         ptrs.add(ob.data_ptr())
         assert np.abs(np.array(o.get_obs()) - ob[1].cpu().numpy()).max() < 1e-9
     assert len(ptrs) <= 2                         # two preallocated stacked frames, no per-call allocation
+    env.close()
+
+
+def test_auto_reset_runs_consecutive_episodes_like_the_reference_loop():
+    """with auto_reset an env that terminates (here: env 1 early, on an unsolvable step; all of them at
+    the episode limit) starts its next episode on the following call and reports `terminated` exactly once — the cadence of
+    the reference's train loop (models/model.py:204-262: reset() right after `done`).  Replayed on the oracle env."""
+    case, B, limit = "case33", 3, 12
+    kw = dict(episode_limit=limit, auto_reset=True)
+    net, prof, env = make(case, B, **kw)
+    oracles = [VoltageControlOracle(net, prof, args_for(case, episode_limit=limit), env_id=e, do_reset=False) for e in range(B)]
+    obs, _ = env.reset()
+    for e, o in enumerate(oracles):
+        oo, _ = o.reset()
+        assert np.abs(np.array(oo) - obs[e].cpu().numpy()).max() < 1e-9
+    rng = np.random.default_rng(11)
+    pending = [False] * B                     # oracle env e terminated in the previous call
+    n_term = [0] * B
+    for t in range(2 * limit + 6):
+        act = rng.uniform(-0.8, 0.8, (B, net.n_sgen))
+        if t == 4:
+            act[1] = 60.0                     # env 1: unsolvable power flow -> terminates early (:188-196)
+        r, term, info = env.step(torch.as_tensor(act, device="cuda:0"))
+        obs = env.get_obs().cpu().numpy()
+        mask = env.auto_reset_mask().cpu().numpy()
+        for e, o in enumerate(oracles):
+            if pending[e]:                    # this call is the env's reset()
+                assert mask[e] and r[e].item() == 0.0 and not term[e].item() and (info[e] == 0).all()
+                oo, _ = o.reset()
+                assert np.abs(np.array(oo) - obs[e]).max() < 1e-9, (t, e)
+                pending[e] = False
+                continue
+            assert not mask[e]
+            ro, to, io = o.step(act[e])
+            assert abs(ro - r[e].item()) < 1e-9 and to == bool(term[e].item()), (t, e)
+            assert max(abs(io[k] - info[e, c].item()) for c, k in enumerate(INFO_KEYS)) < 1e-9
+            assert np.abs(np.array(o.get_obs()) - obs[e]).max() < 1e-9, (t, e)
+            if to:
+                pending[e] = True; n_term[e] += 1
+    assert n_term == [2, 3, 2] and env.stats()["reset_failures"] == 0     # env 1: early end + two full episodes of 11 steps
+    env.close()
+    # without the flag nothing changes: a terminated env stays frozen
+    net, prof, env = make(case, 2, episode_limit=4)
+    env.reset()
+    for t in range(6):
+        r, term, info = env.step(torch.zeros(2, net.n_sgen, dtype=torch.float64, device="cuda:0"))
+    assert term.all() and (r == 0).all() and not env.auto_reset_mask().any()
     env.close()

@@ -21,27 +21,52 @@ VARIANTS = {
 RTOL, ATOL = 2e-5, 2e-6
 
 
-def _load(name):
+def _load(name, device="cpu"):
     z = np.load(os.path.join(HERE, "golden", f"learner_{name}.npz"))
     over = dict(VARIANTS[name]); alg = over.pop("alg")
     n, o = z["batch/state"].shape[1:]
     h = z["batch/hid"].shape[-1]
     args = make_alg_args(n, o, 1, hid_size=h, **over)
-    trainer = PGTrainer(args, alg, env=None, device="cpu", data_parallel=False)
+    trainer = PGTrainer(args, alg, env=None, device=device, data_parallel=False)
     init = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("init/")}
     trainer.behaviour_net.load_state_dict(init, strict=True)          # names/shapes == reference model.pt
-    batch = {k[6:]: torch.from_numpy(z[k]).float() for k in z.files if k.startswith("batch/")}
+    batch = {k[6:]: torch.from_numpy(z[k]).float().to(device) for k in z.files if k.startswith("batch/")}
     return z, args, trainer, batch
 
 
-def _close(a, b, what):
-    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
-    assert np.allclose(a, b, rtol=RTOL, atol=ATOL), (what, np.abs(a - b).max())
+def _close(a, b, what, rtol=RTOL, atol=ATOL):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    assert np.allclose(a, b, rtol=rtol, atol=atol), (what, np.abs(a - b).max())
 
 
 @pytest.mark.parametrize("name", list(VARIANTS))
 def test_forward_and_losses_match_reference(name):
-    z, args, tr, b = _load(name)
+    _check_forward_and_losses(name, "cpu")
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_update_steps_match_reference(name):
+    _check_update_steps(name, "cpu")
+
+
+# the same fixtures of the reference's own learner code, on the device the learner actually runs on (fp32 on the MI355X:
+# rocBLAS / MIOpen reduction orders differ from the CPU's, hence the slightly wider tolerances)
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_forward_and_losses_match_reference_on_gpu(name):
+    _check_forward_and_losses(name, "cuda:0", rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_update_steps_match_reference_on_gpu(name):
+    _check_update_steps(name, "cuda:0", rtol=1e-4, atol=1e-5, move_rtol=1e-2, move_atol=1e-5)
+
+
+def _check_forward_and_losses(name, device, rtol=RTOL, atol=ATOL):
+    import functools
+    _close = functools.partial(globals()["_close"], rtol=rtol, atol=atol)
+    z, args, tr, b = _load(name, device)
     net = tr.behaviour_net
     means, log_stds, hid = net.policy(b["state"], b["last_hid"])
     _close(means, z["out/means"], "means"); _close(log_stds, z["out/log_stds"], "log_stds"); _close(hid, z["out/hiddens"], "hid")
@@ -61,9 +86,10 @@ def test_forward_and_losses_match_reference(name):
     assert only_v[0] is None and only_v[2] is None
 
 
-@pytest.mark.parametrize("name", list(VARIANTS))
-def test_update_steps_match_reference(name):
-    z, args, tr, b = _load(name)
+def _check_update_steps(name, device, rtol=RTOL, atol=ATOL, move_rtol=2e-3, move_atol=2e-6):
+    import functools
+    _close = functools.partial(globals()["_close"], rtol=rtol, atol=atol)
+    z, args, tr, b = _load(name, device)
     net = tr.behaviour_net
     net.get_loss(b)                                    # the generator's loss probe also moved the BatchNorm statistics
     stat = {}
@@ -82,7 +108,7 @@ def test_update_steps_match_reference(name):
         else:
             # parameters moved by lr 1e-4 RMSprop steps: compare the MOVE, not just the value
             init = z["init/" + k]
-            assert np.allclose(final[k].numpy() - init, z["final/" + k] - init, rtol=2e-3, atol=2e-6), k
+            assert np.allclose(final[k].cpu().numpy() - init, z["final/" + k] - init, rtol=move_rtol, atol=move_atol), k
 
 
 def test_valid_mask_and_argument_checks():
