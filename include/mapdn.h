@@ -31,7 +31,7 @@ extern "C" {
 
 #define MAPDN_OK 0
 #define MAPDN_E_INVALID (-1)   /* bad argument / inconsistent netspec                        */
-#define MAPDN_E_TOPOLOGY (-2)  /* net not connected, or meshed (this build solves radial nets) */
+#define MAPDN_E_TOPOLOGY (-2)  /* net not connected, or meshed with more than 65 buses          */
 #define MAPDN_E_HIP (-3)       /* HIP runtime error (no device, OOM, launch failure)           */
 #define MAPDN_E_STATE (-4)     /* call order violated (e.g. step before set_profiles/reset)    */
 
@@ -128,6 +128,10 @@ const char* mapdn_last_error(const mapdn_handle* h);
 /* VoltageControl.__init__ up to (not including) data loading — voltage_control_env.py:36-94.
  * Builds per-unit Ybus (pandapower pd2ppc/makeYbus), the elimination order and all gather index
  * tables on the host, uploads them to `device`, allocates state for n_envs envs.
+ * Topology: pp.runpp (voltage_control_env.py:557) solves any connected net.  Radial feeders (all three MAPDN
+ * scenarios) take the fill-free tree solver; a meshed net (closed tie switches, loops) takes the general solver —
+ * dense Jacobian per env in LDS, blocked LU with f64 MFMA trailing updates — which handles up to 65 buses;
+ * larger meshed nets and nets with buses not connected to the ext_grid return MAPDN_E_TOPOLOGY.
  * device == -1 builds a host-only handle (plan, dims, ybus/obs-index export; no device calls).
  * Tuning knobs read from the environment at create time (defaults are chosen per topology):
  *   MAPDN_NR_WAVES (1/2/4/8), MAPDN_NR_LANES (4/8/16/32)   waves and envs per NR workgroup
@@ -135,7 +139,8 @@ const char* mapdn_last_error(const mapdn_handle* h);
  *   MAPDN_NR_CHECK_DX (default 1e-7)                       Newton-step size below which the next sweep is
  *                                                          first tried mismatch-only (never changes results)
  *   MAPDN_NR_CHECK_QUAD (default 1)                        safety factor of the second predictor, ||F||^3/||F_prev||^2 < tol / factor
- *                                                          ("inf" disables it) */
+ *                                                          ("inf" disables it)
+ *   MAPDN_NR_DENSE (0/1)                                   1: use the general (dense) solver on a radial net too (cross-checks) */
 int mapdn_create(const mapdn_netspec* net, const mapdn_env_config* cfg, int32_t n_envs,
                  int32_t device, mapdn_handle** out);
 void mapdn_destroy(mapdn_handle* h);
@@ -205,6 +210,12 @@ int mapdn_get_schedule(const mapdn_handle* h, int32_t n_waves, int32_t* n_rows, 
  * of the block LU of the Jacobian at V = ext_grid vm_pu everywhere, unknowns [dtheta, d|V|/|V|];
  * bus_of_pos [n+1] (optional) = bus id of every elimination position (position n is the slack). */
 int mapdn_get_flat_factors(const mapdn_handle* h, double* factors, int32_t* bus_of_pos);
+
+/* Debug / pin export of the general solver's linear algebra: solves `batch` independent dense systems A x = b
+ * (device pointers; A row-major [batch, n, n], b and x [batch, n]; n even, <= 128) with the LDS-resident blocked LU
+ * (2x2 block pivots, v_mfma_f64_16x16x4_f64 trailing updates) that k_nr_dense runs on the Jacobian — what pandapower
+ * does with SuperLU in pypower/newtonpf.py (dx = -spsolve(J, F)).  Tests compare with numpy.linalg.solve. */
+int mapdn_dense_solve(const double* a, const double* b, double* x, int32_t n, int32_t batch, void* stream);
 
 /* counters (host, synchronises the given stream): number of envs whose last reset exhausted
  * max_tries; mean / max NR iterations of the last solve */

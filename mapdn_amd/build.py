@@ -8,8 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmapdn_hip.so")
-SOURCES = ["plan.cpp", "kernels.hip", "capi.hip"]
-HEADERS = ["plan.hpp", "kernels.hpp", os.path.join("..", "..", "include", "mapdn.h")]
+SOURCES = ["plan.cpp", "kernels.hip", "dense.hip", "capi.hip"]
+HEADERS = ["plan.hpp", "kernels.hpp", "nr_common.hpp", os.path.join("..", "..", "include", "mapdn.h")]
 
 
 def _stale() -> bool:

@@ -99,6 +99,10 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   if (cfg->episode_limit < 2) { h->err = "episode_limit must be >= 2"; return MAPDN_E_INVALID; }
   int rc = build_plan(*net, *cfg, h->plan, h->err);
   if (rc) return rc;
+  if (!h->plan.radial && 2 * h->plan.n > 128) {   // general-topology solver: dense Jacobian of one env in LDS (dense.hip)
+    h->err = "topology: meshed network with " + std::to_string(h->plan.nb) + " buses; the general-topology solver keeps the dense "
+             "Jacobian of one env in LDS and handles at most 65 buses (radial feeders of any size take the tree solver)";
+    return MAPDN_E_TOPOLOGY; }
   h->cfg = *cfg;
   h->device = device;
   std::memset(&h->d, 0, sizeof(h->d));
@@ -192,6 +196,45 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   rc = dalloc(h, &h->t_pv, (size_t)d.ns * Bp); if (rc) return rc;
   rc = dalloc(h, &h->t_q, (size_t)d.ns * Bp); if (rc) return rc;
   rc = dalloc(h, &h->stats_dev, 4); if (rc) return rc;
+  // NR scratch `nrbuf`: factor blocks (fb_rows pair rows) | Sbus (nblk pair rows, entry sbi[k] for position k) | Vout;
+  // a single buffer resource addresses it
+  auto alloc_nrbuf = [&](size_t fb_rows, size_t nblk, const std::vector<int32_t>& sbi) -> int {
+    const size_t sb_off = fb_rows * Bp * 16;
+    const size_t vout_off = sb_off + nblk * Bp * 16;
+    const size_t bytes = vout_off + (size_t)VOF * (P.n + 1) * Bp * sizeof(double);
+    if (bytes >= (size_t)0xFFFFFFFFu) { h->err = "env batch too large: NR scratch exceeds the 4 GiB one buffer resource addresses; use fewer envs per handle"; return MAPDN_E_INVALID; }
+    rc = dalloc(h, &d.nrbuf, bytes / sizeof(double)); if (rc) return rc;
+    d.nrbuf_bytes = (uint32_t)bytes;
+    d.sb_off = (uint32_t)sb_off;
+    d.r_vout = (uint32_t)(vout_off / (Bp * sizeof(double)));
+    rc = dupload(h, &d.sb_index, sbi); if (rc) return rc;
+    std::vector<double> row(Bp, d.vroot);   // slack entry of Vout: V = vroot + 0j (angle 0 from the memset)
+    double* rootv = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * P.n) * Bp;
+    HIPCHK(h, hipMemcpy(rootv + (size_t)VO_E * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(rootv + (size_t)VO_VM * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<int32_t> vmrow(P.nb), varow(P.nb);
+    for (int b = 0; b < P.nb; ++b) { const int k = P.pos_of_bus[b]; vmrow[b] = (int)d.r_vout + VOF * k + VO_VM; varow[b] = (int)d.r_vout + VOF * k + VO_VA; }
+    rc = dupload(h, &tmp, vmrow); if (rc) return rc; h->vm_row = (int32_t*)tmp;
+    rc = dupload(h, &tmp, varow); if (rc) return rc; h->va_row = (int32_t*)tmp;
+    return MAPDN_OK;
+  };
+  // ---- general-topology path: a meshed net (or MAPDN_NR_DENSE=1 on a radial one, for cross-checks) is solved by
+  // k_nr_dense (dense.hip): one env per workgroup, dense Jacobian in LDS, blocked LU with f64 MFMA trailing updates
+  {
+    const char* s = getenv("MAPDN_NR_DENSE");
+    if (!P.radial || (s && atoi(s))) {
+      d.dense = 1; d.dn_N = (2 * P.n + 15) / 16 * 16; d.dn_lda = d.dn_N + 2;
+      if (d.dn_N > 128 || nr_dense_lds_bytes(d) > 160 * 1024) {
+        h->err = "MAPDN_NR_DENSE: the general-topology solver handles at most 65 buses"; return MAPDN_E_TOPOLOGY; }
+      UP(gy_ptr, P.gy_ptr); UP(gy_col, P.gy_col); UP(gy_val, P.gy_val);
+      std::vector<int32_t> sbi(P.n);
+      for (int k = 0; k < P.n; ++k) sbi[k] = k;
+      rc = alloc_nrbuf(0, (size_t)P.n, sbi); if (rc) return rc;
+      if (nr_dense_prepare(d) != 0) { (void)hipGetLastError(); h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_nr_dense"; return MAPDN_E_HIP; }
+      h->lds_bytes = nr_dense_lds_bytes(d);
+      return MAPDN_OK;
+    }
+  }
   // ---- NR launch geometry: a workgroup = W waves serving L envs; each wave carries 64/L lane-group
   // workers, so Wt = W*64/L workers eliminate independent subtrees of every env concurrently.
   // Small batches get few envs per workgroup (many workgroups, all lanes busy with intra-env
@@ -250,27 +293,11 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   UP(sched, h->sched.steps); d.sched_bytes = (uint32_t)(h->sched.steps.size() * sizeof(StepRec));
   UP(clist, h->sched.clist);
   UP(flat, h->sched.flat); d.flat_bytes = (uint32_t)(h->sched.flat.size() * sizeof(double));
-  {  // NR scratch: factor blocks (one per (worker,row) step) | Sbus (schedule order) | Vout; a single buffer resource addresses it
+  {  // NR scratch: factor blocks (one per (worker,row) step) | Sbus (schedule order) | Vout
     const size_t nblk = (size_t)Wt * h->sched.R;
     const size_t fb_rows = (h_lds && g_lds) ? 0 : nblk * NBP;                 // pair rows of Bp x 16 bytes
-    const size_t sb_off = fb_rows * Bp * 16;
-    const size_t vout_off = sb_off + nblk * Bp * 16;
-    const size_t bytes = vout_off + (size_t)VOF * (P.n + 1) * Bp * sizeof(double);
-    if (bytes >= (size_t)0xFFFFFFFFu) { h->err = "env batch too large: NR scratch exceeds the 4 GiB one buffer resource addresses; use fewer envs per handle"; return MAPDN_E_INVALID; }
-    rc = dalloc(h, &d.nrbuf, bytes / sizeof(double)); if (rc) return rc;
-    d.nrbuf_bytes = (uint32_t)bytes;
-    d.sb_off = (uint32_t)sb_off;
-    d.r_vout = (uint32_t)(vout_off / (Bp * sizeof(double)));
     std::vector<int32_t> sbi(h->sched.step_of_node.begin(), h->sched.step_of_node.begin() + P.n);
-    UP(sb_index, sbi);
-    std::vector<double> row(Bp, d.vroot);   // slack entry of Vout: V = vroot + 0j (angle 0 from the memset)
-    double* rootv = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * P.n) * Bp;
-    HIPCHK(h, hipMemcpy(rootv + (size_t)VO_E * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(rootv + (size_t)VO_VM * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
-    std::vector<int32_t> vmrow(P.nb), varow(P.nb);
-    for (int b = 0; b < P.nb; ++b) { const int k = P.pos_of_bus[b]; vmrow[b] = (int)d.r_vout + VOF * k + VO_VM; varow[b] = (int)d.r_vout + VOF * k + VO_VA; }
-    rc = dupload(h, &tmp, vmrow); if (rc) return rc; h->vm_row = (int32_t*)tmp;
-    rc = dupload(h, &tmp, varow); if (rc) return rc; h->va_row = (int32_t*)tmp;
+    rc = alloc_nrbuf(fb_rows, nblk, sbi); if (rc) return rc;
   }
 #undef UP
   return MAPDN_OK;
@@ -530,6 +557,7 @@ int mapdn_get_obs_index(const mapdn_handle* h, int32_t* kind, int32_t* index) {
 
 int mapdn_get_flat_factors(const mapdn_handle* h, double* factors, int32_t* bus_of_pos) {
   if (!h || !factors) return MAPDN_E_INVALID;
+  if (!h->plan.radial) return MAPDN_E_TOPOLOGY;   // the tree factorisation exists for radial feeders only
   Schedule S;
   build_schedule(h->plan, 1, S);                 // one worker: row r of the schedule is one node
   const int n = h->plan.n;
@@ -543,12 +571,19 @@ int mapdn_get_flat_factors(const mapdn_handle* h, double* factors, int32_t* bus_
 
 int mapdn_get_schedule(const mapdn_handle* h, int32_t W, int32_t* n_rows, int32_t* rows, int32_t* parent) {
   if (!h || !n_rows || W < 1 || W > 16) return MAPDN_E_INVALID;
+  if (!h->plan.radial) return MAPDN_E_TOPOLOGY;
   Schedule S;
   build_schedule(h->plan, W, S);
   *n_rows = S.R;
   if (rows) for (size_t i = 0; i < S.steps.size(); ++i) rows[i] = (S.steps[i].flags & S_LIVE) ? (int32_t)(S.steps[i].kp & 0xffffu) : -1;
   if (parent) std::memcpy(parent, h->plan.par.data(), h->plan.par.size() * sizeof(int32_t));
   return MAPDN_OK;
+}
+
+int mapdn_dense_solve(const double* a, const double* b, double* x, int32_t n, int32_t batch, void* stream) {
+  if (!a || !b || !x) return MAPDN_E_INVALID;
+  const int rc = dense_solve_debug(a, b, x, n, batch, (hipStream_t)stream);
+  return rc == 0 ? MAPDN_OK : (rc == -1 ? MAPDN_E_INVALID : MAPDN_E_HIP);
 }
 
 int mapdn_stats(mapdn_handle* h, int64_t* reset_failures, double* mean_iters, int32_t* max_iters, void* stream) {

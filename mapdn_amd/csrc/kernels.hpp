@@ -64,6 +64,10 @@ struct Dev {
   // forward sweep is first run in its mismatch-only form (k_nr_wtree)
   double nr_check_dx;
   double nr_check_quad;      // safety factor of the quadratic-convergence predictor (inf disables it, tiny = always predict)
+  // ---- general-topology solve (k_nr_dense, dense.hip): Ybus rows by position in CSR form (columns are positions,
+  // n == slack; values (re, im)); the dense Jacobian is N x N (2n rounded up to 16) with row stride dn_lda in LDS
+  int32_t dense, dn_N, dn_lda;
+  const int32_t *gy_ptr, *gy_col; const double* gy_val;
 };
 
 void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,
@@ -85,6 +89,11 @@ static inline size_t nr_lds_bytes(int W, int L, int n, int cslots, int xslots, i
   return rows * (size_t)L * 16 + (size_t)W * 64 + (size_t)64 * W * sizeof(double) + (size_t)((nclist + 3) & ~3) * sizeof(int32_t) +
          nr_line_bytes(n_line_lds) + Wt * rec_rows * sizeof(StepRec) + Wt * flat_rows * FLAT_N * sizeof(double);
 }
+// general-topology kernel (dense.hip): nr_dense_prepare returns -2 when the net is too large for the LDS-resident Jacobian
+size_t nr_dense_lds_bytes(const Dev& d);
+int nr_dense_prepare(const Dev& d);
+void launch_nr_dense(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
+int dense_solve_debug(const double* A, const double* b, double* x, int n, int batch, hipStream_t st);
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);
 void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, hipStream_t st);
 void launch_gather(const Dev& d, const double* base, const int32_t* rows, const double* scales, double scale_all,

@@ -114,7 +114,6 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   }
   if ((int)preorder.size() != nb) { err = "topology: network is not connected to the ext_grid bus (pandapower would drop unsupplied buses; not supported)"; return MAPDN_E_TOPOLOGY; }
   P.radial = (n_edges == (size_t)nb - 1);
-  if (!P.radial) { err = "topology: meshed network (" + std::to_string(n_edges) + " bus pairs for " + std::to_string(nb) + " buses); this build solves radial feeders only"; return MAPDN_E_TOPOLOGY; }
 
   // ---- elimination forest.  The slack has a known voltage: it is not eliminated, it only adds the
   // constant term V_k conj(Y_k,slack V_slack) to the S of its neighbours.  Removing it leaves one tree
@@ -124,7 +123,12 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   const int slack = P.root_bus;
   std::vector<int> el_parent(nb, -1);            // elimination parent (bus id), -1 for elimination roots / slack
   std::vector<int> el_order; el_order.reserve(nb);
-  {
+  if (!P.radial) {
+    // Meshed net (closed tie switches, parallel feeders): no fill-free elimination order exists.  The general-topology
+    // kernel (dense.hip) factorises the full Jacobian, for which any bus order will do: descending bus index here,
+    // i.e. ascending positions after the reversal below.
+    for (int b = nb - 1; b >= 0; --b) if (b != slack) el_order.push_back(b);
+  } else {
     std::vector<int> dist(nb), from(nb);
     auto bfs = [&](int src, std::vector<int>& comp) {      // BFS inside (tree - slack); returns farthest node
       comp.clear();
@@ -171,7 +175,7 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   }
   P.bus_of_pos[P.n] = slack; P.pos_of_bus[slack] = P.n;
   P.par.assign(P.n, 0); P.flags.assign(P.n, 0u); P.yc.assign((size_t)P.n * 8, 0.0);
-  for (int k = 0; k < P.n; ++k) {
+  for (int k = 0; P.radial && k < P.n; ++k) {
     const int bus = P.bus_of_pos[k], pb = el_parent[bus];
     const int p = pb >= 0 ? P.pos_of_bus[pb] : P.n;          // elimination roots point at the slack position (Y = 0)
     if (p <= k) { err = "internal: elimination order violated"; return MAPDN_E_INVALID; }
@@ -187,6 +191,20 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   P.yrr[0] = Y(slack, slack).real(); P.yrr[1] = Y(slack, slack).imag();
   P.root_children.clear(); P.root_y.clear();     // the slack's neighbours and Y[slack, k] (slack injection in res_bus)
   for (int w : adj[slack]) { P.root_children.push_back(P.pos_of_bus[w]); P.root_y.push_back(Y(slack, w).real()); P.root_y.push_back(Y(slack, w).imag()); }
+
+  // ---- Ybus rows by position (CSR; the slack row is not needed: its injection comes from root_children / root_y)
+  P.gy_ptr.assign(1, 0); P.gy_col.clear(); P.gy_val.clear();
+  for (int k = 0; k < P.n; ++k) {
+    const int bus = P.bus_of_pos[k];
+    for (int j = 0; j <= P.n; ++j) {
+      const int bj = P.bus_of_pos[j];
+      const cplx y = Y(bus, bj);
+      const bool linked = bj == bus || std::find(adj[bus].begin(), adj[bus].end(), bj) != adj[bus].end();
+      if (!linked) continue;                     // structural non-zeros only (a zero-valued link stays in the pattern)
+      P.gy_col.push_back(j); P.gy_val.push_back(y.real()); P.gy_val.push_back(y.imag());
+    }
+    P.gy_ptr.push_back((int32_t)P.gy_col.size());
+  }
 
   // ---- res_line flows ---------------------------------------------------------------------------
   P.lines.resize(net.n_line);

@@ -104,6 +104,8 @@ struct Plan {
   std::vector<int32_t> root_children;           // positions of the slack's neighbours
   std::vector<double> root_y;                   // [2*len] Y[slack, neighbour] (re, im)
   std::vector<cplx> ybus;                       // dense [nb*nb], debug export only
+  std::vector<int32_t> gy_ptr, gy_col;          // Ybus rows of the non-slack buses by position, CSR (columns: positions, n == slack)
+  std::vector<double> gy_val;                   // (re, im) per entry — read by the general-topology kernel (dense.hip)
 
   std::vector<LineFlow> lines;                  // [n_line]
   // element -> bus CSR by position (0..nb-1, root last)

@@ -105,6 +105,7 @@ class VoltageControlBatch:
         self._obs_size1, self.state_size = dims.obs_size, dims.state_size
         self.obs_size = self._obs_size1 * self.history          # :303-315 stacks `history` frames
         self.max_zone_size = dims.max_zone_size
+        self.is_radial = bool(dims.is_radial)                   # False: meshed net, general-topology solver (k_nr_dense)
         p = profiles
         _lib.check(self._lib.mapdn_set_profiles(
             self._h, _lib._p(p.pv, _lib._pd), _lib._p(p.load_p, _lib._pd), _lib._p(p.load_q, _lib._pd),

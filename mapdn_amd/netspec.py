@@ -220,6 +220,37 @@ def case33bw_base():
     return net, _BW33[:, 4] * 1e-3, _BW33[:, 5] * 1e-3
 
 
+# The five normally-open tie lines of the Baran-Wu feeder (public literature data): from, to (1-based), r, x [ohm].
+_BW33_TIES = np.array([[8, 21, 2.0, 2.0], [9, 15, 2.0, 2.0], [12, 22, 2.0, 2.0], [18, 33, 0.5, 0.5], [25, 29, 0.5, 0.5]])
+
+
+def add_lines(net: "NetSpec", from_bus, to_bus, r_ohm, x_ohm, c_nf=0.0, length_km=1.0) -> "NetSpec":
+    """A copy of `net` with extra in-service rows appended to the line table (closing tie switches makes the net
+    meshed; pandapower's runpp solves it all the same — voltage_control_env.py:557)."""
+    out = net.copy()
+    k = len(np.atleast_1d(from_bus))
+    cat = lambda a, b, dt: np.concatenate([a, np.broadcast_to(np.asarray(b, dt), (k,))]).astype(dt)
+    out.line_from_bus = cat(net.line_from_bus, from_bus, np.int32)
+    out.line_to_bus = cat(net.line_to_bus, to_bus, np.int32)
+    out.line_r_ohm_per_km = cat(net.line_r_ohm_per_km, r_ohm, np.float64)
+    out.line_x_ohm_per_km = cat(net.line_x_ohm_per_km, x_ohm, np.float64)
+    out.line_c_nf_per_km = cat(net.line_c_nf_per_km, c_nf, np.float64)
+    out.line_g_us_per_km = cat(net.line_g_us_per_km, 0.0, np.float64)
+    out.line_length_km = cat(net.line_length_km, length_km, np.float64)
+    out.line_parallel = cat(net.line_parallel, 1, np.int32)
+    out.line_in_service = cat(net.line_in_service, 1, np.uint8)
+    out.__post_init__()
+    return out
+
+
+def case33_meshed(net: "NetSpec", n_ties: int = 5) -> "NetSpec":
+    """case33 with the first `n_ties` Baran-Wu tie lines closed (a weakly meshed 33-bus net)."""
+    t = _BW33_TIES[:n_ties]
+    out = add_lines(net, t[:, 0].astype(np.int32) - 1, t[:, 1].astype(np.int32) - 1, t[:, 2], t[:, 3])
+    out.name = f"{net.name}_meshed{n_ties}"
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # seeded random radial feeders with the case141 / case322 shapes
 # ------------------------------------------------------------------------------------------------

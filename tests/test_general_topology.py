@@ -1,0 +1,246 @@
+"""General-topology power flow (meshed nets): pp.runpp (voltage_control_env.py:557) solves any connected net; the
+product solves radial feeders with the tree kernel and everything else with k_nr_dense (dense Jacobian in LDS, blocked
+LU with 2x2 block pivots and v_mfma_f64_16x16x4_f64 trailing updates).  Checker: oracle/pp_restated.py (SuperLU
+spsolve on the sparse Jacobian, as pandapower) + the solver-independent residual certificate."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mapdn_amd import _lib
+from mapdn_amd.netspec import NetSpec, Profiles, add_lines, case33_meshed, make_case
+from oracle.pp_restated import make_ybus, residual_inf, runpp_restated
+
+
+def random_meshed_net(seed, nb_max=60):
+    """random tree + random extra links (loops), slack anywhere, random line data / loads / sgens / shunts"""
+    rng = np.random.default_rng(1000 + seed)
+    nb = int(rng.integers(5, nb_max))
+    parent = np.array([-1] + [int(rng.integers(max(0, i - int(rng.integers(1, 6))), i)) for i in range(1, nb)])
+    perm = rng.permutation(nb)
+    f = list(perm[parent[1:]]); t = list(perm[np.arange(1, nb)])
+    pairs = {(min(a, b), max(a, b)) for a, b in zip(f, t)}
+    n_extra = int(rng.integers(1, max(2, nb // 4)))
+    while n_extra:
+        a, b = (int(x) for x in rng.integers(0, nb, 2))
+        if a == b or (min(a, b), max(a, b)) in pairs:
+            continue
+        pairs.add((min(a, b), max(a, b))); f.append(a); t.append(b); n_extra -= 1
+    n_line = len(f)
+    slack = int(perm[int(rng.integers(0, nb))])
+    nz = int(rng.integers(1, 4))
+    zone = rng.integers(1, nz + 1, nb).astype(np.int32); zone[slack] = 0
+    ns = int(rng.integers(1, 7))
+    cand = np.array([b for b in range(nb) if b != slack])
+    sgen_bus = rng.choice(cand, size=ns, replace=True).astype(np.int32)
+    nl = int(rng.integers(1, 2 * nb))
+    load_bus = rng.integers(0, nb, nl).astype(np.int32)
+    vn = float(rng.choice([0.4, 11.0, 20.0])); sn = float(rng.choice([0.5, 1.0, 10.0])); zb = vn * vn / sn
+    nsh = int(rng.integers(0, 3))
+    net = NetSpec(name=f"mesh{seed}", bus_vn_kv=np.full(nb, vn), bus_zone=zone, line_from_bus=np.array(f), line_to_bus=np.array(t),
+                  line_r_ohm_per_km=rng.uniform(0.05, 0.5, n_line) * zb * 0.02, line_x_ohm_per_km=rng.uniform(0.0, 0.4, n_line) * zb * 0.02,
+                  line_c_nf_per_km=rng.uniform(0, 50, n_line), line_g_us_per_km=rng.uniform(0, 1, n_line),
+                  line_length_km=rng.uniform(0.2, 1.5, n_line), line_parallel=rng.integers(1, 3, n_line).astype(np.int32),
+                  line_in_service=np.ones(n_line, np.uint8), load_bus=load_bus, sgen_bus=sgen_bus, sgen_zone=zone[sgen_bus],
+                  ext_grid_bus=slack, ext_grid_vm_pu=float(rng.uniform(0.98, 1.03)), sn_mva=sn, f_hz=50.0,
+                  shunt_bus=rng.integers(0, nb, nsh).astype(np.int32), shunt_p_mw=rng.uniform(0, 0.01 * sn, nsh),
+                  shunt_q_mvar=rng.uniform(-0.05 * sn, 0.05 * sn, nsh))
+    T = 1500
+    pv = rng.uniform(0, 0.3 * sn / ns, (T, ns)); lp = rng.uniform(0, 0.4 * sn / nl, (T, nl)); lq = lp * rng.uniform(0.1, 0.5, (T, nl))
+    return net, Profiles(pv=pv, load_p=lp, load_q=lq, time_delta_min=3)
+
+
+def host_handle(net, args=None):
+    lib = _lib.load()
+    a = dict(episode_limit=240, action_scale=0.8, action_bias=0.0, voltage_barrier_type="l1")
+    a.update(args or {})
+    cnet, keep = _lib.make_cnetspec(net)
+    ccfg = _lib.make_cconfig(a)
+    h = C.c_void_p()
+    rc = lib.mapdn_create(C.byref(cnet), C.byref(ccfg), 4, -1, C.byref(h))
+    return lib, h, rc, keep
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_meshed_nets_are_accepted_and_ybus_matches_the_oracle():
+    base, _ = make_case("case33")
+    for net in [case33_meshed(base, 1), case33_meshed(base, 5)] + [random_meshed_net(s)[0] for s in range(6)]:
+        lib, h, rc, keep = host_handle(net)
+        assert rc == 0, lib.mapdn_last_error(None)
+        dims = _lib.CDims()
+        assert lib.mapdn_dims(h, C.byref(dims)) == 0 and dims.is_radial == 0 and dims.n_bus == net.n_bus
+        out = np.zeros((net.n_bus, net.n_bus, 2))
+        assert lib.mapdn_get_ybus_dense(h, _lib._p(out, _lib._pd)) == 0
+        yo = make_ybus(net)[0].toarray()
+        assert np.abs(out[..., 0] + 1j * out[..., 1] - yo).max() <= 1e-12 * np.abs(yo).max()
+        # the tree-only debug exports refuse a meshed plan instead of returning garbage
+        nrows = C.c_int32()
+        assert lib.mapdn_get_schedule(h, 1, C.byref(nrows), None, None) == _lib_E_TOPOLOGY
+        lib.mapdn_destroy(h)
+
+
+_lib_E_TOPOLOGY = -2
+
+
+def test_large_meshed_and_disconnected_nets_are_refused_loudly():
+    net, _ = make_case("case141")
+    meshed = add_lines(net, [5], [77], 0.3, 0.2)
+    lib, h, rc, keep = host_handle(meshed)
+    assert rc == _lib_E_TOPOLOGY and b"65 buses" in lib.mapdn_last_error(None)
+    island = net.copy(); island.line_in_service[3] = 0
+    lib, h, rc, keep = host_handle(island)
+    assert rc == _lib_E_TOPOLOGY and b"not connected" in lib.mapdn_last_error(None)
+
+
+def test_oracle_on_meshed_nets_meets_the_residual_certificate_and_a_dense_solve():
+    """the checker itself on loops: SuperLU path vs the residual certificate and vs a dense numpy Newton iteration"""
+    from oracle.pp_restated import bus_demand, make_sbus
+    for seed in range(6):
+        net, prof = random_meshed_net(seed)
+        rng = np.random.default_rng(seed)
+        r = int(rng.integers(0, prof.n_rows))
+        qs = rng.uniform(-0.2, 0.2, net.n_sgen) * prof.pv[r]
+        res = runpp_restated(net, prof.load_p[r], prof.load_q[r], prof.pv[r], qs)
+        assert res.converged
+        assert residual_inf(net, res.V, prof.load_p[r], prof.load_q[r], prof.pv[r], qs) < 1e-8 / net.sn_mva
+        # independent dense Newton in rectangular coordinates
+        y = make_ybus(net)[0].toarray()
+        sb = make_sbus(net, *bus_demand(net, prof.load_p[r], prof.load_q[r], prof.pv[r], qs))
+        pq = np.array([b for b in range(net.n_bus) if b != net.ext_grid_bus])
+        v = np.full(net.n_bus, net.ext_grid_vm_pu, complex)
+        for _ in range(20):
+            i_ = y @ v
+            mis = (v * np.conj(i_) - sb)[pq]
+            # dS/de = diag(conj(I)) + diag(V) conj(Y),  dS/df = j diag(conj(I)) - j diag(V) conj(Y)
+            de = np.diag(np.conj(i_)) + np.diag(v) @ np.conj(y)
+            df = 1j * np.diag(np.conj(i_)) - 1j * np.diag(v) @ np.conj(y)
+            J = np.block([[de[np.ix_(pq, pq)].real, df[np.ix_(pq, pq)].real], [de[np.ix_(pq, pq)].imag, df[np.ix_(pq, pq)].imag]])
+            dx = np.linalg.solve(J, -np.r_[mis.real, mis.imag])
+            v[pq] += dx[:len(pq)] + 1j * dx[len(pq):]
+            if np.abs(dx).max() < 1e-14:
+                break
+        assert np.abs(v - res.V).max() < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+gpu = pytest.mark.gpu
+
+
+@gpu
+@pytest.mark.parametrize("n", [2, 14, 16, 30, 32, 48, 64, 66, 96, 126, 128])
+def test_dense_lu_matches_numpy(n):
+    """the kernel's LDS-resident blocked LU (2x2 block pivots, f64 MFMA trailing updates) against numpy.linalg.solve;
+    includes matrices whose scalar diagonal is ZERO (rotation-like bus blocks: only a block pivot survives) and an
+    asymmetric identity-like case that would expose a swapped MFMA fragment layout"""
+    import torch
+    lib = _lib.load()
+    rng = np.random.default_rng(n)
+    batch = 7
+    A = rng.normal(0, 1, (batch, n, n))
+    for s in range(batch):
+        for k in range(0, n, 2):                     # strong 2x2 diagonal blocks [[a, b], [-b, a]]
+            a_, b_ = (0.0 if s % 2 else rng.uniform(1, 2)), rng.uniform(2, 3) * n ** 0.5
+            A[s, k:k + 2, k:k + 2] = [[a_, b_], [-b_, a_]]
+    A[0] = np.triu(rng.normal(0, 1, (n, n)), 2)      # A[0]: identity + a strictly upper part (asymmetric)
+    A[0] += np.eye(n)
+    b = rng.normal(0, 1, (batch, n))
+    x = torch.zeros(batch, n, dtype=torch.float64, device="cuda:0")
+    ta, tb = torch.as_tensor(A, device="cuda:0").contiguous(), torch.as_tensor(b, device="cuda:0").contiguous()
+    rc = lib.mapdn_dense_solve(ta.data_ptr(), tb.data_ptr(), x.data_ptr(), n, batch, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = np.linalg.solve(A, b[..., None])[..., 0]
+    err = np.abs(x.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < 1e-11, err
+
+
+def _solve_inputs(net, prof, B, seed):
+    rng = np.random.default_rng(seed)
+    rows = rng.integers(0, prof.n_rows, B)
+    pv = prof.pv[rows]
+    qs = rng.uniform(-0.8, 0.8, (B, net.n_sgen)) * np.sqrt(prof.s_max() ** 2 - pv ** 2)
+    return prof.load_p[rows], prof.load_q[rows], pv, qs
+
+
+@gpu
+@pytest.mark.parametrize("which", ["case33_tie1", "case33_tie5"] + [f"rand{s}" for s in range(8)])
+def test_meshed_solve_matches_oracle(which):
+    import torch
+    from mapdn_amd.env import VoltageControlBatch
+    if which.startswith("case33"):
+        base, prof = make_case("case33")
+        net = case33_meshed(base, int(which[-1]))
+    else:
+        net, prof = random_meshed_net(int(which[4:]))
+    B = 70
+    a = dict(episode_limit=240, action_scale=0.8, action_bias=0.0, voltage_barrier_type="l2", seed=1)
+    env = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0", obs_dtype=torch.float64)
+    assert not env.is_radial
+    pl, ql, pv, qs = _solve_inputs(net, prof, B, 5)
+    vm, va, it, cv = (t.cpu().numpy() for t in env.solve(pl, ql, pv, qs))
+    assert cv.all()
+    worst = 0.0
+    for e in range(B):
+        r = runpp_restated(net, pl[e], ql[e], pv[e], qs[e])
+        assert r.converged and r.iterations == it[e]
+        worst = max(worst, np.abs(vm[e] - r.vm_pu).max(), np.abs(va[e] - r.va_degree).max() * np.pi / 180)
+        v = vm[e] * np.exp(1j * va[e] * np.pi / 180)
+        assert residual_inf(net, v, pl[e], ql[e], pv[e], qs[e]) < 1e-8 / net.sn_mva
+    assert worst < 1e-9, worst
+    env.close()
+
+
+@gpu
+def test_dense_solver_equals_the_tree_solver_on_a_radial_feeder(monkeypatch):
+    """MAPDN_NR_DENSE=1 forces the general solver onto case33: same Newton iterates as the tree elimination"""
+    import torch
+    from mapdn_amd.env import VoltageControlBatch
+    net, prof = make_case("case33")
+    a = dict(episode_limit=240, action_scale=0.8, action_bias=0.0, voltage_barrier_type="bowl", seed=0)
+    B = 130
+    ins = _solve_inputs(net, prof, B, 9)
+    tree = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0")
+    rt = [t.cpu().numpy() for t in tree.solve(*ins)]
+    tree.close()
+    monkeypatch.setenv("MAPDN_NR_DENSE", "1")
+    dense = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0")
+    rd = [t.cpu().numpy() for t in dense.solve(*ins)]
+    dense.close()
+    assert (rt[2] == rd[2]).all() and rd[3].all()
+    assert np.abs(rt[0] - rd[0]).max() < 1e-12 and np.abs(rt[1] - rd[1]).max() < 1e-10
+
+
+@gpu
+@pytest.mark.parametrize("which", ["case33_tie5", "rand2", "rand5"])
+def test_meshed_env_episode_matches_the_oracle_env(which):
+    """the whole step (inject -> general solve -> fused reward epilogue -> commit -> obs) on a meshed net"""
+    import torch
+    from mapdn_amd.env import VoltageControlBatch
+    from oracle.env_restated import INFO_KEYS, VoltageControlOracle
+    if which.startswith("case33"):
+        base, prof = make_case("case33")
+        net = case33_meshed(base, 5)
+    else:
+        net, prof = random_meshed_net(int(which[4:]))
+    a = dict(episode_limit=240, action_scale=0.8, action_bias=0.0, voltage_barrier_type="bowl", seed=3)
+    B = 5
+    env = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0", obs_dtype=torch.float64)
+    oracles = [VoltageControlOracle(net, prof, a, env_id=e, do_reset=False) for e in range(B)]
+    obs, state = env.reset()
+    for e, o in enumerate(oracles):
+        oo, os_ = o.reset()
+        assert np.abs(np.array(oo) - obs[e].cpu().numpy()).max() < 1e-9 and np.abs(os_ - state[e].cpu().numpy()).max() < 1e-7
+    rng = np.random.default_rng(0)
+    for t in range(4):
+        act = rng.uniform(-0.8, 0.8, (B, net.n_sgen))
+        r, term, info = env.step(torch.as_tensor(act, device="cuda:0"))
+        res = env.results(); obs = env.get_obs()
+        for e, o in enumerate(oracles):
+            ro, to, io = o.step(act[e])
+            assert abs(ro - r[e].item()) < 1e-9 and to == bool(term[e].item())
+            assert max(abs(io[k] - info[e, c].item()) for c, k in enumerate(INFO_KEYS)) < 1e-9
+            assert np.abs(res["vm_pu"][e].cpu().numpy() - o.res.vm_pu).max() < 1e-9
+            assert np.abs(res["p_mw"][e].cpu().numpy() - o.res.p_mw).max() < 1e-9
+            assert np.abs(res["pl_mw"][e].cpu().numpy() - o.res.pl_mw).max() < 1e-9
+            assert np.abs(np.array(o.get_obs()) - obs[e].cpu().numpy()).max() < 1e-9
+    env.close()
