@@ -92,13 +92,16 @@ def test_error_paths(lib):
                  ("line_g_us_per_km", 0.0), ("line_length_km", 1.0)):
         setattr(m, k, np.append(getattr(m, k), v))
     m.line_in_service = np.append(m.line_in_service, 1).astype(np.uint8)
-    rc, h = host_handle(lib, m)
-    assert rc == _lib.load().mapdn_create.restype(-2) or rc == -2
-    assert b"meshed" in lib.mapdn_last_error(None)
-    # the same tie line out of service is fine
+    rc, h = host_handle(lib, m)           # a 33-bus meshed net is accepted (general-topology solver, tests/test_general_topology.py)
+    assert rc == 0
+    dims = _lib.CDims()
+    assert lib.mapdn_dims(h, C.byref(dims)) == 0 and dims.is_radial == 0
+    lib.mapdn_destroy(h)
+    # the same tie line out of service: radial again
     m.line_in_service[-1] = 0
     rc, h = host_handle(lib, m)
     assert rc == 0
+    assert lib.mapdn_dims(h, C.byref(dims)) == 0 and dims.is_radial == 1
     lib.mapdn_destroy(h)
     # disconnected
     d = net.copy()
