@@ -165,6 +165,14 @@ int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, i
 int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int32_t add_noise,
                double* reward, uint8_t* terminated, double* info, void* stream);
 
+/* step() immediately followed by get_obs(), the pair every caller of the reference issues (models/model.py:216,219;
+ * utilities/tester.py:48-49) as one call: the same four launches as mapdn_step + mapdn_get_obs, one host entry.
+ * (A single fused post-solve kernel — commit + profile advance + gather out of an LDS tile — was built and measured:
+ * 29.5 us against 26.3 us for the two wide launches on case141 x 4096; not kept, see DESIGN.md.)
+ * obs: device [B, n_agents, obs_size] of obs_dtype. */
+int mapdn_step_obs(mapdn_handle* h, const void* actions, int32_t actions_dtype, int32_t add_noise,
+                   double* reward, uint8_t* terminated, double* info, void* obs, int32_t obs_dtype, void* stream);
+
 /* get_obs() — voltage_control_env.py:232-316 (distributed mode): [B, n_agents, obs_size]. */
 int mapdn_get_obs(mapdn_handle* h, void* obs, int32_t dtype, void* stream);
 /* get_state() — voltage_control_env.py:213-230: [B, state_size]. */

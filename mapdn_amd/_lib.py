@@ -30,7 +30,7 @@ EXPORTS = (
     "mapdn_last_error", "mapdn_create", "mapdn_destroy", "mapdn_dims", "mapdn_set_profiles", "mapdn_reset",
     "mapdn_step", "mapdn_get_start_rows", "mapdn_get_returns", "mapdn_get_obs", "mapdn_get_state", "mapdn_get_results", "mapdn_get_loads",
     "mapdn_solve_only", "mapdn_get_ybus_dense", "mapdn_get_obs_index", "mapdn_get_schedule", "mapdn_get_flat_factors", "mapdn_stats", "mapdn_nr_timing",
-    "mapdn_nr_time_ms", "mapdn_get_auto_reset_mask", "mapdn_dense_solve",
+    "mapdn_nr_time_ms", "mapdn_get_auto_reset_mask", "mapdn_dense_solve", "mapdn_step_obs",
 )
 
 _pd = C.POINTER(C.c_double)
@@ -109,6 +109,7 @@ def load():
     lib.mapdn_set_profiles.argtypes = [vp, _pd, _pd, _pd, C.c_int64, C.c_int32, C.c_int32]
     lib.mapdn_reset.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     lib.mapdn_step.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
+    lib.mapdn_step_obs.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int32, vp]
     lib.mapdn_get_start_rows.argtypes = [vp, vp, vp]
     lib.mapdn_get_returns.argtypes = [vp, vp, vp]
     lib.mapdn_get_auto_reset_mask.argtypes = [vp, vp, vp]

@@ -436,6 +436,26 @@ int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int3
   return MAPDN_OK;
 }
 
+int mapdn_step_obs(mapdn_handle* h, const void* actions, int32_t actions_dtype, int32_t add_noise, double* reward,
+                   uint8_t* terminated, double* info, void* obs, int32_t obs_dtype, void* stream) {
+  if (!h) return MAPDN_E_INVALID;
+  if (!h->was_reset) { h->err = "step before reset"; return MAPDN_E_STATE; }
+  if (!actions || !reward || !terminated || !info || !obs) { h->err = "step_obs: null buffer"; return MAPDN_E_INVALID; }
+  if (actions_dtype != MAPDN_F32 && actions_dtype != MAPDN_F64) { h->err = "step_obs: bad actions dtype"; return MAPDN_E_INVALID; }
+  if (obs_dtype != MAPDN_F32 && obs_dtype != MAPDN_F64) { h->err = "step_obs: bad obs dtype"; return MAPDN_E_INVALID; }
+  NEEDDEV(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const Dev& d = h->d;
+  const int C = h->plan.n_agents * h->plan.obs_size;
+  launch_inject(d, MODE_STEP, actions, actions_dtype, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, add_noise, st);
+  nr_launch(h, MODE_STEP, reward, terminated, info, st);
+  launch_advance(d, add_noise, 1, 1, st);        // next profile row + res_bus commit in one wide launch
+  launch_gather(d, d.gbuf, h->obs_rows, h->obs_scale, 1.0, h->obs_xptr, h->obs_xrow, obs, obs_dtype, C, st);
+  HIPCHK(h, hipGetLastError());
+  return MAPDN_OK;
+}
+
 int mapdn_get_obs(mapdn_handle* h, void* obs, int32_t dtype, void* stream) {
   if (!h || !obs) return MAPDN_E_INVALID;
   if (!h->was_reset) { h->err = "get_obs before reset"; return MAPDN_E_STATE; }

@@ -119,6 +119,9 @@ class VoltageControlBatch:
         self._obs_hist = None
         self._was_reset = False
         self._stepped = False
+        self._obs_fresh = None                                      # dtype of the obs buffer that holds the current state's obs
+        # step() = mapdn_step_obs (False, or MAPDN_FUSED_STEP=0 for A/B runs: mapdn_step, then mapdn_get_obs)
+        self.fused_step = os.environ.get("MAPDN_FUSED_STEP", "1") != "0"
 
     # ---- plumbing -------------------------------------------------------------------------------
     def _stream(self):
@@ -189,6 +192,7 @@ class VoltageControlBatch:
                                              self.max_reset_tries, self._stream()), self._h)
         self._was_reset = True
         self._stepped = False
+        self._obs_fresh = None
         if self.history > 1:
             self._obs_hist = None
         return self.get_obs(), self.get_state()
@@ -213,20 +217,37 @@ class VoltageControlBatch:
         if a.dtype not in (torch.float32, torch.float64):
             a = a.to(torch.float64)
         a = a.reshape(self.n_envs, self.n_sgen).contiguous()
+        # step() and the get_obs() that always follows it (models/model.py:216,219) as one C call: the obs of the new
+        # state lands in the preallocated buffer of self.obs_dtype and get_obs() hands it out without another launch
+        if not self.fused_step:                                     # plain mapdn_step; get_obs() launches its own gather
+            with torch.cuda.device(self.device):
+                _lib.check(self._lib.mapdn_step(self._h, a.data_ptr(), self._code(a.dtype), int(add_noise),
+                                                self._reward.data_ptr(), self._term.data_ptr(), self._info.data_ptr(),
+                                                self._stream()), self._h)
+            self._stepped = True
+            self._obs_fresh = None
+            return self._out(self._reward), self._out(self._term), self._out(self._info)
+        buf = self._obs_buf(self.obs_dtype)
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.mapdn_step(self._h, a.data_ptr(), self._code(a.dtype), int(add_noise),
-                                            self._reward.data_ptr(), self._term.data_ptr(), self._info.data_ptr(),
-                                            self._stream()), self._h)
+            _lib.check(self._lib.mapdn_step_obs(self._h, a.data_ptr(), self._code(a.dtype), int(add_noise),
+                                                self._reward.data_ptr(), self._term.data_ptr(), self._info.data_ptr(),
+                                                buf.data_ptr(), self._code(self.obs_dtype), self._stream()), self._h)
         self._stepped = True
+        self._obs_fresh = self.obs_dtype
         return self._out(self._reward), self._out(self._term), self._out(self._info)
 
-    def get_obs(self, dtype=None):
-        dtype = dtype or self.obs_dtype
+    def _obs_buf(self, dtype):
         buf = self._obs.get(dtype)
         if buf is None:
             buf = self._obs[dtype] = torch.empty(self.n_envs, self.n_agents, self._obs_size1, dtype=dtype, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(self._lib.mapdn_get_obs(self._h, buf.data_ptr(), self._code(dtype), self._stream()), self._h)
+        return buf
+
+    def get_obs(self, dtype=None):
+        dtype = dtype or self.obs_dtype
+        buf = self._obs_buf(dtype)
+        if self._obs_fresh != dtype:                                # (after step() the obs of this dtype is already there)
+            with torch.cuda.device(self.device):
+                _lib.check(self._lib.mapdn_get_obs(self._h, buf.data_ptr(), self._code(dtype), self._stream()), self._h)
         if self.history > 1:                                        # :303-315: [zeros | older frames | newest]
             o1, key = self._obs_size1, (dtype, "hist")
             pair = self._obs.get(key)

@@ -818,3 +818,37 @@ def test_auto_reset_runs_consecutive_episodes_like_the_reference_loop():
         r, term, info = env.step(torch.zeros(2, net.n_sgen, dtype=torch.float64, device="cuda:0"))
     assert term.all() and (r == 0).all() and not env.auto_reset_mask().any()
     env.close()
+
+
+@pytest.mark.parametrize("case,obs_dtype", [("case33", torch.float64), ("case141", torch.float32), ("case322", torch.float32)])
+def test_fused_step_obs_equals_step_then_get_obs(case, obs_dtype):
+    """mapdn_step_obs (step + get_obs as one C call, what VoltageControlBatch.step() issues) against mapdn_step followed
+    by mapdn_get_obs on twin envs: bit-identical obs / reward / info / results over noisy steps, including an unsolvable
+    step (rollback: the obs of the previous state with the new PV)"""
+    B = 77
+    net, prof = make_case(case)
+    a = args_for(case, seed=5)
+    fused = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0", obs_dtype=obs_dtype)
+    plain = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0", obs_dtype=obs_dtype)
+    plain.fused_step = False
+    o1, s1 = fused.reset(); o2, s2 = plain.reset()
+    assert torch.equal(o1, o2) and torch.equal(s1, s2)
+    rng = np.random.default_rng(1)
+    for t in range(6):
+        act = rng.uniform(-SCALE[case], SCALE[case], (B, net.n_sgen))
+        if t == 3:
+            act[5] = 400.0                                       # absurd q: this env's power flow diverges
+        ta = torch.as_tensor(act, device="cuda:0")
+        r1, d1, i1 = fused.step(ta); r2, d2, i2 = plain.step(ta)
+        assert torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(i1, i2)
+        assert torch.equal(fused.get_obs(), plain.get_obs())
+        assert torch.equal(fused.get_state(), plain.get_state())
+        for k, v in fused.results().items():
+            assert torch.equal(v, plain.results()[k]), k
+        lp1, lq1 = fused.loads(); lp2, lq2 = plain.loads()
+        assert torch.equal(lp1, lp2) and torch.equal(lq1, lq2)
+        if t == 3:
+            assert bool(d1[5]) and i1[5, 10] == 1.0              # destroy
+    # a second get_obs with another dtype still launches its own gather
+    assert torch.allclose(fused.get_obs(torch.float64).float(), fused.get_obs(torch.float32), rtol=1e-6, atol=1e-6)
+    fused.close(); plain.close()

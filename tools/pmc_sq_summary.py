@@ -8,7 +8,7 @@ import csv
 import sys
 
 
-def main(out, files, sub="k_nr_wtree"):
+def main(out, files, sub="k_nr_tree"):
     vals = collections.defaultdict(list)
     for f in files:
         for row in csv.DictReader(open(f)):
@@ -29,4 +29,7 @@ def main(out, files, sub="k_nr_wtree"):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2:])
+    if sys.argv[1] == "--kernel":                  # pmc_sq_summary.py --kernel <substring> <out.txt> <pass.csv> ...
+        main(sys.argv[3], sys.argv[4:], sys.argv[2])
+    else:
+        main(sys.argv[1], sys.argv[2:])
