@@ -88,6 +88,12 @@ typedef struct mapdn_netspec {
   double ext_grid_vm_pu;
   double sn_mva;
   double f_hz;
+  /* optional columns (NULL = default), appended so that zero-initialised older callers keep working */
+  const double* br_g_pu;            /* [n_branch_pu] shunt conductance of the pi branch: ppc BR_B = br_b_pu - 1j*br_g_pu
+                                       (a transformer's iron losses after pandapower's T->pi conversion); NULL = 0   */
+  const double* load_scaling;       /* [n_load] net.load.scaling * in_service (pd2ppc: PD = sum p_mw * scaling); NULL = 1 */
+  const double* sgen_scaling;       /* [n_sgen] net.sgen.scaling * in_service; runpp and res_sgen see p, q * scaling, the env
+                                       (obs, q clip, :189) the raw table values; NULL = 1                               */
 } mapdn_netspec;
 
 /* Constructor kwargs of VoltageControl (args/env_args/var_voltage_control.yaml:3-20). */

@@ -128,7 +128,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   UP(bus_of_pos, P.bus_of_pos); UP(root_children, P.root_children); UP(root_y, P.root_y);
   d.n_root_children = (int32_t)P.root_children.size();
   UP(load_ptr, P.load_ptr); UP(load_idx, P.load_idx); UP(sgen_ptr, P.sgen_ptr); UP(sgen_idx, P.sgen_idx);
-  UP(shunt_p, P.shunt_p); UP(shunt_q, P.shunt_q);
+  UP(shunt_p, P.shunt_p); UP(shunt_q, P.shunt_q); UP(load_scale, P.load_scale); UP(sgen_scale, P.sgen_scale);
   {
     std::vector<LineFlow> padded(P.lines);               // read 16 bytes at a time by the NR kernel's LDS staging
     if (padded.size() % 2) padded.push_back(LineFlow{});

@@ -125,8 +125,8 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
       const double p = profile_value(d, e, ar_row, draw, STREAM_LOAD_P, li, d.ns, add_noise);
       const double q = profile_value(d, e, ar_row, draw, STREAM_LOAD_Q, li, d.ns + d.nl, add_noise);
       d.cur_pl[o] = p; d.cur_ql[o] = q;
-      P += p; Q += q;
-    } else { P += pl[o]; Q += ql[o]; }
+      P += p * d.load_scale[li]; Q += q * d.load_scale[li];
+    } else { P += pl[o] * d.load_scale[li]; Q += ql[o] * d.load_scale[li]; }   // pd2ppc: PD = sum p_mw * scaling
   }
   for (int i = d.sgen_ptr[k]; i < d.sgen_ptr[k + 1]; ++i) {
     const int j = d.sgen_idx[i];
@@ -149,7 +149,7 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
       } else q = 0.0;                            // base-net q_mvar (deepcopy of base_powergrid, :106)
       d.q_new[o] = q;
     }
-    P -= p; Q -= q;
+    P -= p * d.sgen_scale[j]; Q -= q * d.sgen_scale[j];
   }
   if (k < d.n) {   // scheduled injection as an (re, im) pair, stored in the order the NR workers consume it
     double2* sb = (double2*)((char*)d.nrbuf + d.sb_off) + (size_t)d.sb_index[k] * d.Bp + e;

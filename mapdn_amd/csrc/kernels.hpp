@@ -31,6 +31,7 @@ struct Dev {
   const int32_t* bus_of_pos;
   const int32_t *load_ptr, *load_idx, *sgen_ptr, *sgen_idx;
   const double *shunt_p, *shunt_q;
+  const double *load_scale, *sgen_scale;     // [nl], [ns] element scaling * in_service (runpp sees p, q * scaling)
   const LineFlow* lines;
   const int32_t* root_children; const double* root_y; int32_t n_root_children;   // children of the slack: position, Y_root,k
   double yrr0, yrr1;

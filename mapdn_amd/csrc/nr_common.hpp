@@ -178,7 +178,7 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
     const size_t o = (size_t)j * SB + e;
     const double qn = d.q_new[o];
     if (commitf) d.cur_q[o] = qn;
-    q_loss += fabs(qn); q_fail += fabs(qn);                          // :604-606, :189
+    q_loss += fabs(qn * d.sgen_scale[j]); q_fail += fabs(qn);       // res_sgen.q_mvar (:604-606); the raw table (:189)
   }
   // ---- slow path (wave-uniform, rare): an env of this wave is active but did not converge -> its
   // statistics come from the PREVIOUS committed state (voltage_control_env.py:190 restores last_powergrid)
@@ -193,7 +193,7 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
       a_bar += barrier(d.barrier_type, v);
     }
     for (unsigned l = t; l < (unsigned)d.n_line; l += Wt) a_ll += valid ? d.pl[(size_t)l * SB + e] : 0.0;
-    for (unsigned j = t; j < (unsigned)d.ns; j += Wt) a_ql += fabs(d.cur_q[(size_t)j * SB + e]);
+    for (unsigned j = t; j < (unsigned)d.ns; j += Wt) a_ql += fabs(d.cur_q[(size_t)j * SB + e] * d.sgen_scale[j]);
     if (!commitf) { n_lo = a_lo; n_hi = a_hi; dev = a_dev; vsum = a_sum; mdrop = a_drop; mrise = a_rise; bar = a_bar; line_loss = a_ll; q_loss = a_ql; }
   }
   if (mode == MODE_RESET) {

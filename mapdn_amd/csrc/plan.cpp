@@ -35,7 +35,7 @@ PiBranch pi_from_pu(const mapdn_netspec& net, int k) {
   const double ratio = net.br_ratio[k] == 0.0 ? 1.0 : net.br_ratio[k];
   const cplx tap = std::polar(ratio, net.br_shift_deg[k] * M_PI / 180.0);
   const cplx ys = 1.0 / cplx(net.br_r_pu[k], net.br_x_pu[k]);
-  const cplx ytt = ys + cplx(0, 1) * cplx(net.br_b_pu[k], 0.0) / 2.0;
+  const cplx ytt = ys + cplx(0, 1) * cplx(net.br_b_pu[k], net.br_g_pu ? -net.br_g_pu[k] : 0.0) / 2.0;   // BR_B = b - 1j*g
   return PiBranch{net.br_from_bus[k], net.br_to_bus[k], ytt / (tap * std::conj(tap)),
                   -ys / std::conj(tap), -ys / tap, ytt};
 }
@@ -229,6 +229,9 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   csr(net.n_sgen, net.sgen_bus, P.sgen_ptr, P.sgen_idx);
   for (int b = 0; b < nb; ++b) { P.shunt_p[P.pos_of_bus[b]] = sh_p_bus[b]; P.shunt_q[P.pos_of_bus[b]] = sh_q_bus[b]; }
   P.sgen_bus.assign(net.sgen_bus, net.sgen_bus + net.n_sgen);
+  P.load_scale.assign(net.n_load, 1.0); P.sgen_scale.assign(net.n_sgen, 1.0);
+  if (net.load_scaling) P.load_scale.assign(net.load_scaling, net.load_scaling + net.n_load);
+  if (net.sgen_scaling) P.sgen_scale.assign(net.sgen_scaling, net.sgen_scaling + net.n_sgen);
 
   // ---- get_obs (distributed mode) — voltage_control_env.py:245-274 --------------------------------
   const int ss = cfg.state_space;

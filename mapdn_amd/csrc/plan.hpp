@@ -112,6 +112,7 @@ struct Plan {
   std::vector<int32_t> load_ptr, load_idx, sgen_ptr, sgen_idx;
   std::vector<double> shunt_p, shunt_q;         // [nb] by position, MW/MVAr at 1 p.u.
   std::vector<int32_t> sgen_bus;                // [ns] bus ids
+  std::vector<double> load_scale, sgen_scale;   // [nl], [ns] scaling * in_service (pd2ppc sums p, q * scaling)
 
   // get_obs / get_state tables
   int32_t n_agents = 0, obs_size = 0, state_size = 0, max_zone = 0;

@@ -5,7 +5,9 @@
   element each, multiplied by pv_scale / demand_scale; the sampling interval and the day count
   come from the index exactly like `_select_start_day` (:394-398);
 * `NetSpec` <-> `netspec.npz` (the pandapower columns the path reads, see netspec.py);
-* `from_pandapower(net)` for boxes that do have pandapower (column copying, guarded import).
+* `from_pandapower(net)`: pandapower tables -> NetSpec, i.e. what pd2ppc builds for runpp's defaults — lines with their
+  switches, two-winding transformers (T -> pi, tap changer), load / sgen scaling and in_service, shunts; everything
+  the hot path cannot represent is refused loudly.
 """
 from __future__ import annotations
 
@@ -66,37 +68,157 @@ def load_netspec(path: str) -> NetSpec:
     return NetSpec(**kw)
 
 
+def _col(df, name, default):
+    """column `name` of a pandapower table as float64, `default` where the column is missing or NaN"""
+    if name not in df:
+        return np.full(len(df), float(default))
+    v = df[name].to_numpy(dtype=np.float64, na_value=np.nan)
+    return np.where(np.isnan(v), float(default), v)
+
+
+def trafo_to_pi(trafo, bus_vn_kv: np.ndarray, net_sn_mva: float, calculate_voltage_angles: bool = False):
+    """pandapower 2.7.0 build_branch._calc_branch_values_from_trafo_df with runpp's defaults (trafo_model="t",
+    no tap-dependent impedance), restated [PP-recalled; SURVEY.md Appendix A.2]: two-winding transformers ->
+    ppc branch columns (f = hv_bus, t = lv_bus, r, x, b, g, ratio, shift) in per unit on `net_sn_mva`.
+
+      _calc_tap_from_dataframe      vn_hv/lv *= 1 + (tap_pos - tap_neutral) * tap_step_percent / 100 on tap_side
+      _calc_nominal_ratio_...       ratio = (vn_trafo_hv / vn_hv_bus) / (vn_trafo_lv / vn_lv_bus)
+      _calc_r_x_from_dataframe      tap_lv = (vn_trafo_lv / vn_lv_bus)^2 * net_sn;  z = vk% / 100 / sn_trafo * tap_lv;
+                                    r = vkr% / 100 / sn_trafo * tap_lv;  x = sign(z) sqrt(z^2 - r^2);  both / parallel
+      _calc_y_from_dataframe        baseR = vn_lv_bus^2 / net_sn;  b_real = pfe_kw * 1e-3 / vn_lv_kv^2 * baseR;
+                                    b_img = sqrt(max(0, (i0% / 100 * sn_trafo)^2 - (pfe_kw * 1e-3)^2)) * baseR / vn_lv_kv^2;
+                                    y = (-1j * b_real - b_img * sign(i0%)) / (vn_trafo_lv / vn_lv_kv)^2 * parallel
+      _wye_delta (T -> pi)          za = (r + jx) / 2; zc = -1j / y; zs = za^2 + 2 za zc; (r + jx) = zs / zc; y = -2j / (zs / za)
+    The ppc branch then has BR_B = y (= b - 1j*g), TAP = ratio, SHIFT = shift_degree when voltage angles are calculated
+    (runpp calculate_voltage_angles="auto": only if a line touches a bus above 70 kV), else 0.
+    Out-of-service transformers are dropped.  Phase-shifting / cross regulators (tap_step_degree != 0, tap_phase_shifter)
+    and tap-dependent impedance are refused."""
+    t = trafo.sort_index()
+    on = t["in_service"].to_numpy(bool) if "in_service" in t else np.ones(len(t), bool)
+    t = t[on]
+    n = len(t)
+    if n == 0:
+        z = np.zeros(0)
+        return dict(br_from_bus=np.zeros(0, np.int32), br_to_bus=np.zeros(0, np.int32), br_r_pu=z, br_x_pu=z, br_b_pu=z,
+                    br_g_pu=z, br_ratio=z, br_shift_deg=z)
+    if "tap_phase_shifter" in t and t["tap_phase_shifter"].fillna(False).to_numpy(bool).any():
+        raise NotImplementedError("transformers with tap_phase_shifter=True are not converted")
+    if np.any(_col(t, "tap_step_degree", 0.0) != 0.0):
+        raise NotImplementedError("transformers with tap_step_degree != 0 (cross / phase regulators) are not converted")
+    if "tap_dependent_impedance" in t and t["tap_dependent_impedance"].fillna(False).to_numpy(bool).any():
+        raise NotImplementedError("tap-dependent transformer impedance is not converted")
+    hv = t["hv_bus"].to_numpy(np.int64); lv = t["lv_bus"].to_numpy(np.int64)
+    vn_hv_bus, vn_lv_bus = bus_vn_kv[hv], bus_vn_kv[lv]
+    vnh, vnl = t["vn_hv_kv"].to_numpy(np.float64).copy(), t["vn_lv_kv"].to_numpy(np.float64).copy()
+    vn_lv_kv = vnl.copy()                                        # nameplate, before the tap changer
+    tap_diff = _col(t, "tap_pos", 0.0) - _col(t, "tap_neutral", 0.0)
+    tap_step = _col(t, "tap_step_percent", 0.0) / 100.0
+    side = t["tap_side"].to_numpy() if "tap_side" in t else np.full(n, None)
+    vnh = np.where(side == "hv", vnh * (1.0 + tap_diff * tap_step), vnh)
+    vnl = np.where(side == "lv", vnl * (1.0 + tap_diff * tap_step), vnl)
+    ratio = (vnh / vn_hv_bus) / (vnl / vn_lv_bus)
+    shift = _col(t, "shift_degree", 0.0) if calculate_voltage_angles else np.zeros(n)
+    parallel = _col(t, "parallel", 1.0)
+    sn_t = t["sn_mva"].to_numpy(np.float64)
+    tap_lv = np.square(vnl / vn_lv_bus) * net_sn_mva
+    z_sc = t["vk_percent"].to_numpy(np.float64) / 100.0 / sn_t * tap_lv
+    r_sc = t["vkr_percent"].to_numpy(np.float64) / 100.0 / sn_t * tap_lv
+    x_sc = np.sign(z_sc) * np.sqrt(np.maximum(z_sc ** 2 - r_sc ** 2, 0.0))
+    r, x = r_sc / parallel, x_sc / parallel
+    base_r = np.square(vn_lv_bus) / net_sn_mva
+    pfe = t["pfe_kw"].to_numpy(np.float64) * 1e-3
+    i0 = t["i0_percent"].to_numpy(np.float64)
+    b_real = pfe / np.square(vn_lv_kv) * base_r
+    b_img = np.sqrt(np.maximum((i0 / 100.0 * sn_t) ** 2 - pfe ** 2, 0.0)) * base_r / np.square(vn_lv_kv)
+    y = (-1j * b_real - b_img * np.sign(i0)) / np.square(vnl / vn_lv_kv) * parallel
+    nz = y != 0                                                  # _wye_delta: T -> pi for transformers with a magnetising branch
+    za = (r[nz] + 1j * x[nz]) / 2.0
+    zc = -1j / y[nz]
+    zs = za * za + 2.0 * za * zc
+    zab = zs / zc
+    r, x, y = r.copy(), x.copy(), y.copy()
+    r[nz], x[nz], y[nz] = zab.real, zab.imag, -2j / (zs / za)
+    return dict(br_from_bus=hv.astype(np.int32), br_to_bus=lv.astype(np.int32), br_r_pu=r, br_x_pu=x, br_b_pu=y.real,
+                br_g_pu=-y.imag, br_ratio=ratio, br_shift_deg=shift)
+
+
 def from_pandapower(net) -> NetSpec:
-    """pandapowerNet -> NetSpec by column copying (lines, loads, sgens, one ext_grid, shunts).
-    Transformers and bus-bus switches are not converted here."""
-    if len(net.ext_grid) != 1:
-        raise NotImplementedError("exactly one ext_grid expected")
-    if len(getattr(net, "trafo", [])):
-        raise NotImplementedError("transformers: convert to per-unit pi branches (NetSpec.br_*) first")
-    bus_index = np.sort(net.bus.index.to_numpy())
+    """pandapowerNet (`pp.from_pickle(model.p)`, voltage_control_env.py:400-405) -> NetSpec: what pd2ppc would build for
+    runpp's defaults.  Converted: buses (0..n-1, all in service), lines (line switches: an OPEN switch takes the line
+    out, as pandapower does), two-winding transformers (trafo_to_pi), loads / sgens with `scaling` and `in_service`,
+    shunts (step, in_service), one ext_grid.  Refused loudly, never guessed: voltage-dependent loads
+    (const_z_percent / const_i_percent: the constant-Z share would be a time-varying shunt), closed bus-bus switches
+    (bus fusion), generators, three-winding transformers, impedances, wards, dc lines, storage."""
+    def table(name):
+        t = net[name] if name in net else None
+        return t if t is not None and len(t) else None
+    for name in ("gen", "trafo3w", "impedance", "ward", "xward", "dcline", "storage", "motor", "asymmetric_load", "asymmetric_sgen"):
+        t = table(name)
+        if t is not None and (("in_service" not in t) or t["in_service"].to_numpy(bool).any()):
+            raise NotImplementedError(f"net.{name} has in-service rows: not part of the MAPDN hot path, not converted")
+    if len(net.ext_grid) != 1 or not bool(net.ext_grid["in_service"].iloc[0] if "in_service" in net.ext_grid else True):
+        raise NotImplementedError("exactly one in-service ext_grid expected")
+    bus = net.bus.sort_index()
+    bus_index = bus.index.to_numpy()
     if not np.array_equal(bus_index, np.arange(len(bus_index))):
         raise NotImplementedError("bus indices must be 0..n-1")
-    zones = net.bus["zone"].sort_index().to_numpy()
+    if "in_service" in bus and not bus["in_service"].to_numpy(bool).all():
+        raise NotImplementedError("out-of-service buses are not converted")
+    vn = bus["vn_kv"].to_numpy(np.float64)
 
     def zid(z):
         return 0 if z == "main" else int(str(z).replace("zone", ""))
     line = net.line.sort_index()
-    sh = getattr(net, "shunt", None)
+    line_on = line["in_service"].to_numpy(bool).copy()
+    trafo = table("trafo")
+    trafo_on = None if trafo is None else trafo.sort_index()["in_service"].to_numpy(bool).copy()
+    sw = table("switch")
+    if sw is not None:
+        closed = sw["closed"].to_numpy(bool)
+        et = sw["et"].to_numpy()
+        if np.any((et == "b") & closed):
+            raise NotImplementedError("closed bus-bus switches (bus fusion) are not converted")
+        pos = {idx: i for i, idx in enumerate(line.index)}
+        for el in sw["element"].to_numpy()[(et == "l") & ~closed]:
+            line_on[pos[int(el)]] = False                       # a line with an open switch at either end carries nothing
+        if trafo is not None:
+            tpos = {idx: i for i, idx in enumerate(trafo.sort_index().index)}
+            for el in sw["element"].to_numpy()[(et == "t") & ~closed]:
+                trafo_on[tpos[int(el)]] = False
+    load, sgen = net.load, net.sgen
+    for col in ("const_z_percent", "const_i_percent"):
+        if col in load and np.any(_col(load, col, 0.0) != 0.0):
+            raise NotImplementedError(f"net.load.{col} != 0: voltage-dependent loads (runpp voltage_depend_loads=True) are not converted")
+    on = lambda t: (t["in_service"].to_numpy(bool) if "in_service" in t else np.ones(len(t), bool)).astype(np.float64)
     kw = dict(
-        name=str(getattr(net, "name", "net")), bus_vn_kv=net.bus["vn_kv"].sort_index().to_numpy(),
-        bus_zone=np.array([zid(z) for z in zones]),
+        name=str(net["name"] if "name" in net and net["name"] else "net"), bus_vn_kv=vn,
+        bus_zone=np.array([zid(z) for z in bus["zone"].to_numpy()]),
         line_from_bus=line["from_bus"].to_numpy(), line_to_bus=line["to_bus"].to_numpy(),
         line_r_ohm_per_km=line["r_ohm_per_km"].to_numpy(), line_x_ohm_per_km=line["x_ohm_per_km"].to_numpy(),
-        line_c_nf_per_km=line["c_nf_per_km"].to_numpy(),
-        line_g_us_per_km=line["g_us_per_km"].to_numpy() if "g_us_per_km" in line else np.zeros(len(line)),
+        line_c_nf_per_km=line["c_nf_per_km"].to_numpy(), line_g_us_per_km=_col(line, "g_us_per_km", 0.0),
         line_length_km=line["length_km"].to_numpy(), line_parallel=line["parallel"].to_numpy(),
-        line_in_service=line["in_service"].to_numpy().astype(np.uint8),
-        load_bus=net.load["bus"].to_numpy(), sgen_bus=net.sgen["bus"].to_numpy(),
-        sgen_zone=np.array([zid(z) for z in net.sgen["name"].to_numpy()]),
+        line_in_service=line_on.astype(np.uint8),
+        load_bus=load["bus"].to_numpy(), sgen_bus=sgen["bus"].to_numpy(),
+        sgen_zone=np.array([zid(z) for z in sgen["name"].to_numpy()]),
+        load_scaling=_col(load, "scaling", 1.0) * on(load), sgen_scaling=_col(sgen, "scaling", 1.0) * on(sgen),
         ext_grid_bus=int(net.ext_grid["bus"].iloc[0]), ext_grid_vm_pu=float(net.ext_grid["vm_pu"].iloc[0]),
         sn_mva=float(net.sn_mva), f_hz=float(net.f_hz))
-    if sh is not None and len(sh):
-        kw.update(shunt_bus=sh["bus"].to_numpy(), shunt_p_mw=sh["p_mw"].to_numpy(), shunt_q_mvar=sh["q_mvar"].to_numpy())
+    if trafo is not None:
+        t = trafo.sort_index().copy()
+        t["in_service"] = trafo_on
+        # runpp calculate_voltage_angles="auto": True only if a line touches a bus above 70 kV
+        hv_buses = set(np.nonzero(vn > 70.0)[0].tolist())
+        touched = set(line["from_bus"].to_numpy().tolist()) | set(line["to_bus"].to_numpy().tolist())
+        kw.update(trafo_to_pi(t, vn, float(net.sn_mva), calculate_voltage_angles=bool(hv_buses & touched)))
+    sh = table("shunt")
+    if sh is not None:
+        # build_bus._calc_shunts_and_add_on_ppc: p, q per step, referred from the shunt's vn_kv to the bus voltage
+        vn_bus = vn[sh["bus"].to_numpy(np.int64)]
+        vn_sh = _col(sh, "vn_kv", np.nan)
+        vn_sh = np.where(np.isnan(vn_sh), vn_bus, vn_sh)
+        f = on(sh) * _col(sh, "step", 1.0) * np.square(vn_bus / vn_sh)
+        kw.update(shunt_bus=sh["bus"].to_numpy(), shunt_p_mw=sh["p_mw"].to_numpy(np.float64) * f,
+                  shunt_q_mvar=sh["q_mvar"].to_numpy(np.float64) * f)
     return NetSpec(**kw)
 
 

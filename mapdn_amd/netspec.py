@@ -59,18 +59,29 @@ class NetSpec:
     br_b_pu: np.ndarray = field(default_factory=lambda: np.zeros(0))
     br_ratio: np.ndarray = field(default_factory=lambda: np.zeros(0))
     br_shift_deg: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    br_g_pu: np.ndarray = field(default_factory=lambda: np.zeros(0))      # ppc BR_B = br_b_pu - 1j*br_g_pu (trafo iron losses)
     # constant-impedance shunts (pandapower `net.shunt`, MW/MVAr at 1 p.u.; consumer sign)
     shunt_bus: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     shunt_p_mw: np.ndarray = field(default_factory=lambda: np.zeros(0))
     shunt_q_mvar: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    # net.load.scaling / net.sgen.scaling times in_service (pd2ppc: PD = sum p_mw * scaling over in-service elements);
+    # empty = all ones
+    load_scaling: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    sgen_scaling: np.ndarray = field(default_factory=lambda: np.zeros(0))
 
     def __post_init__(self):
         f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
         for k in ("bus_vn_kv", "line_r_ohm_per_km", "line_x_ohm_per_km", "line_c_nf_per_km",
                   "line_g_us_per_km", "line_length_km", "br_r_pu", "br_x_pu", "br_b_pu",
-                  "br_ratio", "br_shift_deg", "shunt_p_mw", "shunt_q_mvar"):
+                  "br_ratio", "br_shift_deg", "shunt_p_mw", "shunt_q_mvar", "br_g_pu", "load_scaling", "sgen_scaling"):
             setattr(self, k, f64(getattr(self, k)))
+        if self.br_g_pu.shape[0] == 0 and np.shape(self.br_r_pu)[0]:
+            self.br_g_pu = np.zeros(np.shape(self.br_r_pu)[0])
+        if self.load_scaling.shape[0] == 0:
+            self.load_scaling = np.ones(np.shape(self.load_bus)[0])
+        if self.sgen_scaling.shape[0] == 0:
+            self.sgen_scaling = np.ones(np.shape(self.sgen_bus)[0])
         for k in ("bus_zone", "line_from_bus", "line_to_bus", "line_parallel", "load_bus",
                   "sgen_bus", "sgen_zone", "br_from_bus", "br_to_bus", "shunt_bus"):
             setattr(self, k, i32(getattr(self, k)))

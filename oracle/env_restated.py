@@ -133,7 +133,7 @@ class VoltageControlOracle:
             solvable = res.converged
             if solvable:
                 self.res = res
-                self.res_sgen_q = self.sgen_q.copy()
+                self.res_sgen_q = self.sgen_q * self.net.sgen_scaling     # res_sgen.q_mvar = q_mvar * scaling
         return self.get_obs(), self.get_state()
 
     def manual_reset(self, day, hour, interval):
@@ -166,7 +166,7 @@ class VoltageControlOracle:
         res = runpp_restated(self.net, self.load_p, self.load_q, self.sgen_p, self.sgen_q)
         if res.converged:
             self.res = res
-            self.res_sgen_q = self.sgen_q.copy()
+            self.res_sgen_q = self.sgen_q * self.net.sgen_scaling     # res_sgen.q_mvar = q_mvar * scaling
         return res.converged
 
     def _clip_reactive_power(self, reactive_actions, active_power):                          # :568-572

@@ -64,7 +64,7 @@ def build_branches(net):
         t = np.concatenate([t, net.br_to_bus.astype(np.int64)])
         r = np.concatenate([r, net.br_r_pu])
         x = np.concatenate([x, net.br_x_pu])
-        bc = np.concatenate([bc, net.br_b_pu.astype(np.complex128)])
+        bc = np.concatenate([bc, net.br_b_pu - 1j * net.br_g_pu])          # BR_B = b - 1j*g (trafo: iron losses)
         tap = np.concatenate([tap, ratio * np.exp(1j * np.pi / 180.0 * net.br_shift_deg)])
         is_line = np.concatenate([is_line, np.zeros(net.n_branch_pu, dtype=bool)])
     return f, t, r, x, bc, tap, is_line
@@ -101,13 +101,13 @@ def make_ybus(net):
 
 def bus_demand(net, p_load, q_load, p_sgen, q_sgen):
     """pandapower/build_bus.py::_calc_pq_elements_and_add_on_ppc: PD/QD per bus in MW/MVAr,
-    loads positive, sgens negative (scaling == 1, all in service)."""
+    loads positive, sgens negative, each times its scaling * in_service."""
     pd_ = np.zeros(net.n_bus)
     qd = np.zeros(net.n_bus)
-    np.add.at(pd_, net.load_bus, p_load)
-    np.add.at(qd, net.load_bus, q_load)
-    np.add.at(pd_, net.sgen_bus, -np.asarray(p_sgen))
-    np.add.at(qd, net.sgen_bus, -np.asarray(q_sgen))
+    np.add.at(pd_, net.load_bus, np.asarray(p_load) * net.load_scaling)
+    np.add.at(qd, net.load_bus, np.asarray(q_load) * net.load_scaling)
+    np.add.at(pd_, net.sgen_bus, -np.asarray(p_sgen) * net.sgen_scaling)
+    np.add.at(qd, net.sgen_bus, -np.asarray(q_sgen) * net.sgen_scaling)
     return pd_, qd
 
 

@@ -1,0 +1,208 @@
+"""pandapower tables -> NetSpec (mapdn_amd.data.from_pandapower; reference loader voltage_control_env.py:400-405):
+transformers (T -> pi, tap changer), switches, load / sgen scaling and in_service, shunts, loud refusals.
+pandapower itself is absent, so the transformer conversion is pinned on (a) the nameplate definitions
+(no-load losses / current, short-circuit voltage), (b) an explicit three-node T circuit solved by the oracle: the
+wye-delta conversion is an exact circuit identity, so both must give the same terminal voltages."""
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import importlib.util                                    # noqa: E402
+# the stub's table container (plain attribute dict, no arithmetic), loaded by path so that `import pandapower` keeps
+# failing for tests/test_pandapower_pin.py's importorskip
+_spec = importlib.util.spec_from_file_location(
+    "_pp_stub_auxiliary", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "pp_stub", "pandapower", "auxiliary.py"))
+_aux = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_aux)
+pandapowerNet = _aux.pandapowerNet
+
+from mapdn_amd.data import from_pandapower, trafo_to_pi  # noqa: E402
+from mapdn_amd.netspec import NetSpec                    # noqa: E402
+from oracle.pp_restated import make_ybus, runpp_restated  # noqa: E402
+
+TRAFO = dict(hv_bus=0, lv_bus=1, sn_mva=25.0, vn_hv_kv=110.0, vn_lv_kv=20.0, vk_percent=12.0, vkr_percent=0.41,
+             pfe_kw=14.0, i0_percent=0.07, shift_degree=150.0, tap_side="hv", tap_neutral=0, tap_min=-9, tap_max=9,
+             tap_step_percent=1.5, tap_step_degree=0.0, tap_pos=-2, tap_phase_shifter=False, parallel=1, df=1.0, in_service=True)
+
+
+def substation_net(trafo=TRAFO, sn_mva=10.0):
+    """110 kV grid bus -> 25 MVA 110/20 kV transformer -> small 20 kV feeder with two PV zones"""
+    net = pandapowerNet()
+    net["name"] = "substation"; net["sn_mva"] = sn_mva; net["f_hz"] = 50.0
+    net["bus"] = pd.DataFrame({"name": [f"b{i}" for i in range(6)], "vn_kv": [110.0, 20.0, 20.0, 20.0, 20.0, 20.0], "type": "b",
+                               "zone": ["main", "main", "zone1", "zone1", "zone2", "zone2"], "in_service": True})
+    net["line"] = pd.DataFrame({"from_bus": [1, 2, 1, 4], "to_bus": [2, 3, 4, 5], "length_km": [2.0, 1.5, 3.0, 1.0],
+                                "r_ohm_per_km": [0.2, 0.3, 0.25, 0.4], "x_ohm_per_km": [0.12, 0.1, 0.11, 0.1],
+                                "c_nf_per_km": [250.0, 200.0, 240.0, 210.0], "g_us_per_km": 0.0, "max_i_ka": 0.4, "df": 1.0,
+                                "parallel": 1, "type": "cs", "in_service": True})
+    net["load"] = pd.DataFrame({"name": None, "bus": [2, 3, 4, 5, 5], "p_mw": [1.0, 0.8, 1.2, 0.5, 0.3], "q_mvar": [0.3, 0.2, 0.4, 0.1, 0.1],
+                                "const_z_percent": 0.0, "const_i_percent": 0.0, "sn_mva": np.nan, "scaling": [1.0, 1.0, 0.9, 1.0, 1.0],
+                                "in_service": [True, True, True, True, False], "type": "wye"})
+    net["sgen"] = pd.DataFrame({"name": ["zone1", "zone2"], "bus": [3, 5], "p_mw": [1.5, 0.7], "q_mvar": [0.2, -0.1], "sn_mva": np.nan,
+                                "scaling": [1.0, 0.5], "in_service": True, "type": "PV", "current_source": True})
+    net["ext_grid"] = pd.DataFrame({"name": [None], "bus": [0], "vm_pu": [1.02], "va_degree": [0.0], "in_service": [True]})
+    net["trafo"] = pd.DataFrame([trafo])
+    net["shunt"] = pd.DataFrame({"bus": [4], "p_mw": [0.0], "q_mvar": [-0.25], "vn_kv": [20.0], "step": [2], "max_step": [3], "in_service": [True]})
+    net["switch"] = pd.DataFrame({"bus": [4], "element": [3], "et": ["l"], "type": ["LBS"], "closed": [True]})
+    return net
+
+
+def pre_pi(t, vn_lv_bus, net_sn):
+    """the T-model values of trafo_to_pi before the wye-delta step (same restated formulas)"""
+    tapped_hv = t["vn_hv_kv"] * (1 + (t["tap_pos"] - t["tap_neutral"]) * t["tap_step_percent"] / 100) if t["tap_side"] == "hv" else t["vn_hv_kv"]
+    tapped_lv = t["vn_lv_kv"] * (1 + (t["tap_pos"] - t["tap_neutral"]) * t["tap_step_percent"] / 100) if t["tap_side"] == "lv" else t["vn_lv_kv"]
+    tap_lv = (tapped_lv / vn_lv_bus) ** 2 * net_sn
+    z = t["vk_percent"] / 100 / t["sn_mva"] * tap_lv
+    r = t["vkr_percent"] / 100 / t["sn_mva"] * tap_lv
+    x = np.sqrt(z * z - r * r)
+    base_r = vn_lv_bus ** 2 / net_sn
+    pfe = t["pfe_kw"] * 1e-3
+    b_real = pfe / t["vn_lv_kv"] ** 2 * base_r
+    b_img = np.sqrt(max((t["i0_percent"] / 100 * t["sn_mva"]) ** 2 - pfe ** 2, 0.0)) * base_r / t["vn_lv_kv"] ** 2
+    y = (-1j * b_real - b_img) / (tapped_lv / t["vn_lv_kv"]) ** 2
+    return r, x, y, tapped_hv, tapped_lv
+
+
+def test_transformer_nameplate_definitions():
+    """no-load: P = pfe_kw, |S| = i0% * sn (at rated lv voltage); short circuit: |z| = vk% on the transformer's own base"""
+    t = dict(TRAFO, tap_pos=0)
+    sn = 10.0
+    r, x, y, _, _ = pre_pi(t, 20.0, sn)
+    ym = 1j * y                                            # magnetising admittance (makeYbus: Ytt = Ys + 1j*BR_B/2, both halves)
+    s0 = np.conj(ym) * sn                                  # MVA drawn at 1 p.u.
+    assert abs(s0.real - t["pfe_kw"] * 1e-3) < 1e-12
+    assert abs(abs(s0) - t["i0_percent"] / 100 * t["sn_mva"]) < 1e-12 and s0.imag > 0      # inductive
+    assert abs(abs(r + 1j * x) * t["sn_mva"] / sn - t["vk_percent"] / 100) < 1e-15
+    assert abs(r * t["sn_mva"] / sn - t["vkr_percent"] / 100) < 1e-15
+
+
+@pytest.mark.parametrize("variant", ["hv_tap", "lv_tap", "offnominal_bus_kv", "parallel2", "no_magnetising"])
+def test_trafo_pi_equals_the_explicit_t_circuit(variant):
+    t = dict(TRAFO)
+    vn_lv_bus = 20.0
+    if variant == "lv_tap":
+        t.update(tap_side="lv", tap_pos=3)
+    if variant == "offnominal_bus_kv":
+        t.update(vn_lv_kv=21.0, vn_hv_kv=115.0)
+    if variant == "parallel2":
+        t.update(parallel=2)
+    if variant == "no_magnetising":
+        t.update(pfe_kw=0.0, i0_percent=0.0)
+    pnet = substation_net(t)
+    a = from_pandapower(pnet)
+    assert a.n_branch_pu == 1 and a.br_from_bus[0] == 0 and a.br_to_bus[0] == 1
+    assert a.br_shift_deg[0] == 0.0                        # no line touches a bus above 70 kV: angles are not calculated
+    assert abs(a.br_ratio[0] - pre_pi(t, vn_lv_bus, 10.0)[3] / 110.0 / (pre_pi(t, vn_lv_bus, 10.0)[4] / 20.0)) < 1e-15
+    # explicit T: hv --[za, ideal ratio at the hv side]-- star --[zb]-- lv, magnetising shunt at the star point
+    r, x, y, _, _ = pre_pi(t, vn_lv_bus, 10.0)
+    par = t["parallel"]
+    r, x, y = r / par, x / par, y * par
+    star = a.n_bus
+    ym = 1j * y
+    b = NetSpec(name="T", bus_vn_kv=np.append(a.bus_vn_kv, 20.0), bus_zone=np.append(a.bus_zone, 0),
+                line_from_bus=a.line_from_bus, line_to_bus=a.line_to_bus, line_r_ohm_per_km=a.line_r_ohm_per_km,
+                line_x_ohm_per_km=a.line_x_ohm_per_km, line_c_nf_per_km=a.line_c_nf_per_km, line_g_us_per_km=a.line_g_us_per_km,
+                line_length_km=a.line_length_km, line_parallel=a.line_parallel, line_in_service=a.line_in_service,
+                load_bus=a.load_bus, sgen_bus=a.sgen_bus, sgen_zone=a.sgen_zone, ext_grid_bus=0, ext_grid_vm_pu=a.ext_grid_vm_pu,
+                sn_mva=a.sn_mva, f_hz=50.0, load_scaling=a.load_scaling, sgen_scaling=a.sgen_scaling,
+                br_from_bus=[0, star], br_to_bus=[star, 1], br_r_pu=[r / 2, r / 2], br_x_pu=[x / 2, x / 2], br_b_pu=[0, 0],
+                br_ratio=[a.br_ratio[0], 1.0], br_shift_deg=[0, 0],
+                shunt_bus=np.append(a.shunt_bus, star), shunt_p_mw=np.append(a.shunt_p_mw, ym.real * a.sn_mva),
+                shunt_q_mvar=np.append(a.shunt_q_mvar, -ym.imag * a.sn_mva))
+    pl, ql = pnet.load["p_mw"].to_numpy(), pnet.load["q_mvar"].to_numpy()
+    ps, qs = pnet.sgen["p_mw"].to_numpy(), pnet.sgen["q_mvar"].to_numpy()
+    ra, rb = runpp_restated(a, pl, ql, ps, qs), runpp_restated(b, pl, ql, ps, qs)
+    assert ra.converged and rb.converged
+    assert np.abs(ra.V - rb.V[:a.n_bus]).max() < 1e-9       # (each Newton solve stops at 1e-8 MVA mismatch)
+    # the slack supplies the same power either way (losses of the T circuit == losses of its pi equivalent)
+    assert abs(ra.p_mw[0] - rb.p_mw[0]) < 1e-7 and abs(ra.q_mvar[0] - rb.q_mvar[0]) < 1e-7      # (both solves stop at 1e-8 MVA)
+    if variant != "no_magnetising":
+        assert a.br_g_pu[0] > 0 and a.br_b_pu[0] < 0        # iron losses, inductive magnetising current
+
+
+def test_scaling_in_service_shunt_steps_and_switches():
+    pnet = substation_net()
+    a = from_pandapower(pnet)
+    assert np.array_equal(a.load_scaling, [1.0, 1.0, 0.9, 1.0, 0.0])          # scaling * in_service
+    assert np.array_equal(a.sgen_scaling, [1.0, 0.5])
+    assert a.shunt_q_mvar[0] == -0.5 and a.shunt_p_mw[0] == 0.0               # q_mvar * step
+    assert a.line_in_service.all()
+    pnet["switch"].loc[0, "closed"] = False                                     # an open line switch takes the line out
+    b = from_pandapower(pnet)
+    assert list(b.line_in_service) == [1, 1, 1, 0]
+    # scaled elements enter the power flow scaled: compare with hand-scaled inputs on an unscaled copy
+    pl, ql = pnet.load["p_mw"].to_numpy(), pnet.load["q_mvar"].to_numpy()
+    ps, qs = pnet.sgen["p_mw"].to_numpy(), pnet.sgen["q_mvar"].to_numpy()
+    plain = a.copy(); plain.load_scaling[:] = 1.0; plain.sgen_scaling[:] = 1.0
+    r1 = runpp_restated(a, pl, ql, ps, qs)
+    r2 = runpp_restated(plain, pl * a.load_scaling, ql * a.load_scaling, ps * a.sgen_scaling, qs * a.sgen_scaling)
+    assert np.abs(r1.V - r2.V).max() < 1e-14
+    assert abs(r1.p_mw[5] - (0.5 * 1.0 - 0.7 * 0.5)) < 1e-12                   # res_bus: scaled element powers
+
+
+def test_what_cannot_be_represented_is_refused():
+    for mutate, msg in [
+        (lambda n: n["load"].__setitem__("const_z_percent", 30.0), "const_z_percent"),
+        (lambda n: n["load"].__setitem__("const_i_percent", 10.0), "const_i_percent"),
+        (lambda n: n.__setitem__("switch", pd.DataFrame({"bus": [2], "element": [3], "et": ["b"], "type": ["CB"], "closed": [True]})), "bus-bus"),
+        (lambda n: n.__setitem__("gen", pd.DataFrame({"bus": [3], "p_mw": [1.0], "vm_pu": [1.0], "in_service": [True]})), "net.gen"),
+        (lambda n: n["trafo"].__setitem__("tap_step_degree", 2.0), "tap_step_degree"),
+        (lambda n: n["trafo"].__setitem__("tap_phase_shifter", True), "tap_phase_shifter"),
+        (lambda n: n["bus"].__setitem__("in_service", [True] * 5 + [False]), "out-of-service buses"),
+    ]:
+        pnet = substation_net()
+        mutate(pnet)
+        with pytest.raises(NotImplementedError, match=msg):
+            from_pandapower(pnet)
+
+
+def test_host_plan_accepts_the_converted_net_and_builds_the_same_ybus():
+    import ctypes as C
+    from mapdn_amd import _lib
+    a = from_pandapower(substation_net())
+    lib = _lib.load()
+    cnet, keep = _lib.make_cnetspec(a)
+    ccfg = _lib.make_cconfig(dict(episode_limit=240, action_scale=0.8, action_bias=0.0))
+    h = C.c_void_p()
+    assert lib.mapdn_create(C.byref(cnet), C.byref(ccfg), 4, -1, C.byref(h)) == 0, lib.mapdn_last_error(None)
+    out = np.zeros((a.n_bus, a.n_bus, 2))
+    assert lib.mapdn_get_ybus_dense(h, _lib._p(out, _lib._pd)) == 0
+    yo = make_ybus(a)[0].toarray()
+    assert np.abs(out[..., 0] + 1j * out[..., 1] - yo).max() <= 1e-12 * np.abs(yo).max()
+    lib.mapdn_destroy(h)
+
+
+@pytest.mark.gpu
+def test_env_on_the_converted_substation_net_matches_the_oracle_env():
+    """trafo pi branch with iron losses + scaled / out-of-service elements through the whole GPU step"""
+    import torch
+    from mapdn_amd.env import VoltageControlBatch
+    from mapdn_amd.netspec import Profiles
+    from oracle.env_restated import INFO_KEYS, VoltageControlOracle
+    net = from_pandapower(substation_net())
+    rng = np.random.default_rng(0)
+    T = 1500
+    prof = Profiles(pv=rng.uniform(0, 1.5, (T, 2)), load_p=rng.uniform(0.1, 1.2, (T, 5)), load_q=rng.uniform(0.0, 0.4, (T, 5)), time_delta_min=3)
+    a = dict(episode_limit=240, action_scale=0.8, action_bias=0.0, voltage_barrier_type="bowl", seed=2)
+    B = 6
+    env = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0", obs_dtype=torch.float64)
+    oracles = [VoltageControlOracle(net, prof, a, env_id=e, do_reset=False) for e in range(B)]
+    obs, state = env.reset()
+    for e, o in enumerate(oracles):
+        oo, os_ = o.reset()
+        assert np.abs(np.array(oo) - obs[e].cpu().numpy()).max() < 1e-9 and np.abs(os_ - state[e].cpu().numpy()).max() < 1e-7
+    for t in range(4):
+        act = rng.uniform(-0.8, 0.8, (B, net.n_sgen))
+        r, term, info = env.step(torch.as_tensor(act, device="cuda:0"))
+        res = env.results(); obs = env.get_obs()
+        for e, o in enumerate(oracles):
+            ro, to, io = o.step(act[e])
+            assert abs(ro - r[e].item()) < 1e-9 and to == bool(term[e].item())
+            assert max(abs(io[k] - info[e, c].item()) for c, k in enumerate(INFO_KEYS)) < 1e-9
+            assert np.abs(res["vm_pu"][e].cpu().numpy() - o.res.vm_pu).max() < 1e-9
+            assert np.abs(res["p_mw"][e].cpu().numpy() - o.res.p_mw).max() < 1e-9
+            assert np.abs(np.array(o.get_obs()) - obs[e].cpu().numpy()).max() < 1e-9
+    env.close()

@@ -375,8 +375,12 @@ def _featured_net():
               load_bus=n.load_bus, sgen_bus=n.sgen_bus, sgen_zone=n.sgen_zone,
               ext_grid_bus=0, ext_grid_vm_pu=1.02, sn_mva=5.0, f_hz=50.0,
               br_from_bus=[0], br_to_bus=[1], br_r_pu=[0.002], br_x_pu=[0.02], br_b_pu=[0.01], br_ratio=[0.98], br_shift_deg=[1.5],
+              br_g_pu=[0.004],                         # iron-loss conductance of the branch (BR_B = b - 1j*g)
               shunt_bus=[5, 17], shunt_p_mw=[0.01, 0.0], shunt_q_mvar=[-0.3, 0.15])
     x = NetSpec(**kw)
+    # element scaling / in_service (pd2ppc: PD = sum p * scaling): a load out of service, one scaled, a scaled sgen —
+    # runpp and res_sgen (q_loss) see the scaled values, obs / the q clip the raw table values
+    x.load_scaling[4] = 0.0; x.load_scaling[9] = 1.3; x.sgen_scaling[2] = 0.8
     # a doubled line (parallel = 2), an extra out-of-service tie line, and a line entered twice (two rows, same bus pair)
     x.line_parallel[3] = 2
     for k, v in (("line_from_bus", 20), ("line_to_bus", 7)):
@@ -432,6 +436,8 @@ def test_generic_network_features():
             assert np.abs(res["pl_mw"][e].cpu().numpy() - o.res.pl_mw).max() < 1e-9
             assert res["pl_mw"][e, 31].item() == 0.0                       # out-of-service row
             assert abs(io["total_line_loss"] - info[e, 8].item()) < 1e-9
+            assert abs(io["q_loss"] - info[e, 9].item()) < 1e-12
+            assert np.abs(np.array(o.get_obs()) - env.get_obs()[e].cpu().numpy()).max() < 1e-9
     env.close()
 
 

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 
 pp = pytest.importorskip("pandapower")
+if not hasattr(pp, "create_empty_network"):      # oracle/pp_stub on sys.path is not pandapower
+    pytest.skip("the pandapower on sys.path is the test stub", allow_module_level=True)
 
 from mapdn_amd.data import from_pandapower          # noqa: E402
 from mapdn_amd.netspec import make_case             # noqa: E402
@@ -55,3 +57,30 @@ def test_oracle_matches_real_pandapower(case):
         assert int(n._ppc["iterations"]) == r.iterations
         back = from_pandapower(n)                                # and the converter round-trips the topology
         assert np.array_equal(back.line_from_bus, net.line_from_bus) and np.array_equal(back.sgen_zone, net.sgen_zone)
+
+
+def test_transformer_net_matches_real_pandapower():
+    """from_pandapower's restated trafo -> pi conversion (T model, tap changer, iron losses) and the element scaling /
+    in_service handling against the real pd2ppc + runpp on a 110/20 kV substation feeder"""
+    n = pp.create_empty_network(sn_mva=10.0)
+    hv = pp.create_bus(n, vn_kv=110.0, zone="main")
+    b = [pp.create_bus(n, vn_kv=20.0, zone=z) for z in ("main", "zone1", "zone1", "zone2", "zone2")]
+    pp.create_transformer_from_parameters(n, hv, b[0], sn_mva=25.0, vn_hv_kv=110.0, vn_lv_kv=20.0, vk_percent=12.0, vkr_percent=0.41,
+                                          pfe_kw=14.0, i0_percent=0.07, shift_degree=150.0, tap_side="hv", tap_neutral=0, tap_min=-9,
+                                          tap_max=9, tap_step_percent=1.5, tap_pos=-2)
+    for f, t, l, r, x, c in ((0, 1, 2.0, 0.2, 0.12, 250.0), (1, 2, 1.5, 0.3, 0.1, 200.0), (0, 3, 3.0, 0.25, 0.11, 240.0), (3, 4, 1.0, 0.4, 0.1, 210.0)):
+        pp.create_line_from_parameters(n, b[f], b[t], length_km=l, r_ohm_per_km=r, x_ohm_per_km=x, c_nf_per_km=c, max_i_ka=0.4)
+    for bus, p, q, sc, on in ((1, 1.0, 0.3, 1.0, True), (2, 0.8, 0.2, 1.0, True), (3, 1.2, 0.4, 0.9, True), (4, 0.5, 0.1, 1.0, True), (4, 0.3, 0.1, 1.0, False)):
+        pp.create_load(n, b[bus], p_mw=p, q_mvar=q, scaling=sc, in_service=on)
+    pp.create_sgen(n, b[2], p_mw=1.5, q_mvar=0.2, name="zone1")
+    pp.create_sgen(n, b[4], p_mw=0.7, q_mvar=-0.1, name="zone2", scaling=0.5)
+    pp.create_shunt(n, b[3], q_mvar=-0.25, p_mw=0.0, step=2, max_step=3)
+    pp.create_ext_grid(n, hv, vm_pu=1.02)
+    pp.runpp(n)
+    net = from_pandapower(n)
+    r = runpp_restated(net, n.load.p_mw.to_numpy(), n.load.q_mvar.to_numpy(), n.sgen.p_mw.to_numpy(), n.sgen.q_mvar.to_numpy())
+    rb = n.res_bus.sort_index()
+    assert np.abs(rb.vm_pu.to_numpy() - r.vm_pu).max() < 1e-9
+    assert np.abs(rb.p_mw.to_numpy() - r.p_mw).max() < 1e-8 and np.abs(rb.q_mvar.to_numpy() - r.q_mvar).max() < 1e-8
+    assert np.abs(n.res_line.sort_index().pl_mw.to_numpy() - r.pl_mw).max() < 1e-8
+    assert int(n._ppc["iterations"]) == r.iterations
