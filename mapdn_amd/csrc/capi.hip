@@ -295,7 +295,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   UP(flat, h->sched.flat); d.flat_bytes = (uint32_t)(h->sched.flat.size() * sizeof(double));
   {  // NR scratch: factor blocks (one per (worker,row) step) | Sbus (schedule order) | Vout
     const size_t nblk = (size_t)Wt * h->sched.R;
-    const size_t fb_rows = (h_lds && g_lds) ? 0 : nblk * NBP;                 // pair rows of Bp x 16 bytes
+    const size_t fb_rows = (h_lds && g_lds) ? 0 : (size_t)(P.n + 2) * NBP;   // pair rows of Bp x 16 bytes: one block per node (+ slack, trash)
     std::vector<int32_t> sbi(h->sched.step_of_node.begin(), h->sched.step_of_node.begin() + P.n);
     rc = alloc_nrbuf(fb_rows, nblk, sbi); if (rc) return rc;
   }

@@ -269,7 +269,11 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   const unsigned bb = (unsigned)NBP * pb;        // bytes per factor block
   const unsigned voT = t * (unsigned)R * TB;     // this worker's records (same address for its L lanes)
   const unsigned voF = t * (unsigned)R * FB;     // this worker's flat-start steps
-  const unsigned voB = e * 16u + t * (unsigned)R * bb;                 // factor blocks: + field * pb, scalar row offset
+  // factor blocks are addressed by NODE (block k of env e at e*16 + k*bb, field offset on the scalar side): the idle steps of
+  // all workers share the trash node's block, so a sweep moves n blocks per env, not workers x rows
+  const unsigned voE = e * 16u;
+  const unsigned sF_H = __builtin_amdgcn_readfirstlane(NB_H * pb), sF_G01 = __builtin_amdgcn_readfirstlane(NB_G01 * pb),
+                 sF_G23 = __builtin_amdgcn_readfirstlane(NB_G23 * pb);
   const unsigned voS = d.sb_off + e * 16u + t * (unsigned)R * pb;      // scheduled injection, in schedule order: scalar row offset
   // LDS map, in pair rows (L x 16 bytes: one d2 per env; a worker's 16 lanes read 256 contiguous bytes with one
   // conflict-free ds_read_b128):  V [n+2] | h [n+2] if HL | G [2(n+2)] if GL | contribution slots x 4 | x slots x 1
@@ -527,10 +531,10 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
             c[0] = d2{apk_r, apk_i}; c[L] = d2{s0, s1}; c[2 * L] = d2{s2, s3}; c[3 * L] = d2{t0, t1};
           }
           SCHED_FENCE();                           // the factors leave after the contribution is on its way
-          const unsigned k = kp & 0xffffu, sbF = row_s(r, bb);
-          if (HL) sH[(size_t)k * L] = d2{h0, h1}; else bst2(d2{h0, h1}, rs, voB + NB_H * pb, sbF);
+          const unsigned k = kp & 0xffffu, voN = voE + k * bb;
+          if (HL) sH[(size_t)k * L] = d2{h0, h1}; else bst2(d2{h0, h1}, rs, voN, sF_H);
           if (GL) { sG[(size_t)(2 * k) * L] = d2{G0, G1}; sG[(size_t)(2 * k + 1) * L] = d2{G2, G3}; }
-          else { bst2(d2{G0, G1}, rs, voB + NB_G01 * pb, sbF); bst2(d2{G2, G3}, rs, voB + NB_G23 * pb, sbF); }
+          else { bst2(d2{G0, G1}, rs, voN, sF_G01); bst2(d2{G2, G3}, rs, voN, sF_G23); }
         } else {
           cS0 = apk_r; cS1 = apk_i;
           if (flu & SU_W_ANY) cs[(size_t)(slots & 1023u) * (4 * L)] = d2{apk_r, apk_i};
@@ -588,7 +592,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         if (flu & SU_W_ANY) cs[((size_t)(slots & 1023u) * 4 + 3) * L] = d2{t0, t1};
         SCHED_FENCE();
         const unsigned k = kp & 0xffffu;
-        if (HL) sH[(size_t)k * L] = d2{h0, h1}; else bst2(d2{h0, h1}, rs, voB + NB_H * pb, row_s(r, bb));
+        if (HL) sH[(size_t)k * L] = d2{h0, h1}; else bst2(d2{h0, h1}, rs, voE + k * bb, sF_H);
         if (W > 1) lds_barrier();
         STAMP(102);
         ++r;
@@ -620,26 +624,29 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     constexpr int SRC = decltype(src)::value;
     constexpr bool gG = (SRC == 0) || !GL;         // G comes from global memory (flat table or factor block)
     constexpr bool gH = !HL;
-    u32x4 ixq[3]; BwdF fq[3];
-    auto load_b = [&](int row, u32x4& ix, BwdF& f) {
-      ix = load_ix(row);
-      if (gH) f.h = bld2(rs, voB + NB_H * pb, row_s(row, bb));
+    // rings of 4 (static indices): the record of a row is read THREE rows ahead, so that its node number is there when the
+    // factor loads of that row are issued TWO rows ahead (factor blocks are addressed by node)
+    u32x4 ixq[4]; BwdF fq[4];
+    auto load_f = [&](int row, const u32x4& ix, BwdF& f) {
+      const unsigned voN = voE + (ix.w & 0xffffu) * bb;
+      if (gH) f.h = bld2(rs, voN, sF_H);
       if (gG) {
         if (SRC == 0) {
           if (flatL) { const char* p = flatT + (unsigned)row * FB; f.g01 = *(const d2*)(p + FL_G0 * 8); f.g23 = *(const d2*)(p + FL_G2 * 8); }
           else { const unsigned sf = row_s(row, FB); f.g01 = bld2(rsF, voF + FL_G0 * 8u, sf); f.g23 = bld2(rsF, voF + FL_G2 * 8u, sf); }
         }
-        else { const unsigned sb = row_s(row, bb); f.g01 = bld2(rs, voB + NB_G01 * pb, sb); f.g23 = bld2(rs, voB + NB_G23 * pb, sb); }
+        else { f.g01 = bld2(rs, voN, sF_G01); f.g23 = bld2(rs, voN, sF_G23); }
       }
     };
-    load_b(R - 1, ixq[0], fq[0]); load_b(max(R - 2, 0), ixq[1], fq[1]);
+    ixq[0] = load_ix(R - 1); ixq[1] = load_ix(max(R - 2, 0)); ixq[2] = load_ix(max(R - 3, 0));
+    load_f(R - 1, ixq[0], fq[0]); load_f(max(R - 2, 0), ixq[1], fq[1]);
     double py0 = 0.0, py1 = 0.0; d2 pvk = sV[(size_t)(n + 1) * L]; unsigned pk = n + 1; bool pLive = false;   // deferred update of the previous row
     int r = R - 1;
     while (r >= 0) {
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
+      for (int u = 0; u < 4; ++u) {
         if (r < 0) break;
-        const u32x4 ix = ixq[u % 3];
+        const u32x4 ix = ixq[u % 4];
         const uint32_t fl = ix.x, slots = ix.y;
         const uint32_t flu = uni(fl);
         const unsigned k = ix.w & 0xffffu;
@@ -647,15 +654,12 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         d2 q;
         const bool xr = (flu & SU_XR_ANY) != 0;
         if (xr) q = xs[(size_t)((slots >> 20) & 1023u) * L];
-        const d2 hh = gH ? fq[u % 3].h : sH[(size_t)k * L];
-        const d2 g01 = gG ? fq[u % 3].g01 : sG[(size_t)(2 * k) * L];
-        const d2 g23 = gG ? fq[u % 3].g23 : sG[(size_t)(2 * k + 1) * L];
+        const d2 hh = gH ? fq[u % 4].h : sH[(size_t)k * L];
+        const d2 g01 = gG ? fq[u % 4].g01 : sG[(size_t)(2 * k) * L];
+        const d2 g23 = gG ? fq[u % 4].g23 : sG[(size_t)(2 * k + 1) * L];
         const d2 vk = sV[(size_t)k * L];           // (only this node's own deferred update ever writes it)
-#if (MAPDN_EXP & 8)
-        ixq[(u + 2) % 3] = ixq[u % 3]; fq[(u + 2) % 3] = fq[u % 3];
-#else
-        load_b(max(r - 2, 0), ixq[(u + 2) % 3], fq[(u + 2) % 3]);
-#endif
+        ixq[(u + 3) % 4] = load_ix(max(r - 3, 0));
+        load_f(max(r - 2, 0), ixq[(u + 2) % 4], fq[(u + 2) % 4]);
         SCHED_FENCE();
         // (2) shadow: the previous row's voltage update
         apply_update(py0, py1, pvk, pk, pLive);

@@ -11,9 +11,10 @@ enum { MODE_STEP = 0, MODE_RESET = 1, MODE_SOLVE = 2 };
 enum { STREAM_PV = 0, STREAM_LOAD_P = 1, STREAM_LOAD_Q = 2, STREAM_ACTION = 3, STREAM_START = 4 };
 
 // NR global scratch `nrbuf` (env-minor), three regions:
-//   factor blocks  [nblk][NBP] pair rows (Bp x 16 bytes)  one block per (worker,row) step: the LU factors (G0,G1)
-//                                (G2,G3) (h0,h1) written in the forward sweep and read back in the backward sweep by the
-//                                same worker — only for the factors that do not fit in LDS (nr_h_lds / nr_g_lds)
+//   factor blocks  [n+2][NBP] pair rows (Bp x 16 bytes)  one block per NODE (position; n+1 = the trash node every idle
+//                                step works on): the LU factors (G0,G1) (G2,G3) (h0,h1) written in the forward sweep and
+//                                read back in the backward sweep — only for the factors that do not fit in LDS
+//                                (nr_h_lds / nr_g_lds)
 //   Sbus           [nblk] pair rows   (Re, Im) of the scheduled injection, stored in SCHEDULE order (k_inject writes
 //                                entry sb_index[k]; the NR workers prefetch theirs by (worker,row)); idle steps stay 0
 //   Vout           [n+1][4] rows of Bp doubles   per position (n == slack): e f |V| angle — the solution (k_nr_tree)
