@@ -969,7 +969,7 @@ void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const
 constexpr int nr_res(int w, int l, bool h_lds) {
   return h_lds ? (((w == 1 && l == 16) || (w == 4 && l == 16) || (w == 4 && l == 8)) ? 1 : 0) : ((w == 2 && l == 16) ? 2 : 0);
 }
-// (W, L) instantiations of k_nr_wtree
+// (W, L) instantiations of k_nr_tree
 #define NR_FOR_EACH(X) X(1, 8) X(1, 16) X(1, 32) X(2, 8) X(2, 16) X(2, 32) X(4, 8) X(4, 16) X(4, 32) X(8, 16)
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
   if (d.dense) { launch_nr_dense(d, mode, reward, term, info, st); return; }
@@ -1002,7 +1002,7 @@ void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, 
   hipLaunchKernelGGL(k_reset_begin, dim3((d.B + 255) / 256), dim3(256), 0, st, d, start_rows, first_try);
 }
 // do_profiles: next profile row + noise for the envs queued in adv_row; do_commit: res_bus commit of
-// the envs flagged by the preceding k_nr_wtree launch
+// the envs flagged by the preceding k_nr_tree launch
 void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, hipStream_t st) {
   const int pairs = do_profiles ? ((d.ns + 1) >> 1) + 2 * ((d.nl + 1) >> 1) : 0;
   const int rows = pairs + (do_commit ? d.nb : 0);

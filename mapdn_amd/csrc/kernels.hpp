@@ -58,12 +58,12 @@ struct Dev {
   double* nrbuf; uint32_t nrbuf_bytes; uint32_t sb_off, r_vout;   // sb_off: byte offset of the Sbus region
   const int32_t* sb_index;                                           // [n] Sbus entry (schedule step) of elimination position k
   int32_t* iters; uint8_t* conv;
-  // ---- NR schedule (k_nr_wtree): W waves per workgroup, L envs per workgroup (64/L lane-group workers per wave), R rows
+  // ---- NR schedule (k_nr_tree): W waves per workgroup, L envs per workgroup (64/L lane-group workers per wave), R rows
   int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots, nr_nclist, nr_h_lds, nr_g_lds, nr_line_lds, nr_rec_lds, nr_flat_lds;
   const StepRec* sched; uint32_t sched_bytes; const int32_t* clist;
   const double* flat; uint32_t flat_bytes;   // Schedule::flat, [Wt][R][FLAT_N]
   // a Newton step whose largest component (|dtheta|, |d|V|/|V||) is below this predicts convergence: the next
-  // forward sweep is first run in its mismatch-only form (k_nr_wtree)
+  // forward sweep is first run in its mismatch-only form (k_nr_tree)
   double nr_check_dx;
   double nr_check_quad;      // safety factor of the quadratic-convergence predictor (inf disables it, tiny = always predict)
   // ---- general-topology solve (k_nr_dense, dense.hip): Ybus rows by position in CSR form (columns are positions,

@@ -424,7 +424,7 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw) {
       for (int w = w0; w < w0 + Sw; ++w) S.steps[(size_t)w * R + r].flags |= (gmax << SU_GMAX_SHIFT) | any;
     }
   if (S.clist.empty()) S.clist.push_back(0);
-  // ---- flat-start factorisation (same formulas as k_nr_wtree's forward step with V == vroot everywhere)
+  // ---- flat-start factorisation (same formulas as k_nr_tree's forward step with V == vroot everywhere)
   {
     const double v = P.vroot, v2 = v * v;
     std::vector<double> aS((size_t)n * 2, 0.0), aD((size_t)n * 4, 0.0), node((size_t)n * FLAT_N, 0.0);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Summarise the SQ counter passes of `rocprofv3 -i tools/pmc_sq.txt --output-format csv -- python bench.py`
-(one *_counter_collection.csv per pass) for the k_nr_wtree dispatches into the table kept under profiles/.
+(one *_counter_collection.csv per pass) for the k_nr_tree dispatches into the table kept under profiles/.
 
 usage: pmc_sq_summary.py <out.txt> <pass1.csv> [<pass2.csv> ...]"""
 import collections

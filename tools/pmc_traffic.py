@@ -23,7 +23,7 @@ def mean_counter(d, name, sub):
 
 if __name__ == "__main__":
     fdir, wdir, out = sys.argv[1:4]
-    sub = sys.argv[4] if len(sys.argv) > 4 else "k_nr_wtree"
+    sub = sys.argv[4] if len(sys.argv) > 4 else "k_nr_tree"
     f, nf = mean_counter(fdir, "FETCH_SIZE", sub)
     w, nw = mean_counter(wdir, "WRITE_SIZE", sub)
     res = {"kernel": sub, "fetch_bytes_per_launch": f * 1024, "write_bytes_per_launch": w * 1024,
