@@ -225,6 +225,15 @@ int mapdn_get_schedule(const mapdn_handle* h, int32_t n_waves, int32_t* n_rows, 
  * bus_of_pos [n+1] (optional) = bus id of every elimination position (position n is the slack). */
 int mapdn_get_flat_factors(const mapdn_handle* h, double* factors, int32_t* bus_of_pos);
 
+/* Host-side export of the general sparse solver's elimination PROGRAM for S sub-lanes (plan check, CPU tests): dims [6] =
+ * block slots, fill-only blocks, phases, assembly rows per sub-lane, max row entries, number of off-diagonal blocks;
+ * ops [phases * S * 4] = (type, c, a, b) with type 0 NOP, 1 B[c] = inv(B[a]), 2 B[c] = B[a] B[b], 3 B[c] -= B[a] B[b]
+ * (block slots: diagonal of node i = i, right-hand side of node i = n + i as the block [b | 0]); order [n] = minimum-degree
+ * elimination order (positions); slots_ij [3 * dims[5]] = (i, j, slot) of every off-diagonal block incl. fill.  Executing the
+ * ops in phase order on the assembled blocks solves J x = b — tests/test_general_topology.py does it in numpy against
+ * scipy's spsolve (what pandapower calls in pypower/newtonpf.py).  Any pointer but dims may be NULL. */
+int mapdn_get_sparse_program(const mapdn_handle* h, int32_t sub_lanes, int32_t* dims, int32_t* ops, int32_t* order, int32_t* slots_ij);
+
 /* Debug / pin export of the general solver's linear algebra: solves `batch` independent dense systems A x = b
  * (device pointers; A row-major [batch, n, n], b and x [batch, n]; n even, <= 128) with the LDS-resident blocked LU
  * (2x2 block pivots, v_mfma_f64_16x16x4_f64 trailing updates) that k_nr_dense runs on the Jacobian — what pandapower

@@ -16,6 +16,9 @@ using namespace mapdn;
 struct mapdn_handle {
   Plan plan;
   Schedule sched;
+  SparseProg sprog;
+  int solver = 0;                 // 0 tree (radial), 1 general sparse (k_nr_sparse), 2 general dense (k_nr_dense)
+  int sp_lanes = 0;
   mapdn_env_config cfg;
   Dev d;
   int device = 0;
@@ -99,10 +102,30 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   if (cfg->episode_limit < 2) { h->err = "episode_limit must be >= 2"; return MAPDN_E_INVALID; }
   int rc = build_plan(*net, *cfg, h->plan, h->err);
   if (rc) return rc;
-  if (!h->plan.radial && 2 * h->plan.n > 128) {   // general-topology solver: dense Jacobian of one env in LDS (dense.hip)
-    h->err = "topology: meshed network with " + std::to_string(h->plan.nb) + " buses; the general-topology solver keeps the dense "
-             "Jacobian of one env in LDS and handles at most 65 buses (radial feeders of any size take the tree solver)";
-    return MAPDN_E_TOPOLOGY; }
+  {
+    // Solver choice.  pp.runpp (voltage_control_env.py:557) solves any connected net: radial feeders take the fill-free
+    // tree kernel; meshed nets the general sparse kernel (host symbolic factorisation with fill + a block program, all
+    // blocks of L envs in LDS); MAPDN_NR_DENSE=1 selects the dense LDS-resident LU with f64 MFMA (<= 65 buses),
+    // MAPDN_NR_SPARSE=1 the sparse kernel on a radial net (cross-checks).
+    const Plan& P0 = h->plan;
+    const char* fs = getenv("MAPDN_NR_SPARSE"); const char* fd = getenv("MAPDN_NR_DENSE");
+    const bool want_dense = fd && atoi(fd);
+    const bool want_sparse = !want_dense && ((fs && atoi(fs)) || !P0.radial);
+    if (want_dense) {
+      if (2 * P0.n > 128) { h->err = "MAPDN_NR_DENSE: the dense general-topology solver handles at most 65 buses"; return MAPDN_E_TOPOLOGY; }
+      h->solver = 2;
+    } else if (want_sparse) {
+      SparseProg g0;
+      sparse_symbolic(P0, g0);
+      int Lc = 0;
+      for (int l : {16, 8, 4, 2}) if (nr_sparse_lds_bytes(P0.n, g0.n_blocks, l) <= 160 * 1024) { Lc = l; break; }
+      if (!Lc) {
+        h->err = "topology: meshed network with " + std::to_string(P0.nb) + " buses needs " + std::to_string(g0.n_blocks) +
+                 " Jacobian blocks after fill; two envs of it do not fit the 160 KB LDS of a CU";
+        return MAPDN_E_TOPOLOGY; }
+      h->solver = 1; h->sp_lanes = Lc;
+    }
+  }
   h->cfg = *cfg;
   h->device = device;
   std::memset(&h->d, 0, sizeof(h->d));
@@ -218,22 +241,36 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     rc = dupload(h, &tmp, varow); if (rc) return rc; h->va_row = (int32_t*)tmp;
     return MAPDN_OK;
   };
-  // ---- general-topology path: a meshed net (or MAPDN_NR_DENSE=1 on a radial one, for cross-checks) is solved by
-  // k_nr_dense (dense.hip): one env per workgroup, dense Jacobian in LDS, blocked LU with f64 MFMA trailing updates
-  {
-    const char* s = getenv("MAPDN_NR_DENSE");
-    if (!P.radial || (s && atoi(s))) {
-      d.dense = 1; d.dn_N = (2 * P.n + 15) / 16 * 16; d.dn_lda = d.dn_N + 2;
-      if (d.dn_N > 128 || nr_dense_lds_bytes(d) > 160 * 1024) {
-        h->err = "MAPDN_NR_DENSE: the general-topology solver handles at most 65 buses"; return MAPDN_E_TOPOLOGY; }
-      UP(gy_ptr, P.gy_ptr); UP(gy_col, P.gy_col); UP(gy_val, P.gy_val);
-      std::vector<int32_t> sbi(P.n);
-      for (int k = 0; k < P.n; ++k) sbi[k] = k;
-      rc = alloc_nrbuf(0, (size_t)P.n, sbi); if (rc) return rc;
-      if (nr_dense_prepare(d) != 0) { (void)hipGetLastError(); h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_nr_dense"; return MAPDN_E_HIP; }
-      h->lds_bytes = nr_dense_lds_bytes(d);
-      return MAPDN_OK;
+  // ---- general-topology paths (see the solver choice above)
+  if (h->solver == 2) {                           // k_nr_dense (dense.hip): one env per workgroup, dense Jacobian in LDS, f64 MFMA
+    d.dense = 1; d.dn_N = (2 * P.n + 15) / 16 * 16; d.dn_lda = d.dn_N + 2;
+    UP(gy_ptr, P.gy_ptr); UP(gy_col, P.gy_col); UP(gy_val, P.gy_val);
+    std::vector<int32_t> sbi(P.n);
+    for (int k = 0; k < P.n; ++k) sbi[k] = k;
+    rc = alloc_nrbuf(0, (size_t)P.n, sbi); if (rc) return rc;
+    if (nr_dense_prepare(d) != 0) { (void)hipGetLastError(); h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_nr_dense"; return MAPDN_E_HIP; }
+    h->lds_bytes = nr_dense_lds_bytes(d);
+    return MAPDN_OK;
+  }
+  if (h->solver == 1) {                           // k_nr_sparse (sparse.hip): host-compiled block elimination program
+    if (const char* s_ = getenv("MAPDN_SP_LANES")) {   // experiments: envs per workgroup (16 / 8 / 4 / 2)
+      const int l = atoi(s_);
+      if ((l == 16 || l == 8 || l == 4 || l == 2) && nr_sparse_lds_bytes(P.n, 0, l) <= 160 * 1024) h->sp_lanes = l;
     }
+    sparse_program(P, 64 / h->sp_lanes, h->sprog);
+    const SparseProg& G = h->sprog;
+    if (nr_sparse_lds_bytes(P.n, G.n_blocks, h->sp_lanes) > 160 * 1024) { h->err = "MAPDN_SP_LANES: does not fit in LDS"; return MAPDN_E_INVALID; }
+    d.sparse = 1; d.sp_lanes = h->sp_lanes; d.sp_blocks = G.n_blocks; d.sp_fill = (int32_t)G.fill_slots.size();
+    d.sp_phases = G.n_phases; d.sp_rows_per_sub = G.rows_per_sub; d.sp_max_nnz = G.max_nnz;
+    UP(sp_ops, G.ops); d.sp_ops_bytes = (uint32_t)(G.ops.size() * sizeof(SpOp));
+    UP(sp_nz, G.nz); d.sp_nz_bytes = (uint32_t)(G.nz.size() * sizeof(SpNz));
+    { std::vector<int32_t> fs(G.fill_slots); if (fs.empty()) fs.push_back(G.n_blocks - 1); UP(sp_fill_slots, fs); }
+    std::vector<int32_t> sbi(P.n);
+    for (int k = 0; k < P.n; ++k) sbi[k] = k;
+    rc = alloc_nrbuf(0, (size_t)P.n, sbi); if (rc) return rc;
+    if (nr_sparse_prepare(h->sp_lanes) != 0) { (void)hipGetLastError(); h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_nr_sparse"; return MAPDN_E_HIP; }
+    h->lds_bytes = nr_sparse_lds_bytes(P.n, G.n_blocks, h->sp_lanes);
+    return MAPDN_OK;
   }
   // ---- NR launch geometry: a workgroup = W waves serving L envs; each wave carries 64/L lane-group
   // workers, so Wt = W*64/L workers eliminate independent subtrees of every env concurrently.
@@ -597,6 +634,18 @@ int mapdn_get_schedule(const mapdn_handle* h, int32_t W, int32_t* n_rows, int32_
   *n_rows = S.R;
   if (rows) for (size_t i = 0; i < S.steps.size(); ++i) rows[i] = (S.steps[i].flags & S_LIVE) ? (int32_t)(S.steps[i].kp & 0xffffu) : -1;
   if (parent) std::memcpy(parent, h->plan.par.data(), h->plan.par.size() * sizeof(int32_t));
+  return MAPDN_OK;
+}
+
+int mapdn_get_sparse_program(const mapdn_handle* h, int32_t S, int32_t* dims, int32_t* ops, int32_t* order, int32_t* slots_ij) {
+  if (!h || !dims || S < 1 || S > 64) return MAPDN_E_INVALID;
+  SparseProg G;
+  sparse_program(h->plan, S, G);
+  dims[0] = G.n_blocks; dims[1] = G.n_fill; dims[2] = G.n_phases; dims[3] = G.rows_per_sub; dims[4] = G.max_nnz;
+  dims[5] = (int32_t)(G.slots_ij.size() / 3);
+  if (ops) std::memcpy(ops, G.ops.data(), G.ops.size() * sizeof(SpOp));
+  if (order) std::memcpy(order, G.order.data(), G.order.size() * sizeof(int32_t));
+  if (slots_ij) std::memcpy(slots_ij, G.slots_ij.data(), G.slots_ij.size() * sizeof(int32_t));
   return MAPDN_OK;
 }
 

@@ -973,6 +973,7 @@ constexpr int nr_res(int w, int l, bool h_lds) {
 #define NR_FOR_EACH(X) X(1, 8) X(1, 16) X(1, 32) X(2, 8) X(2, 16) X(2, 32) X(4, 8) X(4, 16) X(4, 32) X(8, 16)
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
   if (d.dense) { launch_nr_dense(d, mode, reward, term, info, st); return; }
+  if (d.sparse) { launch_nr_sparse(d, mode, reward, term, info, st); return; }
   const dim3 grid(d.Bp / d.nr_lanes);
   const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.n, d.nr_cslots, d.nr_xslots, d.nr_nclist, d.nr_h_lds, d.nr_g_lds,
                                   d.nr_line_lds ? d.n_line : 0, d.nr_rec_lds ? d.nr_rows : 0, d.nr_flat_lds ? d.nr_rows : 0);

@@ -68,6 +68,9 @@ struct Dev {
   double nr_check_quad;      // safety factor of the quadratic-convergence predictor (inf disables it, tiny = always predict)
   // ---- general-topology solve (k_nr_dense, dense.hip): Ybus rows by position in CSR form (columns are positions,
   // n == slack; values (re, im)); the dense Jacobian is N x N (2n rounded up to 16) with row stride dn_lda in LDS
+  // ---- general sparse path (k_nr_sparse, sparse.hip): host-compiled elimination program (plan.hpp SparseProg)
+  int32_t sparse, sp_lanes, sp_blocks, sp_fill, sp_phases, sp_rows_per_sub, sp_max_nnz;
+  const SpOp* sp_ops; uint32_t sp_ops_bytes; const SpNz* sp_nz; uint32_t sp_nz_bytes; const int32_t* sp_fill_slots;
   int32_t dense, dn_N, dn_lda;
   const int32_t *gy_ptr, *gy_col; const double* gy_val;
 };
@@ -91,6 +94,10 @@ static inline size_t nr_lds_bytes(int W, int L, int n, int cslots, int xslots, i
   return rows * (size_t)L * 16 + (size_t)W * 64 + (size_t)64 * W * sizeof(double) + (size_t)((nclist + 3) & ~3) * sizeof(int32_t) +
          nr_line_bytes(n_line_lds) + Wt * rec_rows * sizeof(StepRec) + Wt * flat_rows * FLAT_N * sizeof(double);
 }
+// general sparse kernel (sparse.hip): L envs per one-wave workgroup; prepare returns -2 for an L that is not instantiated
+size_t nr_sparse_lds_bytes(int n, int n_blocks, int L);
+int nr_sparse_prepare(int L);
+void launch_nr_sparse(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
 // general-topology kernel (dense.hip): nr_dense_prepare returns -2 when the net is too large for the LDS-resident Jacobian
 size_t nr_dense_lds_bytes(const Dev& d);
 int nr_dense_prepare(const Dev& d);

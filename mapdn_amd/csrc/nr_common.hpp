@@ -224,7 +224,7 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
     return;
   }
   double tot[10];
-  constexpr unsigned UNR = Wt <= 32 ? Wt : 8;     // (the one-env-per-workgroup kernel has 64 or 128 workers)
+  constexpr unsigned UNR = Wt <= 16 ? Wt : 8;     // (the general solvers have up to 128 workers)
 #pragma unroll
   for (int q = 0; q < 10; ++q) {
     double a = sm[(size_t)(q * Wt) * L];

@@ -273,6 +273,121 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   return MAPDN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// general sparse path: symbolic factorisation + program (see plan.hpp)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Symbolic {
+  std::vector<int> order;                       // elimination order
+  std::vector<std::vector<int>> nbr;            // nbr[k]: neighbours of pivot k at its elimination (ascending)
+  std::map<std::pair<int, int>, int> slot;      // off-diagonal block (i, j) -> slot
+  std::vector<int> fill;                        // slots that are fill only
+  int n_blocks = 0;
+};
+Symbolic symbolic(const Plan& P) {
+  const int n = P.n;
+  Symbolic Y;
+  std::vector<std::vector<char>> adj(n, std::vector<char>(n, 0));
+  int next = 2 * n;
+  for (int i = 0; i < n; ++i)
+    for (int q = P.gy_ptr[i]; q < P.gy_ptr[i + 1]; ++q) {
+      const int j = P.gy_col[q];
+      if (j < n && j != i) { adj[i][j] = 1; if (!Y.slot.count({i, j})) Y.slot[{i, j}] = next++; }
+    }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) if (adj[i][j] && !adj[j][i]) { adj[j][i] = 1; if (!Y.slot.count({j, i})) { Y.slot[{j, i}] = next; Y.fill.push_back(next++); } }
+  std::vector<char> gone(n, 0);
+  Y.nbr.assign(n, {});
+  for (int step = 0; step < n; ++step) {        // minimum degree, ties to the smallest position
+    int best = -1, bd = 1 << 30;
+    for (int k = 0; k < n; ++k) if (!gone[k]) {
+      int dg = 0;
+      for (int j = 0; j < n; ++j) dg += (!gone[j] && adj[k][j]);
+      if (dg < bd) { bd = dg; best = k; }
+    }
+    const int k = best;
+    gone[k] = 1; Y.order.push_back(k);
+    for (int j = 0; j < n; ++j) if (!gone[j] && adj[k][j]) Y.nbr[k].push_back(j);
+    for (int i : Y.nbr[k]) for (int j : Y.nbr[k]) if (i != j && !adj[i][j]) {      // fill
+      adj[i][j] = 1;
+      Y.slot[{i, j}] = next; Y.fill.push_back(next++);
+    }
+  }
+  Y.n_blocks = next + 1;                        // + one scratch slot (NOPs, padding)
+  return Y;
+}
+}  // namespace
+
+void sparse_symbolic(const Plan& P, SparseProg& G) {
+  const Symbolic Y = symbolic(P);
+  G.n_blocks = Y.n_blocks; G.n_fill = (int32_t)Y.fill.size();
+  G.order.assign(Y.order.begin(), Y.order.end());
+}
+
+void sparse_program(const Plan& P, int S, SparseProg& G) {
+  const int n = P.n;
+  const Symbolic Y = symbolic(P);
+  G = SparseProg{};
+  G.S = S; G.n_blocks = Y.n_blocks; G.n_fill = (int32_t)Y.fill.size();
+  G.order.assign(Y.order.begin(), Y.order.end());
+  const uint32_t scratch = (uint32_t)(Y.n_blocks - 1);
+  G.fill_slots.assign(Y.fill.begin(), Y.fill.end());
+  while (G.fill_slots.size() % S) G.fill_slots.push_back((int32_t)scratch);
+  // ---- assembly rows: node i -> sub-lane i % S
+  G.rows_per_sub = (n + S - 1) / S;
+  G.max_nnz = 1;
+  for (int i = 0; i < n; ++i) G.max_nnz = std::max<int32_t>(G.max_nnz, P.gy_ptr[i + 1] - P.gy_ptr[i]);
+  G.rows.assign((size_t)S * G.rows_per_sub, SpRow{(uint32_t)(n + 1), 0u, 0u, 0u});
+  G.nz.assign((size_t)S * G.rows_per_sub * G.max_nnz, SpNz{(uint32_t)(n + 1), -1, {0.0, 0.0}, {0u, 0u}});
+  for (int i = 0; i < n; ++i) {
+    const size_t r = (size_t)(i % S) * G.rows_per_sub + i / S;
+    G.rows[r] = SpRow{(uint32_t)i, (uint32_t)(P.gy_ptr[i + 1] - P.gy_ptr[i]), (uint32_t)i, 1u};
+    for (int q = P.gy_ptr[i]; q < P.gy_ptr[i + 1]; ++q) {
+      const int j = P.gy_col[q];
+      SpNz& z = G.nz[r * G.max_nnz + (q - P.gy_ptr[i])];
+      z.col = (uint32_t)j; z.y[0] = P.gy_val[2 * q]; z.y[1] = P.gy_val[2 * q + 1];
+      z.slot = (j < n && j != i) ? Y.slot.at({i, j}) : -1;
+    }
+  }
+  // ---- operations in elimination order, then list scheduling into phases of <= S independent ops
+  std::vector<SpOp> seq;
+  auto off = [&](int i, int j) { return (uint32_t)Y.slot.at({i, j}); };
+  auto diag = [&](int i) { return (uint32_t)i; };
+  auto rhs = [&](int i) { return (uint32_t)(n + i); };
+  for (int k : Y.order) {
+    seq.push_back(SpOp{1u, diag(k), diag(k), diag(k)});                                   // D_k^-1 in place
+    for (int i : Y.nbr[k]) seq.push_back(SpOp{2u, off(i, k), off(i, k), diag(k)});        // L_ik = A_ik D_k^-1
+    for (int i : Y.nbr[k]) {
+      for (int j : Y.nbr[k]) seq.push_back(SpOp{3u, i == j ? diag(i) : off(i, j), off(i, k), off(k, j)});   // A_ij -= L_ik A_kj
+      seq.push_back(SpOp{3u, rhs(i), off(i, k), rhs(k)});                                 // b_i -= L_ik b_k
+    }
+  }
+  for (auto it = Y.order.rbegin(); it != Y.order.rend(); ++it) {
+    const int k = *it;
+    for (int j : Y.nbr[k]) seq.push_back(SpOp{3u, rhs(k), off(k, j), rhs(j)});            // b_k -= U_kj x_j
+    seq.push_back(SpOp{2u, rhs(k), diag(k), rhs(k)});                                     // x_k = D_k^-1 b_k
+  }
+  std::vector<int> lw((size_t)Y.n_blocks, -1), lr((size_t)Y.n_blocks, -1);               // last phase that wrote / read a block
+  std::vector<std::vector<SpOp>> phases;
+  for (const SpOp& o : seq) {
+    // reads (a, b, and c of an UPD) need the last write to be in an EARLIER phase; the write of c may share a phase with
+    // earlier reads of c (all lanes read before any lane writes within a phase) but not with another write of c
+    int p = std::max(lw[o.a], lw[o.b]) + 1;
+    p = std::max(p, lw[o.c] + 1);
+    p = std::max(p, lr[o.c]);
+    while (p < (int)phases.size() && (int)phases[p].size() >= S) ++p;
+    // (a later phase is always admissible: dependencies only bound p from below)
+    if (p >= (int)phases.size()) phases.resize(p + 1);
+    phases[p].push_back(o);
+    lr[o.a] = std::max(lr[o.a], p); lr[o.b] = std::max(lr[o.b], p);
+    if (o.type == 3u) lr[o.c] = std::max(lr[o.c], p);
+    lw[o.c] = p;
+  }
+  for (const auto& kv : Y.slot) { G.slots_ij.push_back(kv.first.first); G.slots_ij.push_back(kv.first.second); G.slots_ij.push_back(kv.second); }
+  G.n_phases = (int32_t)phases.size();
+  G.ops.assign((size_t)G.n_phases * S, SpOp{0u, scratch, scratch, scratch});
+  for (int p = 0; p < G.n_phases; ++p) for (size_t q = 0; q < phases[p].size(); ++q) G.ops[(size_t)p * S + q] = phases[p][q];
+}
+
 void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw) {
   const int n = P.n;
   if (Sw < 1 || W % Sw) Sw = 1;

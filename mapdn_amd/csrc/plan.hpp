@@ -120,6 +120,33 @@ struct Plan {
   std::vector<int32_t> state_kind, state_idx;   // [state_size]
 };
 
+// -------------------------------------------------------------------------------------------------------------------
+// General sparse path (k_nr_sparse, sparse.hip): for a MESHED net the block-2x2 LU of the Jacobian has fill, so the host
+// does the symbolic work once per topology — minimum-degree order on the bus graph, fill pattern, a slot for every
+// structurally non-zero 2x2 block — and compiles the numeric factorisation + forward / backward substitution into a
+// PROGRAM of block operations  B[c] = inv(B[a]) | B[c] = B[a] B[b] | B[c] -= B[a] B[b]  that a list scheduler packs
+// into phases of at most S independent operations (S = sub-lanes per env in the kernel).  Right-hand sides live in the
+// block array as [b | 0] blocks, so substitution uses the same three operations.  What pandapower leaves to SuperLU
+// at run time (pypower newtonpf.py: dx = -spsolve(J, F)) is thus decided here, off the hot path.
+struct SpOp { uint32_t type, c, a, b; };                                  // type: 0 NOP, 1 INV, 2 MUL, 3 UPD; block slots
+struct SpNz { uint32_t col; int32_t slot; double y[2]; uint32_t pad[2]; };   // Ybus entry of a row: column position (n = slack), block slot (-1: none), Y
+struct SpRow { uint32_t node, nnz, sb, live; };                           // assembly row: position, entries, Sbus entry, 1 if a real node
+static_assert(sizeof(SpOp) == 16 && sizeof(SpNz) == 32 && sizeof(SpRow) == 16, "sparse program records");
+struct SparseProg {
+  int32_t S = 0;                    // sub-lanes the program is packed for
+  int32_t n_blocks = 0;             // block slots: diag [0, n) | rhs [n, 2n) | off-diagonal incl. fill [2n, ..) | one scratch slot
+  int32_t n_fill = 0, n_phases = 0, rows_per_sub = 0, max_nnz = 0;
+  std::vector<int32_t> order;       // elimination order (positions)
+  std::vector<int32_t> fill_slots;  // blocks that exist only as fill: zeroed before every assembly (padded with the scratch slot to a multiple of S)
+  std::vector<SpRow> rows;          // [S][rows_per_sub]
+  std::vector<SpNz> nz;             // [S][rows_per_sub][max_nnz]
+  std::vector<SpOp> ops;            // [n_phases][S]
+  std::vector<int32_t> slots_ij;    // (i, j, slot) of every off-diagonal block incl. fill (host only: plan checks)
+};
+// symbolic factorisation only (n_blocks etc.; S-independent), then the packed program for S sub-lanes
+void sparse_symbolic(const Plan& P, SparseProg& out);
+void sparse_program(const Plan& P, int S, SparseProg& out);
+
 // returns MAPDN_OK or an error code, filling `err`
 int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& out, std::string& err);
 

@@ -82,11 +82,16 @@ def test_meshed_nets_are_accepted_and_ybus_matches_the_oracle():
 _lib_E_TOPOLOGY = -2
 
 
-def test_large_meshed_and_disconnected_nets_are_refused_loudly():
+def test_large_meshed_nets_are_accepted_and_disconnected_ones_refused_loudly(monkeypatch):
     net, _ = make_case("case141")
     meshed = add_lines(net, [5], [77], 0.3, 0.2)
+    lib, h, rc, keep = host_handle(meshed)                  # general sparse solver: any meshed net whose blocks fit in LDS
+    assert rc == 0, lib.mapdn_last_error(None)
+    lib.mapdn_destroy(h)
+    monkeypatch.setenv("MAPDN_NR_DENSE", "1")               # the dense MFMA solver keeps one env's Jacobian in LDS: <= 65 buses
     lib, h, rc, keep = host_handle(meshed)
     assert rc == _lib_E_TOPOLOGY and b"65 buses" in lib.mapdn_last_error(None)
+    monkeypatch.delenv("MAPDN_NR_DENSE")
     island = net.copy(); island.line_in_service[3] = 0
     lib, h, rc, keep = host_handle(island)
     assert rc == _lib_E_TOPOLOGY and b"not connected" in lib.mapdn_last_error(None)
@@ -162,16 +167,33 @@ def _solve_inputs(net, prof, B, seed):
     return prof.load_p[rows], prof.load_q[rows], pv, qs
 
 
-@gpu
-@pytest.mark.parametrize("which", ["case33_tie1", "case33_tie5"] + [f"rand{s}" for s in range(8)])
-def test_meshed_solve_matches_oracle(which):
-    import torch
-    from mapdn_amd.env import VoltageControlBatch
+def _meshed(which):
     if which.startswith("case33"):
         base, prof = make_case("case33")
-        net = case33_meshed(base, int(which[-1]))
-    else:
-        net, prof = random_meshed_net(int(which[4:]))
+        return case33_meshed(base, int(which[-1])), prof
+    if which == "case141_ties":
+        base, prof = make_case("case141")
+        return add_lines(base, [5, 40, 77, 100], [77, 120, 130, 12], 0.3, 0.2), prof
+    if which == "case322_ties":
+        base, prof = make_case("case322")
+        return add_lines(base, [5, 40, 177, 200, 300], [77, 120, 30, 12, 150], 0.3, 0.2), prof
+    if which.startswith("big"):
+        return random_meshed_net(int(which[3:]), nb_max=160)
+    return random_meshed_net(int(which[4:]))
+
+
+@gpu
+@pytest.mark.parametrize("solver,which", [("sparse", w) for w in ["case33_tie1", "case33_tie5", "case141_ties", "case322_ties", "big1", "big2", "big3"]
+                                          + [f"rand{s}" for s in range(8)]]
+                         + [("dense", w) for w in ["case33_tie1", "case33_tie5"] + [f"rand{s}" for s in range(8)]])
+def test_meshed_solve_matches_oracle(solver, which, monkeypatch):
+    """both general-topology solvers — the sparse block program (default for meshed nets, any size that fits LDS) and the
+    dense LU with f64 MFMA (MAPDN_NR_DENSE=1, <= 65 buses) — against the oracle's SuperLU Newton"""
+    import torch
+    from mapdn_amd.env import VoltageControlBatch
+    net, prof = _meshed(which)
+    if solver == "dense":
+        monkeypatch.setenv("MAPDN_NR_DENSE", "1")
     B = 70
     a = dict(episode_limit=240, action_scale=0.8, action_bias=0.0, voltage_barrier_type="l2", seed=1)
     env = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0", obs_dtype=torch.float64)
@@ -191,18 +213,21 @@ def test_meshed_solve_matches_oracle(which):
 
 
 @gpu
-def test_dense_solver_equals_the_tree_solver_on_a_radial_feeder(monkeypatch):
-    """MAPDN_NR_DENSE=1 forces the general solver onto case33: same Newton iterates as the tree elimination"""
+@pytest.mark.parametrize("solver,case", [("MAPDN_NR_DENSE", "case33"), ("MAPDN_NR_SPARSE", "case33"), ("MAPDN_NR_SPARSE", "case141"),
+                                         ("MAPDN_NR_SPARSE", "case322")])
+def test_general_solvers_equal_the_tree_solver_on_radial_feeders(solver, case, monkeypatch):
+    """MAPDN_NR_DENSE=1 / MAPDN_NR_SPARSE=1 force a general solver onto a radial feeder: same Newton iterates as the tree
+    elimination (a tree has no fill: the sparse program is then the tree elimination in minimum-degree order)"""
     import torch
     from mapdn_amd.env import VoltageControlBatch
-    net, prof = make_case("case33")
+    net, prof = make_case(case)
     a = dict(episode_limit=240, action_scale=0.8, action_bias=0.0, voltage_barrier_type="bowl", seed=0)
     B = 130
     ins = _solve_inputs(net, prof, B, 9)
     tree = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0")
     rt = [t.cpu().numpy() for t in tree.solve(*ins)]
     tree.close()
-    monkeypatch.setenv("MAPDN_NR_DENSE", "1")
+    monkeypatch.setenv(solver, "1")
     dense = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0")
     rd = [t.cpu().numpy() for t in dense.solve(*ins)]
     dense.close()
@@ -211,17 +236,16 @@ def test_dense_solver_equals_the_tree_solver_on_a_radial_feeder(monkeypatch):
 
 
 @gpu
-@pytest.mark.parametrize("which", ["case33_tie5", "rand2", "rand5"])
-def test_meshed_env_episode_matches_the_oracle_env(which):
+@pytest.mark.parametrize("solver,which", [("sparse", "case33_tie5"), ("sparse", "rand2"), ("sparse", "case141_ties"), ("sparse", "big2"),
+                                          ("dense", "case33_tie5"), ("dense", "rand5")])
+def test_meshed_env_episode_matches_the_oracle_env(solver, which, monkeypatch):
     """the whole step (inject -> general solve -> fused reward epilogue -> commit -> obs) on a meshed net"""
     import torch
     from mapdn_amd.env import VoltageControlBatch
     from oracle.env_restated import INFO_KEYS, VoltageControlOracle
-    if which.startswith("case33"):
-        base, prof = make_case("case33")
-        net = case33_meshed(base, 5)
-    else:
-        net, prof = random_meshed_net(int(which[4:]))
+    net, prof = _meshed(which)
+    if solver == "dense":
+        monkeypatch.setenv("MAPDN_NR_DENSE", "1")
     a = dict(episode_limit=240, action_scale=0.8, action_bias=0.0, voltage_barrier_type="bowl", seed=3)
     B = 5
     env = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0", obs_dtype=torch.float64)
@@ -244,3 +268,90 @@ def test_meshed_env_episode_matches_the_oracle_env(which):
             assert np.abs(res["pl_mw"][e].cpu().numpy() - o.res.pl_mw).max() < 1e-9
             assert np.abs(np.array(o.get_obs()) - obs[e].cpu().numpy()).max() < 1e-9
     env.close()
+
+
+# ------------------------------------------------------------------------------------------------ sparse program (CPU)
+def _emulate_program(n, S, dims, ops, slots_ij, J, b):
+    """execute the host-compiled elimination program in numpy: blocks B[slot] (2x2), rhs as [b | 0] blocks"""
+    nblk, nph = dims[0], dims[2]
+    B = np.zeros((nblk, 2, 2))
+    for i in range(n):
+        B[i] = J[2 * i:2 * i + 2, 2 * i:2 * i + 2]
+        B[n + i][:, 0] = b[2 * i:2 * i + 2]
+    covered = np.zeros((n, n), bool)
+    for i, j, s in slots_ij.reshape(-1, 3):
+        B[s] = J[2 * i:2 * i + 2, 2 * j:2 * j + 2]
+        covered[i, j] = True
+    for i in range(n):
+        for j in range(n):
+            if i != j and not covered[i, j]:
+                assert not J[2 * i:2 * i + 2, 2 * j:2 * j + 2].any()      # every structural block has a slot
+    ops = ops.reshape(nph, S, 4)
+    for p in range(nph):
+        rd = [(B[a].copy(), B[bb].copy(), B[c].copy()) for (t, c, a, bb) in ops[p]]          # all lanes read, then all write
+        writes = set()
+        for (t, c, a, bb), (Aa, Bb, Cc) in zip(ops[p], rd):
+            if t == 0:
+                continue
+            assert c not in writes, "two writes of one block in a phase"
+            writes.add(c)
+            B[c] = np.linalg.inv(Aa) if t == 1 else (Aa @ Bb if t == 2 else Cc - Aa @ Bb)
+    return np.concatenate([B[n + i][:, 0] for i in range(n)])
+
+
+@pytest.mark.parametrize("which,S", [("case33_tie5", 4), ("case33_tie5", 16), ("rand3", 8), ("rand6", 32), ("case141_ties", 8), ("case322_ties", 16), ("case141_radial", 8)])
+def test_sparse_elimination_program_solves_the_jacobian(which, S):
+    """host symbolic factorisation (minimum degree, fill) + list-scheduled block program, executed in numpy, against
+    scipy's spsolve on the oracle's Jacobian — for weakly meshed 141 / 322-bus nets too"""
+    import scipy.sparse.linalg as spla
+    from oracle.pp_restated import jacobian
+    if which.startswith("case33"):
+        net = case33_meshed(make_case("case33")[0], 5)
+    elif which == "case141_ties":
+        net = add_lines(make_case("case141")[0], [5, 40, 77, 100], [77, 120, 130, 12], 0.3, 0.2)
+    elif which == "case322_ties":
+        net = add_lines(make_case("case322")[0], [5, 40, 177, 200, 300], [77, 120, 30, 12, 150], 0.3, 0.2)
+    elif which == "case141_radial":
+        net = make_case("case141")[0]
+    else:
+        net = random_meshed_net(int(which[4:]))[0]
+    lib, h, rc, keep = host_handle(net)
+    assert rc == 0, lib.mapdn_last_error(None)
+    n = net.n_bus - 1
+    dims = np.zeros(6, np.int32)
+    assert lib.mapdn_get_sparse_program(h, S, _lib._p(dims, _lib._pi), None, None, None) == 0
+    ops = np.zeros(dims[2] * S * 4, np.int32); order = np.zeros(n, np.int32); sl = np.zeros(3 * dims[5], np.int32)
+    assert lib.mapdn_get_sparse_program(h, S, _lib._p(dims, _lib._pi), _lib._p(ops, _lib._pi), _lib._p(order, _lib._pi), _lib._p(sl, _lib._pi)) == 0
+    assert sorted(order.tolist()) == list(range(n))
+    # positions: ask the library which bus sits where (flat-factor export is tree-only; use the schedule-free bus_of_pos via ybus order)
+    # meshed plans order positions by ascending bus id without the slack; radial ones by the elimination forest: rebuild J in
+    # POSITION order from the library's own dense Ybus permuted accordingly
+    pos_bus = _positions(lib, h, net)
+    rng = np.random.default_rng(0)
+    v = (1.0 + 0.05 * rng.standard_normal(net.n_bus)) * np.exp(1j * 0.05 * rng.standard_normal(net.n_bus))
+    ybus = make_ybus(net)[0]
+    pq = np.array(pos_bus[:n])
+    Jpp = jacobian(ybus, v, pq, pq).toarray()          # [[dP/dth, dP/dVm], [dQ/dth, dQ/dVm]] over pq in position order
+    Jpp[:, n:] *= np.abs(v[pq])[None, :]                # scaled unknowns d|V|/|V|
+    perm = np.ravel(np.column_stack([np.arange(n), n + np.arange(n)]))   # interleave (theta_k, v_k) / (P_k, Q_k) per node
+    J = Jpp[np.ix_(perm, perm)]
+    b = rng.standard_normal(2 * n)
+    x = _emulate_program(n, S, dims, ops, sl, J, b)
+    ref = spla.spsolve(__import__("scipy.sparse", fromlist=["csc_matrix"]).csc_matrix(J), b)
+    assert np.abs(x - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+    nph = int(dims[2])
+    if which == "case141_radial":
+        assert dims[1] == 0 and nph < 200                # a tree has no fill; list scheduling finds its parallelism
+    lib.mapdn_destroy(h)
+
+
+def _positions(lib, h, net):
+    """bus id of every position (position n = slack): meshed plans use ascending bus ids, radial ones export it"""
+    n = net.n_bus - 1
+    dims = _lib.CDims()
+    assert lib.mapdn_dims(h, C.byref(dims)) == 0
+    if dims.is_radial:
+        fac = np.zeros((n, 12)); bop = np.zeros(n + 1, np.int32)
+        assert lib.mapdn_get_flat_factors(h, _lib._p(fac, _lib._pd), _lib._p(bop, _lib._pi)) == 0
+        return bop.tolist()
+    return [b for b in range(net.n_bus) if b != net.ext_grid_bus] + [int(net.ext_grid_bus)]

@@ -23,14 +23,14 @@ full) timeout 900 python $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_def
 sq) timeout 600 rocprofv3 -i $R/tools/pmc_sq.txt --output-format csv -d $OUT/sq -o sq -- python $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-traffic > $OUT/sq.log 2>&1
     python $R/tools/pmc_sq_summary.py --kernel k_nr_tree $OUT/nr_sq_counters.txt $(find $OUT/sq -name "*counter_collection.csv") | head -24; rm -rf $OUT/sq;;
 dense) rocprofv3 --list-avail 2>/dev/null | grep -i -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*" | sort -u > $OUT/mfma_counter_names.txt
-    timeout 300 python $R/tools/dense_bench.py > $OUT/dense_bench_case33_meshed5.json 2> $OUT/dense_bench.err; cat $OUT/dense_bench_case33_meshed5.json
-    MAPDN_NR_DENSE=1 timeout 300 python $R/tools/dense_bench.py --ties 0 > $OUT/dense_bench_case33_radial_forced.json 2>> $OUT/dense_bench.err
+    MAPDN_NR_DENSE=1 timeout 300 python $R/tools/general_bench.py > $OUT/dense_bench_case33_meshed5.json 2> $OUT/dense_bench.err; cat $OUT/dense_bench_case33_meshed5.json
+    MAPDN_NR_DENSE=1 timeout 300 python $R/tools/general_bench.py --ties 0 > $OUT/dense_bench_case33_radial_forced.json 2>> $OUT/dense_bench.err
     timeout 300 python $R/bench.py --case case33 --envs 4096 --steps 100 --warmup 10 --no-cpu-baseline --no-traffic > $OUT/tree_bench_case33.json 2>> $OUT/dense_bench.err
-    timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ksd -o ks -- python $R/tools/dense_bench.py > /dev/null 2> $OUT/ksd.log
+    MAPDN_NR_DENSE=1 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ksd -o ks -- python $R/tools/general_bench.py > /dev/null 2> $OUT/ksd.log
     db=$(find $OUT/ksd -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/prof_summary.py $db $OUT/kernel_stats_dense_case33_meshed5.txt > /dev/null; rm -rf $OUT/ksd
     for pm in "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
       tag=$(echo $pm | cut -d' ' -f1)
-      timeout 300 rocprofv3 --pmc $pm --output-format csv -d $OUT/pmd_$tag -o pm -- python $R/tools/dense_bench.py --steps 20 > /dev/null 2> $OUT/pmd_$tag.log
+      MAPDN_NR_DENSE=1 timeout 300 rocprofv3 --pmc $pm --output-format csv -d $OUT/pmd_$tag -o pm -- python $R/tools/general_bench.py --steps 20 > /dev/null 2> $OUT/pmd_$tag.log
       python - <<PY
 import csv, glob, collections
 v = collections.defaultdict(list)
@@ -46,6 +46,13 @@ with open("$OUT/dense_mfma_counters.txt", "a") as o:
 PY
       rm -rf $OUT/pmd_$tag
     done;;
+sparse) for cfg in "case33 5" "case141 5" "case322 5"; do set -- $cfg
+      timeout 300 python $R/tools/general_bench.py --case $1 --ties $2 > $OUT/sparse_bench_$1_meshed$2.json 2>> $OUT/sparse_bench.err; cat $OUT/sparse_bench_$1_meshed$2.json
+      MAPDN_NR_SPARSE=1 timeout 300 python $R/tools/general_bench.py --case $1 --ties 0 > $OUT/sparse_bench_$1_radial_forced.json 2>> $OUT/sparse_bench.err; cat $OUT/sparse_bench_$1_radial_forced.json
+      timeout 300 python $R/tools/general_bench.py --case $1 --ties 0 > $OUT/tree_bench_$1.json 2>> $OUT/sparse_bench.err; cat $OUT/tree_bench_$1.json
+    done
+    timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kss -o ks -- python $R/tools/general_bench.py --case case141 --ties 5 > /dev/null 2> $OUT/kss.log
+    db=$(find $OUT/kss -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/prof_summary.py $db $OUT/kernel_stats_sparse_case141_meshed5.txt > /dev/null; rm -rf $OUT/kss;;
 e2e) timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kse -o ks -- python $R/examples/train_ddpg.py --case case322 --envs 8192 --episodes 1 --max-steps 120 > $OUT/e2e.log 2>&1
     db=$(find $OUT/kse -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/prof_summary.py $db $OUT/e2e_kernel_stats.txt | head -30; rm -rf $OUT/kse; tail -5 $OUT/e2e.log;;
 esac
