@@ -253,9 +253,25 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     return MAPDN_OK;
   }
   if (h->solver == 1) {                           // k_nr_sparse (sparse.hip): host-compiled block elimination program
+    // Envs per (one-wave) workgroup: fewer envs = more sub-lanes per env = fewer phases, and a smaller LDS tile = more
+    // resident waves per CU to hide each other's LDS latency.  Score = envs in flight per CU / length of the per-iteration
+    // instruction stream (phases + assembly entries); measured on case33 / case141 / case322 with tie lines closed
+    // (profiles/r02_sparse_lanes_sweep.txt): the score ranks the four geometries in the measured order.
+    {
+      double best = -1.0;
+      for (int l : {16, 8, 4, 2}) {
+        SparseProg g;
+        sparse_program(P, 64 / l, g);
+        const size_t lds = nr_sparse_lds_bytes(P.n, g.n_blocks, l);
+        if (lds > 160 * 1024) continue;
+        const double waves = (double)std::min<size_t>(160 * 1024 / lds, 8);
+        const double score = waves * l / ((double)g.n_phases + 0.5 * g.rows_per_sub * g.max_nnz);
+        if (score > best) { best = score; h->sp_lanes = l; }
+      }
+    }
     if (const char* s_ = getenv("MAPDN_SP_LANES")) {   // experiments: envs per workgroup (16 / 8 / 4 / 2)
       const int l = atoi(s_);
-      if ((l == 16 || l == 8 || l == 4 || l == 2) && nr_sparse_lds_bytes(P.n, 0, l) <= 160 * 1024) h->sp_lanes = l;
+      if (l == 16 || l == 8 || l == 4 || l == 2) h->sp_lanes = l;
     }
     sparse_program(P, 64 / h->sp_lanes, h->sprog);
     const SparseProg& G = h->sprog;

@@ -117,6 +117,7 @@ k_nr_sparse(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ 
     {                                                              // AND over the sub-lanes of an env
       s_epi[(size_t)s * L] = ok ? 1.0 : 0.0;
       bool all = true;
+#pragma unroll 4
       for (unsigned t = 0; t < S; ++t) all = all && (s_epi[(size_t)t * L] != 0.0);
       ok = all;
     }
