@@ -31,7 +31,7 @@ extern "C" {
 
 #define MAPDN_OK 0
 #define MAPDN_E_INVALID (-1)   /* bad argument / inconsistent netspec                        */
-#define MAPDN_E_TOPOLOGY (-2)  /* net not connected, or meshed with more than 65 buses          */
+#define MAPDN_E_TOPOLOGY (-2)  /* net not connected, or meshed and too large for a CU's LDS        */
 #define MAPDN_E_HIP (-3)       /* HIP runtime error (no device, OOM, launch failure)           */
 #define MAPDN_E_STATE (-4)     /* call order violated (e.g. step before set_profiles/reset)    */
 
@@ -135,9 +135,10 @@ const char* mapdn_last_error(const mapdn_handle* h);
  * Builds per-unit Ybus (pandapower pd2ppc/makeYbus), the elimination order and all gather index
  * tables on the host, uploads them to `device`, allocates state for n_envs envs.
  * Topology: pp.runpp (voltage_control_env.py:557) solves any connected net.  Radial feeders (all three MAPDN
- * scenarios) take the fill-free tree solver; a meshed net (closed tie switches, loops) takes the general solver —
- * dense Jacobian per env in LDS, blocked LU with f64 MFMA trailing updates — which handles up to 65 buses;
- * larger meshed nets and nets with buses not connected to the ext_grid return MAPDN_E_TOPOLOGY.
+ * scenarios) take the fill-free tree solver; a meshed net (closed tie switches, loops) takes the general sparse solver:
+ * symbolic factorisation with fill on the host, the numeric part as a program of 2x2 block operations interpreted with
+ * all blocks of a few envs in LDS (nets up to ~2400 blocks after fill: the 322-bus case with tie lines fits).
+ * Nets beyond that and nets with buses not connected to the ext_grid return MAPDN_E_TOPOLOGY.
  * device == -1 builds a host-only handle (plan, dims, ybus/obs-index export; no device calls).
  * Tuning knobs read from the environment at create time (defaults are chosen per topology):
  *   MAPDN_NR_WAVES (1/2/4/8), MAPDN_NR_LANES (4/8/16/32)   waves and envs per NR workgroup
@@ -146,7 +147,10 @@ const char* mapdn_last_error(const mapdn_handle* h);
  *                                                          first tried mismatch-only (never changes results)
  *   MAPDN_NR_CHECK_QUAD (default 1)                        safety factor of the second predictor, ||F||^3/||F_prev||^2 < tol / factor
  *                                                          ("inf" disables it)
- *   MAPDN_NR_DENSE (0/1)                                   1: use the general (dense) solver on a radial net too (cross-checks) */
+ *   MAPDN_NR_SPARSE (0/1)                                  1: use the general sparse solver on a radial net too (cross-checks)
+ *   MAPDN_NR_DENSE (0/1)                                   1: use the dense LDS-resident LU with f64 MFMA trailing updates
+ *                                                          (<= 65 buses; any topology) instead
+ *   MAPDN_SP_LANES (16/8/4/2)                              envs per workgroup of the sparse solver (default: scored per net) */
 int mapdn_create(const mapdn_netspec* net, const mapdn_env_config* cfg, int32_t n_envs,
                  int32_t device, mapdn_handle** out);
 void mapdn_destroy(mapdn_handle* h);
