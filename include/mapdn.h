@@ -231,7 +231,8 @@ int mapdn_get_flat_factors(const mapdn_handle* h, double* factors, int32_t* bus_
 
 /* Host-side export of the general sparse solver's elimination PROGRAM for S sub-lanes (plan check, CPU tests): dims [6] =
  * block slots, fill-only blocks, phases, assembly rows per sub-lane, max row entries, number of off-diagonal blocks;
- * ops [phases * S * 4] = (type, c, a, b) with type 0 NOP, 1 B[c] = inv(B[a]), 2 B[c] = B[a] B[b], 3 B[c] -= B[a] B[b]
+ * ops [phases * S * 4] = (type, c, a, b) with (type & 255) 0 NOP, 1 B[c] = inv(B[a]), 2 B[c] = B[a] B[b], 3 B[c] -= B[a] B[b]
+ * (bits 8 / 9 of type: wave-uniform hints "this phase holds an INV / an UPD")
  * (block slots: diagonal of node i = i, right-hand side of node i = n + i as the block [b | 0]); order [n] = minimum-degree
  * elimination order (positions); slots_ij [3 * dims[5]] = (i, j, slot) of every off-diagonal block incl. fill.  Executing the
  * ops in phase order on the assembled blocks solves J x = b — tests/test_general_topology.py does it in numpy against

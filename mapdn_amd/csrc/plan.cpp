@@ -385,7 +385,14 @@ void sparse_program(const Plan& P, int S, SparseProg& G) {
   for (const auto& kv : Y.slot) { G.slots_ij.push_back(kv.first.first); G.slots_ij.push_back(kv.first.second); G.slots_ij.push_back(kv.second); }
   G.n_phases = (int32_t)phases.size();
   G.ops.assign((size_t)G.n_phases * S, SpOp{0u, scratch, scratch, scratch});
-  for (int p = 0; p < G.n_phases; ++p) for (size_t q = 0; q < phases[p].size(); ++q) G.ops[(size_t)p * S + q] = phases[p][q];
+  for (int p = 0; p < G.n_phases; ++p) {
+    for (size_t q = 0; q < phases[p].size(); ++q) G.ops[(size_t)p * S + q] = phases[p][q];
+    // wave-uniform hints (the same in every record of a phase): bit 8 = the phase holds an INV, bit 9 = it holds an UPD —
+    // the kernel skips the 2x2 inverse / the loads of C for phases that have neither
+    uint32_t hint = 0;
+    for (const SpOp& o : phases[p]) hint |= o.type == 1u ? 256u : (o.type == 3u ? 512u : 0u);
+    for (int q = 0; q < S; ++q) G.ops[(size_t)p * S + q].type |= hint;
+  }
 }
 
 void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw) {

@@ -139,16 +139,21 @@ k_nr_sparse(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ 
           if (p < NPH) {                           // (uniform)
           const u32x4 op = oq[u];
           oq[u] = __builtin_amdgcn_raw_buffer_load_b128(rsO, voO, __builtin_amdgcn_readfirstlane((unsigned)min(p + PF, NPH - 1) * S * 16u), 0);
-          const unsigned type = op.x;
+          const unsigned type = op.x & 255u;
+          const unsigned hint = __builtin_amdgcn_readfirstlane(op.x);     // bits 8 / 9: the phase holds an INV / an UPD (wave-uniform)
           const d2* A = blk(op.z); const d2* B = blk(op.w); d2* C = blk(op.y);
-          const d2 a0 = A[0], a1 = A[1], b0 = B[0], b1 = B[1], c0 = C[0], c1 = C[1];
+          const d2 a0 = A[0], a1 = A[1], b0 = B[0], b1 = B[1];
+          d2 c0 = d2{0.0, 0.0}, c1 = d2{0.0, 0.0};
+          if (hint & 512u) { c0 = C[0]; c1 = C[1]; }
           const double p00 = a0.x * b0.x + a0.y * b1.x, p01 = a0.x * b0.y + a0.y * b1.y;
           const double p10 = a1.x * b0.x + a1.y * b1.x, p11 = a1.x * b0.y + a1.y * b1.y;
-          const double idet = rcp_nr(a0.x * a1.y - a0.y * a1.x);
           d2 n0, n1;
-          if (type == 1u) { n0 = d2{a1.y * idet, -a0.y * idet}; n1 = d2{-a1.x * idet, a0.x * idet}; }
-          else if (type == 2u) { n0 = d2{p00, p01}; n1 = d2{p10, p11}; }
+          if (type == 2u) { n0 = d2{p00, p01}; n1 = d2{p10, p11}; }
           else { n0 = d2{c0.x - p00, c0.y - p01}; n1 = d2{c1.x - p10, c1.y - p11}; }
+          if (hint & 256u) {
+            const double idet = rcp_nr(a0.x * a1.y - a0.y * a1.x);
+            if (type == 1u) { n0 = d2{a1.y * idet, -a0.y * idet}; n1 = d2{-a1.x * idet, a0.x * idet}; }
+          }
           if (type != 0u && !done) { C[0] = n0; C[1] = n1; }
           }
         }

@@ -290,7 +290,12 @@ def _emulate_program(n, S, dims, ops, slots_ij, J, b):
     for p in range(nph):
         rd = [(B[a].copy(), B[bb].copy(), B[c].copy()) for (t, c, a, bb) in ops[p]]          # all lanes read, then all write
         writes = set()
+        hints = {int(t) >> 8 for (t, c, a, bb) in ops[p]}
+        assert len(hints) == 1                                        # the phase hints are wave-uniform
+        kinds = {int(t) & 255 for (t, c, a, bb) in ops[p]}
+        assert ((1 in kinds) == bool(next(iter(hints)) & 1)) and ((3 in kinds) == bool(next(iter(hints)) & 2))
         for (t, c, a, bb), (Aa, Bb, Cc) in zip(ops[p], rd):
+            t = int(t) & 255
             if t == 0:
                 continue
             assert c not in writes, "two writes of one block in a phase"
