@@ -1,7 +1,7 @@
 # Convenience targets; the Python entry points (mapdn_amd.build, __graft_entry__.build) do the same build.
 HIPCC ?= /opt/rocm/bin/hipcc
 LIB   := mapdn_amd/libmapdn_hip.so
-SRC   := mapdn_amd/csrc/plan.cpp mapdn_amd/csrc/kernels.hip mapdn_amd/csrc/dense.hip mapdn_amd/csrc/sparse.hip mapdn_amd/csrc/capi.hip
+SRC   := mapdn_amd/csrc/plan.cpp mapdn_amd/csrc/kernels.hip mapdn_amd/csrc/dense.hip mapdn_amd/csrc/sparse.hip mapdn_amd/csrc/policy.hip mapdn_amd/csrc/capi.hip
 HDR   := mapdn_amd/csrc/plan.hpp mapdn_amd/csrc/kernels.hpp mapdn_amd/csrc/nr_common.hpp include/mapdn.h
 
 lib: $(LIB)

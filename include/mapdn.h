@@ -245,6 +245,16 @@ int mapdn_get_sparse_program(const mapdn_handle* h, int32_t sub_lanes, int32_t* 
  * does with SuperLU in pypower/newtonpf.py (dx = -spsolve(J, F)).  Tests compare with numpy.linalg.solve. */
 int mapdn_dense_solve(const double* a, const double* b, double* x, int32_t n, int32_t batch, void* stream);
 
+/* Rollout-side forward of the shared-parameter recurrent agent (agents/rnn_agent.py:5-32 as called by
+ * models/model.py:101-139): fc1 (+ one-hot agent-id column) -> LayerNorm -> ReLU -> GRUCell -> fc2, one launch, inference only.
+ * Device pointers, fp32, contiguous: obs [rows, obs_dim] (rows = envs x agents, agent = row % n_agents), hid_in / hid_out
+ * [rows, 64], w1 [64, obs_dim + id_dim] (id_dim = n_agents or 0), w_ih / w_hh [192, 64] (torch.nn.GRUCell layout: r, z, n),
+ * w2 [1, 64]; means [rows].  Hidden size 64, action_dim 1 (the reference's defaults). */
+int mapdn_policy_forward(const float* obs, const float* hid_in, const float* w1, const float* b1, const float* ln_g,
+                         const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                         const float* w2, const float* b2, float* means, float* hid_out, int32_t rows, int32_t n_agents,
+                         int32_t obs_dim, int32_t id_dim, float ln_eps, void* stream);
+
 /* counters (host, synchronises the given stream): number of envs whose last reset exhausted
  * max_tries; mean / max NR iterations of the last solve */
 int mapdn_stats(mapdn_handle* h, int64_t* reset_failures, double* mean_iters, int32_t* max_iters,

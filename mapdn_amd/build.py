@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmapdn_hip.so")
-SOURCES = ["plan.cpp", "kernels.hip", "dense.hip", "sparse.hip", "capi.hip"]
+SOURCES = ["plan.cpp", "kernels.hip", "dense.hip", "sparse.hip", "policy.hip", "capi.hip"]
 HEADERS = ["plan.hpp", "kernels.hpp", "nr_common.hpp", os.path.join("..", "..", "include", "mapdn.h")]
 
 

@@ -1,0 +1,186 @@
+// policy.hip — rollout-side forward of MAPDN's shared-parameter recurrent agent, gfx950 (MI355X).
+//
+// Reference: agents/rnn_agent.py:5-32 (fc1 -> LayerNorm -> ReLU -> GRUCell -> fc2) as called once per env step by the
+// rollout (models/model.py:101-139, 204-262) on [envs x agents] rows of 58-82 observation values + a one-hot agent id.
+// The stock PyTorch path is five launches whose small GEMMs / LayerNorm / GRU-cell kernels run far below any roof at this
+// shape (profiles/e2e): the batched env made them the bulk of a training step.  This kernel does the whole forward in one
+// launch for inference (no autograd; training-time forward passes stay in PyTorch): one wavefront per tile of 16 rows, the
+// three products on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, like the reference's fp32 modules), the
+// whole parameter set (~130 KB) staged once per workgroup in LDS in MFMA operand order (weight-stationary), LayerNorm /
+// gates / fc2 on the accumulator layout with DPP-row reductions.  Results agree with PyTorch to ~1e-6 (summation order).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "../../include/mapdn.h"
+
+namespace mapdn {
+
+constexpr int PH = 64;          // hidden size (args.hid_size of the reference's default.yaml)
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// sum over the 16 lanes of a DPP row (lanes that share lane >> 4)
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __shfl_xor(v, 1, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 8, 16);
+  return v;
+}
+
+// One wavefront = one tile of 16 rows at a time; every product runs on v_mfma_f32_16x16x4_f32 (exact fp32 at the vector
+// rate, but 1024 MACs per 256 bytes of operand traffic — the VALU form of this kernel, one thread per row with the weights
+// as LDS broadcasts, measured 1.02 ms for 311 k rows, exactly PyTorch's time: LDS-bound at 0.25 MAC per LDS byte).
+// Operand maps (CDNA4 guide): A lane l = A[i = l & 15][k], B lane l = B[k][j = l & 15], C/D reg r of lane l = row 4 (l >> 4) + r,
+// column l & 15.  The k index of MFMA step s of chunk c is 16 c + 4 (l >> 4) + s for BOTH operands, so a lane's four steps of
+// a chunk are 16 contiguous bytes: one b128 load per operand and chunk.  Weights are staged ONCE per workgroup in LDS in
+// exactly that operand order (Wop[n-tile][chunk][lane] = 4 floats), weight-stationary.
+__global__ void __launch_bounds__(256)
+k_policy_fwd(const float* __restrict__ obs, const float* __restrict__ hid_in, const float* __restrict__ w1, const float* __restrict__ b1,
+             const float* __restrict__ ln_g, const float* __restrict__ ln_b, const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+             const float* __restrict__ b_ih, const float* __restrict__ b_hh, const float* __restrict__ w2, const float* __restrict__ b2,
+             float* __restrict__ means, float* __restrict__ hid_out, int rows, int n_agents, int o, int ids, float ln_eps) {
+  extern __shared__ float sm[];
+  const int KC1 = (o + 15) >> 4;                                  // 16-wide k chunks of fc1 (zero-padded weights)
+  f4* sW1 = (f4*)sm;                                              // [4][KC1][64]
+  f4* sWih = sW1 + (size_t)4 * KC1 * 64;                          // [12][4][64]
+  f4* sWhh = sWih + 12 * 4 * 64;                                  // [12][4][64]
+  float* sW1id = (float*)(sWhh + 12 * 4 * 64);                    // [ids][64]
+  float* sB1 = sW1id + (size_t)ids * PH;
+  float* sG = sB1 + PH; float* sB = sG + PH;
+  float* sBih = sB + PH; float* sBhh = sBih + 3 * PH; float* sW2 = sBhh + 3 * PH;
+  float* sX = sW2 + PH;                                           // [4 waves][16][68]: C layout -> A layout of the activations
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15, in1 = o + ids;
+  for (int i = tid; i < 4 * KC1 * 64; i += 256) {
+    const int l = i & 63, c = (i >> 6) % KC1, nt = (i >> 6) / KC1;
+    f4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int k = 16 * c + 4 * (l >> 4) + q; v[q] = k < o ? w1[(size_t)(16 * nt + (l & 15)) * in1 + k] : 0.0f; }
+    sW1[i] = v;
+  }
+  for (int i = tid; i < 12 * 4 * 64; i += 256) {
+    const int l = i & 63, c = (i >> 6) & 3, nt = i >> 8;
+    const size_t base = (size_t)(16 * nt + (l & 15)) * PH + 16 * c + 4 * (l >> 4);
+    sWih[i] = *(const f4*)(w_ih + base); sWhh[i] = *(const f4*)(w_hh + base);
+  }
+  for (int i = tid; i < ids * PH; i += 256) sW1id[i] = w1[(size_t)(i % PH) * in1 + o + i / PH];      // [agent][unit]
+  for (int i = tid; i < PH; i += 256) { sB1[i] = b1[i]; sG[i] = ln_g[i]; sB[i] = ln_b[i]; sW2[i] = w2[i]; }
+  for (int i = tid; i < 3 * PH; i += 256) { sBih[i] = b_ih[i]; sBhh[i] = b_hh[i]; }
+  __syncthreads();
+  float* xt = sX + (size_t)wave * 16 * 68;
+  const float bias2 = b2[0];
+  const int n_tiles = (rows + 15) >> 4;
+  for (int T = blockIdx.x * 4 + wave; T < n_tiles; T += gridDim.x * 4) {
+    const int row0 = T << 4;
+    const int arow = min(row0 + j, rows - 1);                     // the row this lane feeds as A operand
+    // ---- fc1: X1[16 x 64] = obs[16 x o] W1^T
+    f4 acc[4] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
+    const float* ob = obs + (size_t)arow * o;
+    for (int c = 0; c < KC1; ++c) {
+      float a[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int k = 16 * c + 4 * g + q; a[q] = k < o ? ob[k] : 0.0f; }
+      f4 bw[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bw[nt] = sW1[(size_t)(nt * KC1 + c) * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], bw[nt][q], acc[nt], 0, 0, 0);
+    }
+    // ---- + bias + one-hot id column, LayerNorm (biased variance, eps inside the root), ReLU; C layout: reg r <-> row 4 g + r
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int agent = min(row0 + 4 * g + r, rows - 1) % n_agents;
+      float sum = 0.0f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int u = 16 * nt + j;
+        acc[nt][r] += sB1[u] + (ids ? sW1id[(size_t)agent * PH + u] : 0.0f);
+        sum += acc[nt][r];
+      }
+      mean[r] = row_sum16(sum) * (1.0f / PH);
+      float var = 0.0f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) { const float dlt = acc[nt][r] - mean[r]; var = fmaf(dlt, dlt, var); }
+      rstd[r] = rsqrtf(row_sum16(var) * (1.0f / PH) + ln_eps);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int u = 16 * nt + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xt[(4 * g + r) * 68 + u] = fmaxf(fmaf((acc[nt][r] - mean[r]) * rstd[r], sG[u], sB[u]), 0.0f);
+    }
+    // (one wavefront: its LDS writes are visible to its later reads, no barrier)
+    // ---- GRUCell pre-activations: r, z over [x | h] (K = 128), i_n over x, h_n over h
+    f4 aR[4], aZ[4], aIN[4], aHN[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { aR[nt] = f4{0, 0, 0, 0}; aZ[nt] = f4{0, 0, 0, 0}; aIN[nt] = f4{0, 0, 0, 0}; aHN[nt] = f4{0, 0, 0, 0}; }
+    const float* hrow = hid_in + (size_t)arow * PH;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f4 ax = *(const f4*)(xt + j * 68 + 16 * c + 4 * g);
+      const f4 ah = *(const f4*)(hrow + 16 * c + 4 * g);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const f4 wir = sWih[(size_t)(nt * 4 + c) * 64 + lane], whr = sWhh[(size_t)(nt * 4 + c) * 64 + lane];
+        const f4 wiz = sWih[(size_t)((4 + nt) * 4 + c) * 64 + lane], whz = sWhh[(size_t)((4 + nt) * 4 + c) * 64 + lane];
+        const f4 win = sWih[(size_t)((8 + nt) * 4 + c) * 64 + lane], whn = sWhh[(size_t)((8 + nt) * 4 + c) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          aR[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[q], wir[q], aR[nt], 0, 0, 0);
+          aZ[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[q], wiz[q], aZ[nt], 0, 0, 0);
+          aIN[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[q], win[q], aIN[nt], 0, 0, 0);
+          aR[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[q], whr[q], aR[nt], 0, 0, 0);
+          aZ[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[q], whz[q], aZ[nt], 0, 0, 0);
+          aHN[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[q], whn[q], aHN[nt], 0, 0, 0);
+        }
+      }
+    }
+    // ---- gates (torch.nn.GRUCell), new hidden state, fc2
+    float outp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r;
+      const int rc = min(row, rows - 1);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int u = 16 * nt + j;
+        const float rg = sigmoidf_(aR[nt][r] + sBih[u] + sBhh[u]);
+        const float zg = sigmoidf_(aZ[nt][r] + sBih[PH + u] + sBhh[PH + u]);
+        const float nn = tanhf(fmaf(rg, aHN[nt][r] + sBhh[2 * PH + u], aIN[nt][r] + sBih[2 * PH + u]));
+        const float hu = hid_in[(size_t)rc * PH + u];
+        const float hnew = fmaf(zg, hu - nn, nn);                 // (1 - z) n + z h
+        if (row < rows) hid_out[(size_t)row * PH + u] = hnew;
+        outp[r] = fmaf(sW2[u], hnew, outp[r]);
+      }
+      const float tot = row_sum16(outp[r]);
+      if (j == 0 && row < rows) means[row] = tot + bias2;
+    }
+  }
+}
+
+}  // namespace mapdn
+
+extern "C" int mapdn_policy_forward(const float* obs, const float* hid_in, const float* w1, const float* b1, const float* ln_g,
+                                    const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                                    const float* w2, const float* b2, float* means, float* hid_out, int32_t rows, int32_t n_agents,
+                                    int32_t obs_dim, int32_t id_dim, float ln_eps, void* stream) {
+  using namespace mapdn;
+  if (!obs || !hid_in || !w1 || !means || !hid_out || rows < 1 || n_agents < 1 || obs_dim < 1 || id_dim < 0) return MAPDN_E_INVALID;
+  const int kc1 = (obs_dim + 15) / 16;
+  const size_t lds = ((size_t)4 * kc1 * 64 + 2 * 12 * 4 * 64) * 16 + ((size_t)id_dim * PH + 4 * PH + 2 * 3 * PH + 4 * 16 * 68) * sizeof(float);
+  if (lds > 160 * 1024) return MAPDN_E_INVALID;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k_policy_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MAPDN_E_HIP;
+    attr = true;
+  }
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int tiles = (rows + 15) / 16;
+  const int blocks = std::min((tiles + 3) / 4, cus);              // one resident workgroup per CU (its LDS is the parameter set)
+  hipLaunchKernelGGL(k_policy_fwd, dim3(blocks), dim3(256), lds, (hipStream_t)stream, obs, hid_in, w1, b1, ln_g, ln_b, w_ih, w_hh,
+                     b_ih, b_hh, w2, b2, means, hid_out, rows, n_agents, obs_dim, id_dim, ln_eps);
+  return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
+}

@@ -21,6 +21,7 @@ Only the configuration the DDPG family trains with exists: continuous actions, d
 from __future__ import annotations
 
 import math
+import os
 from types import SimpleNamespace
 from typing import Dict, Optional
 
@@ -172,9 +173,36 @@ class DDPGNet(nn.Module):
         return self.policy_dicts[0].fc1.weight.new_zeros(batch, self.n_, self.hid_dim)    # rnn_agent.py:22-24
 
     # ---- policy (models/model.py:101-139) --------------------------------------------------------
+    def _fused_policy_ok(self, obs: torch.Tensor, last_hid: torch.Tensor) -> bool:
+        """the one-launch HIP forward (libmapdn_hip.so: mapdn_policy_forward) covers the reference's default agent — shared
+        parameters, LayerNorm, ReLU, hidden size 64, one action — for inference on the GPU in fp32"""
+        a = self.args
+        return (not torch.is_grad_enabled() and obs.is_cuda and obs.dtype == torch.float32 and last_hid.dtype == torch.float32
+                and a.shared_params and a.layernorm and a.hid_activation == "relu" and self.hid_dim == 64 and self.act_dim == 1
+                and os.environ.get("MAPDN_FUSED_POLICY", "1") != "0")
+
+    def _fused_policy(self, obs: torch.Tensor, last_hid: torch.Tensor):
+        from . import _lib
+        ag = self.policy_dicts[0]
+        b, n, o = obs.shape[0], self.n_, self.obs_dim
+        obs_c, hid_c = obs.contiguous(), last_hid.contiguous()
+        means = torch.empty(b, n, 1, dtype=torch.float32, device=obs.device)
+        hid = torch.empty(b, n, self.hid_dim, dtype=torch.float32, device=obs.device)
+        P = lambda t: t.detach().contiguous().data_ptr()
+        ids = n if self.args.agent_id else 0
+        with torch.cuda.device(obs.device):
+            _lib.check(_lib.load().mapdn_policy_forward(
+                obs_c.data_ptr(), hid_c.data_ptr(), P(ag.fc1.weight), P(ag.fc1.bias), P(ag.layernorm.weight), P(ag.layernorm.bias),
+                P(ag.rnn.weight_ih), P(ag.rnn.weight_hh), P(ag.rnn.bias_ih), P(ag.rnn.bias_hh), P(ag.fc2.weight), P(ag.fc2.bias),
+                means.data_ptr(), hid.data_ptr(), b * n, n, o, ids, float(ag.layernorm.eps),
+                torch.cuda.current_stream(obs.device).cuda_stream))
+        return means, torch.full_like(means, math.log(self.args.fixed_policy_std)), hid
+
     def policy(self, obs: torch.Tensor, last_hid: torch.Tensor):
         """obs [b, n, o], last_hid [b, n, h] -> means [b, n, a], log_stds, hiddens [b, n, h]"""
         b, n, o = obs.shape[0], self.n_, self.obs_dim
+        if self._fused_policy_ok(obs, last_hid):
+            return self._fused_policy(obs, last_hid)
         if self.args.shared_params:
             ag = self.policy_dicts[0]
             w = ag.fc1.weight

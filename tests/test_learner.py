@@ -229,3 +229,31 @@ def test_data_parallel_update_equals_union_batch():
     tr.policy_transition_process(stat, union)
     for k, v in tr.behaviour_net.state_dict().items():
         assert np.allclose(v.numpy(), got[0][k], rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_agents,obs_dim,agent_id,rows_b", [(6, 26, True, 37), (22, 58, True, 129), (38, 82, True, 64), (22, 58, False, 5)])
+def test_fused_policy_forward_matches_pytorch(n_agents, obs_dim, agent_id, rows_b, monkeypatch):
+    """mapdn_policy_forward (one HIP launch: fc1 + id column -> LayerNorm -> ReLU -> GRUCell -> fc2, weights in LDS) against
+    the PyTorch modules it replaces in the rollout (agents/rnn_agent.py:5-32 via models/model.py:101-139)"""
+    import torch
+    from mapdn_amd.learner import DDPGNet, make_alg_args
+    torch.manual_seed(0)
+    args = make_alg_args(n_agents, obs_dim, 1, action_scale=0.8, action_bias=0.0, agent_id=agent_id)
+    net = DDPGNet(args, "maddpg").to("cuda:0")
+    with torch.no_grad():
+        for p in net.policy_dicts.parameters():
+            p.add_(0.3 * torch.randn_like(p))                    # non-trivial LayerNorm gains / biases
+    obs = torch.randn(rows_b, n_agents, obs_dim, device="cuda:0")
+    hid = torch.randn(rows_b, n_agents, 64, device="cuda:0")
+    with torch.no_grad():
+        assert net._fused_policy_ok(obs, hid)
+        m1, ls1, h1 = net.policy(obs, hid)
+        monkeypatch.setenv("MAPDN_FUSED_POLICY", "0")
+        assert not net._fused_policy_ok(obs, hid)
+        m0, ls0, h0 = net.policy(obs, hid)
+    assert m1.shape == m0.shape and h1.shape == h0.shape and torch.equal(ls1, ls0)
+    assert (h1 - h0).abs().max().item() < 2e-5 and (m1 - m0).abs().max().item() < 2e-5
+    # with autograd on (training-time forward) the PyTorch modules run
+    monkeypatch.setenv("MAPDN_FUSED_POLICY", "1")
+    assert not net._fused_policy_ok(obs, hid)
