@@ -438,8 +438,9 @@ class PGTrainer:
         env, net, a = self.env, self.behaviour_net, self.args
         B, dv = env.n_envs, self.device
         prefix = "mean_train_" if train else "mean_test_"
+        own = (lambda t: t) if getattr(env, "copy", False) else (lambda t: t.clone())    # copy=True envs already hand out fresh tensors
         obs, _ = env.reset()
-        obs = obs.float().clone()
+        obs = own(obs.float())
         last_hid = net.init_hidden(B)
         avail = env.get_avail_actions().to(dv)
         alive = torch.ones(B, dtype=torch.bool, device=dv)
@@ -454,7 +455,7 @@ class PGTrainer:
                     action, action_pol, _, _, hid = net.get_actions(obs, "test", False, avail, False, last_hid)
                 actual = translate_action(action.squeeze(-1), a.action_scale, a.action_bias)      # util.py:123-132
             reward, done, info = env.step(actual)
-            next_obs = env.get_obs().float().clone()
+            next_obs = own(env.get_obs().float())
             w = alive.double()
             info_sum += (info.double() * w.unsqueeze(-1)).sum(0); rew_sum += (reward.double() * w).sum(); n_alive += w.sum()
             if train:
