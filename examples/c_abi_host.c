@@ -1,6 +1,7 @@
 /* Minimal C host of the C ABI (include/mapdn.h): builds a 5-bus radial feeder, creates a host-only handle
  * (device == -1: plan only, no GPU needed), and prints what any FFI binding would read back — dimensions,
- * the per-unit Ybus the library built and the elimination schedule of the Newton-Raphson kernel.
+ * the per-unit Ybus the library built and the elimination schedule of the Newton-Raphson kernel; then closes a
+ * tie line (meshed net) and reads back the general sparse solver's program.
  * With a GPU, pass a device index instead of -1 and continue with mapdn_set_profiles / mapdn_reset /
  * mapdn_step as INTEGRATION.md shows.
  *
@@ -65,5 +66,27 @@ int main(void) {
   rc = mapdn_reset(h, NULL, 1, 3, NULL);
   printf("mapdn_reset on a host-only handle -> %d (%s)\n", rc, mapdn_last_error(h));
   mapdn_destroy(h);
-  return rc == MAPDN_E_STATE ? 0 : 6;
+  if (rc != MAPDN_E_STATE) return 6;
+
+  /* close a tie line 3-4: the net is meshed now and takes the general sparse solver, whose elimination program (minimum
+   * degree order, fill, list-scheduled 2x2 block operations) can be read back like the tree schedule */
+  {
+    const int32_t fb2[5] = {0, 1, 2, 2, 3}, tb2[5] = {1, 2, 3, 4, 4};
+    const double r2[5] = {0.09, 0.49, 0.37, 0.38, 0.5}, x2[5] = {0.05, 0.25, 0.19, 0.19, 0.3}, z5[5] = {0, 0, 0, 0, 0};
+    const double len2[5] = {1, 1, 1, 1, 1};
+    const int32_t par2[5] = {1, 1, 1, 1, 1};
+    const uint8_t on2[5] = {1, 1, 1, 1, 1};
+    int32_t dims[6];
+    net.n_line = 5; net.line_from_bus = fb2; net.line_to_bus = tb2; net.line_r_ohm_per_km = r2; net.line_x_ohm_per_km = x2;
+    net.line_c_nf_per_km = z5; net.line_g_us_per_km = z5; net.line_length_km = len2; net.line_parallel = par2; net.line_in_service = on2;
+    h = NULL;
+    rc = mapdn_create(&net, &cfg, 8, -1, &h);
+    if (rc != MAPDN_OK) { fprintf(stderr, "mapdn_create (meshed): %d %s\n", rc, mapdn_last_error(NULL)); return 7; }
+    if (mapdn_dims(h, &d) != MAPDN_OK || d.is_radial != 0) return 8;
+    if (mapdn_get_sparse_program(h, 8, dims, NULL, NULL, NULL) != MAPDN_OK) return 9;
+    printf("meshed (tie 3-4 closed): radial %d; sparse program for 8 sub-lanes: %d block slots, %d fill, %d phases\n",
+           d.is_radial, dims[0], dims[1], dims[2]);
+    mapdn_destroy(h);
+  }
+  return 0;
 }
