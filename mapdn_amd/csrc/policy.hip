@@ -171,11 +171,8 @@ extern "C" int mapdn_policy_forward(const float* obs, const float* hid_in, const
   const int kc1 = (obs_dim + 15) / 16;
   const size_t lds = ((size_t)4 * kc1 * 64 + 2 * 12 * 4 * 64) * 16 + ((size_t)id_dim * PH + 4 * PH + 2 * 3 * PH + 4 * 16 * 68) * sizeof(float);
   if (lds > 160 * 1024) return MAPDN_E_INVALID;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)k_policy_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MAPDN_E_HIP;
-    attr = true;
-  }
+  // (per call, not once per process: the attribute belongs to the current device)
+  if (hipFuncSetAttribute((const void*)k_policy_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MAPDN_E_HIP;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int tiles = (rows + 15) / 16;
