@@ -239,6 +239,18 @@ __device__ __forceinline__ void bst2(d2 x, __amdgpu_buffer_rsrc_t r, unsigned vo
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), r, voff, soff, 0);
 }
 
+// max over the four 16-lane rows of a wavefront, per column (lane & 15), every lane receiving the result: with 16 envs per
+// workgroup the rows are the wave's four workers, so this is the per-env reduction over them — two gfx950 row swaps
+// (v_permlane16_swap / v_permlane32_swap, VALU rate) per dword instead of an LDS round trip
+__device__ __forceinline__ double rows_max(double v) {
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  u32x2 a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double m = fmax(__hiloint2double((int)b.x, (int)a.x), __hiloint2double((int)b.y, (int)a.y));
+  lo = (unsigned)__double2loint(m); hi = (unsigned)__double2hiint(m);
+  a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false); b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return fmax(__hiloint2double((int)b.x, (int)a.x), __hiloint2double((int)b.y, (int)a.y));
+}
+
 struct Rec { u32x4 ix; d2 ykk, ykp, ypk, cks, sb; };    // per-(worker,row) constants + the env's scheduled injection
 struct RecF { u32x4 ix; d2 s, i01, i23, ap, sb; };      // flat-start form: host-factorised constants (Schedule::flat)
 struct BwdF { d2 h, g01, g23; };                        // factors of one step when they come from global memory
@@ -698,7 +710,17 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     if (first) fwd_sweep_flat();
     else if (light) fwd_sweep(std::integral_constant<int, 1>{});
     else fwd_sweep(std::integral_constant<int, 0>{});
-    {                                            // AND of the workers' verdicts, per env
+    if constexpr (L == 16) {                     // AND of the workers' verdicts, per env: in the wave by row swaps, across
+      fmx = rows_max(fmx);                       // the W waves through W LDS entries (instead of Wt)
+      allok = rows_max(allok ? 0.0 : 1.0) == 0.0;
+      if (W > 1) {
+        s_ok[w * L + el] = allok ? 1 : 0;
+        s_dx[(size_t)w * L] = fmx;               // (free here: the step sizes it holds were consumed before this sweep)
+        lds_barrier();
+#pragma unroll
+        for (unsigned ww = 0; ww < (unsigned)W; ++ww) { allok = allok && (s_ok[ww * L + el] != 0); fmx = fmax(fmx, s_dx[(size_t)ww * L]); }
+      }
+    } else {
       s_ok[t * L + el] = allok ? 1 : 0;
       s_dx[(size_t)t * L] = fmx;                 // (free here: the step sizes it holds were consumed before this sweep)
       if (W > 1) lds_barrier();
@@ -727,10 +749,20 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     first = false;
     if (!done) ++it;
     {                                            // size of the step just taken, per env: max over the workers
-      s_dx[(size_t)t * L] = dxm;
-      if (W > 1) lds_barrier();
       double dxe = 0.0;
-      for (unsigned tt = 0; tt < Wt; ++tt) dxe = fmax(dxe, s_dx[(size_t)tt * L]);
+      if constexpr (L == 16) {
+        dxe = rows_max(dxm);
+        if (W > 1) {
+          s_dx[(size_t)w * L] = dxe;
+          lds_barrier();
+#pragma unroll
+          for (unsigned ww = 0; ww < (unsigned)W; ++ww) dxe = fmax(dxe, s_dx[(size_t)ww * L]);
+        }
+      } else {
+        s_dx[(size_t)t * L] = dxm;
+        if (W > 1) lds_barrier();
+        for (unsigned tt = 0; tt < Wt; ++tt) dxe = fmax(dxe, s_dx[(size_t)tt * L]);
+      }
       // convergence is predicted from a tiny step, or — scale-free — from quadratic convergence of the mismatch:
       // ||F_next|| ~ ||F||^3 / ||F_prev||^2 (two sweeps of history needed)
       const bool quad = it >= 2 && Fcur * Fcur * Fcur * d.nr_check_quad < tol * Fprev * Fprev;
