@@ -858,3 +858,42 @@ def test_fused_step_obs_equals_step_then_get_obs(case, obs_dtype):
     # a second get_obs with another dtype still launches its own gather
     assert torch.allclose(fused.get_obs(torch.float64).float(), fused.get_obs(torch.float32), rtol=1e-6, atol=1e-6)
     fused.close(); plain.close()
+
+
+@pytest.mark.parametrize("case,geoms", [
+    ("case141", [("4", "16", None), ("2", "16", "1"), ("2", "16", "0"), ("1", "8", "1"), ("4", "8", None), ("8", "16", "1"), ("1", "32", "1"), ("2", "32", "1")]),
+    ("case33", [("1", "16", None), ("2", "16", None), ("1", "8", None), ("4", "32", None)]),
+    ("case322", [("4", "8", None), ("2", "8", "1"), ("4", "16", "1")]),
+])
+def test_every_nr_launch_geometry_gives_the_same_bits(case, geoms, monkeypatch):
+    """MAPDN_NR_WAVES / MAPDN_NR_LANES / MAPDN_NR_LEAN overrides: every (waves, envs per workgroup, LDS residency) variant
+    of k_nr_tree — the specialised default instantiations, the generic ones, both per-env reduction paths (row swaps at 16
+    envs per workgroup, LDS elsewhere) — sums the children in the same canonical order, so voltages, angles and iteration
+    counts are bit-identical"""
+    B = 200
+    net, prof = make_case(case)
+    rng = np.random.default_rng(11)
+    rows = rng.integers(0, prof.n_rows, B)
+    pv = prof.pv[rows]
+    qs = rng.uniform(-SCALE[case], SCALE[case], (B, net.n_sgen)) * np.sqrt(prof.s_max() ** 2 - pv ** 2)
+    ins = (prof.load_p[rows], prof.load_q[rows], pv, qs)
+    ref = None
+    for w, l, lean in geoms:
+        monkeypatch.setenv("MAPDN_NR_WAVES", w); monkeypatch.setenv("MAPDN_NR_LANES", l)
+        if lean is None:
+            monkeypatch.delenv("MAPDN_NR_LEAN", raising=False)
+        else:
+            monkeypatch.setenv("MAPDN_NR_LEAN", lean)
+        try:
+            env = VoltageControlBatch(net, prof, args_for(case), n_envs=B, device="cuda:0")
+        except Exception as exc:                              # a geometry whose LDS need exceeds a CU is refused, not wrong
+            assert "LDS" in str(exc), exc
+            continue
+        out = [t.cpu().numpy() for t in env.solve(*ins)]
+        env.close()
+        assert out[3].all()
+        if ref is None:
+            ref = out
+        else:
+            assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2]), (w, l, lean)
+    assert ref is not None
