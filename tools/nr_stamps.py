@@ -9,6 +9,7 @@ from mapdn_amd.env import VoltageControlBatch
 from mapdn_amd.netspec import make_case
 ap = argparse.ArgumentParser(); ap.add_argument("--case", default="case141"); ap.add_argument("--envs", type=int, default=4096)
 ap.add_argument("--rows", action="store_true")
+ap.add_argument("--step", action="store_true", help="stamp a step() launch (with the fused reward / commit epilogue) instead of solve-only")
 a = ap.parse_args()
 net, prof = make_case(a.case)
 scale = {"case33": 0.8, "case141": 0.6, "case322": 0.8}[a.case]
@@ -18,10 +19,18 @@ rows = rng.integers(0, prof.n_rows, a.envs)
 pv = prof.pv[rows]
 qs = rng.uniform(-scale, scale, (a.envs, net.n_sgen)) * np.sqrt(prof.s_max() ** 2 - pv ** 2)
 ins = [torch.as_tensor(x, device="cuda:0") for x in (prof.load_p[rows], prof.load_q[rows], pv, qs)]
-for _ in range(3):
-    vm, va, it, cv = env.solve(*ins)         # MODE_SOLVE: every env active, fixed inputs
-torch.cuda.synchronize()
-print("iters mean", it.float().mean().item(), "conv", cv.float().mean().item())
+if a.step:
+    env.reset()
+    act = torch.as_tensor(rng.uniform(-scale, scale, (a.envs, net.n_sgen)), device="cuda:0")
+    for _ in range(3):
+        env.step(act)                        # MODE_STEP: solve + epilogue
+    torch.cuda.synchronize()
+    print("step mode", env.stats())
+else:
+    for _ in range(3):
+        vm, va, it, cv = env.solve(*ins)         # MODE_SOLVE: every env active, fixed inputs
+    torch.cuda.synchronize()
+    print("iters mean", it.float().mean().item(), "conv", cv.float().mean().item())
 lib = _lib.load()
 out = (ctypes.c_ulonglong * 4096)()
 assert lib.mapdn_debug_stamps(out, 4096) == 0
