@@ -34,42 +34,45 @@ __device__ __forceinline__ float row_sum16(float v) {
 // column l & 15.  The k index of MFMA step s of chunk c is 16 c + 4 (l >> 4) + s for BOTH operands, so a lane's four steps of
 // a chunk are 16 contiguous bytes: one b128 load per operand and chunk.  Weights are staged ONCE per workgroup in LDS in
 // exactly that operand order (Wop[n-tile][chunk][lane] = 4 floats), weight-stationary.
-__global__ void __launch_bounds__(256)
+// PT threads per workgroup: 512 (8 waves = two per SIMD, one wave's MFMA phase overlaps another's VALU / memory phase) when the
+// activation tiles of 8 waves still fit beside the parameters in LDS, else 256
+template <int PT>
+__global__ void __launch_bounds__(PT)
 k_policy_fwd(const float* __restrict__ obs, const float* __restrict__ hid_in, const float* __restrict__ w1, const float* __restrict__ b1,
              const float* __restrict__ ln_g, const float* __restrict__ ln_b, const float* __restrict__ w_ih, const float* __restrict__ w_hh,
              const float* __restrict__ b_ih, const float* __restrict__ b_hh, const float* __restrict__ w2, const float* __restrict__ b2,
-             float* __restrict__ means, float* __restrict__ hid_out, int rows, int n_agents, int o, int ids, float ln_eps) {
+             float* __restrict__ means, float* __restrict__ hid_out, int rows, int n_agents, int o, int ids, float ln_eps, int ids_lds) {
   extern __shared__ float sm[];
   const int KC1 = (o + 15) >> 4;                                  // 16-wide k chunks of fc1 (zero-padded weights)
   f4* sW1 = (f4*)sm;                                              // [4][KC1][64]
   f4* sWih = sW1 + (size_t)4 * KC1 * 64;                          // [12][4][64]
   f4* sWhh = sWih + 12 * 4 * 64;                                  // [12][4][64]
   float* sW1id = (float*)(sWhh + 12 * 4 * 64);                    // [ids][64]
-  float* sB1 = sW1id + (size_t)ids * PH;
+  float* sB1 = sW1id + (size_t)(ids_lds ? ids : 0) * PH;      // (the id columns stay in global memory when LDS is short: 8 waves matter more)
   float* sG = sB1 + PH; float* sB = sG + PH;
   float* sBih = sB + PH; float* sBhh = sBih + 3 * PH; float* sW2 = sBhh + 3 * PH;
-  float* sX = sW2 + PH;                                           // [4 waves][16][68]: C layout -> A layout of the activations
+  float* sX = sW2 + PH;                                           // [PT / 64 waves][16][68]: C layout -> A layout of the activations
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15, in1 = o + ids;
-  for (int i = tid; i < 4 * KC1 * 64; i += 256) {
+  for (int i = tid; i < 4 * KC1 * 64; i += PT) {
     const int l = i & 63, c = (i >> 6) % KC1, nt = (i >> 6) / KC1;
     f4 v;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int k = 16 * c + 4 * (l >> 4) + q; v[q] = k < o ? w1[(size_t)(16 * nt + (l & 15)) * in1 + k] : 0.0f; }
     sW1[i] = v;
   }
-  for (int i = tid; i < 12 * 4 * 64; i += 256) {
+  for (int i = tid; i < 12 * 4 * 64; i += PT) {
     const int l = i & 63, c = (i >> 6) & 3, nt = i >> 8;
     const size_t base = (size_t)(16 * nt + (l & 15)) * PH + 16 * c + 4 * (l >> 4);
     sWih[i] = *(const f4*)(w_ih + base); sWhh[i] = *(const f4*)(w_hh + base);
   }
-  for (int i = tid; i < ids * PH; i += 256) sW1id[i] = w1[(size_t)(i % PH) * in1 + o + i / PH];      // [agent][unit]
-  for (int i = tid; i < PH; i += 256) { sB1[i] = b1[i]; sG[i] = ln_g[i]; sB[i] = ln_b[i]; sW2[i] = w2[i]; }
-  for (int i = tid; i < 3 * PH; i += 256) { sBih[i] = b_ih[i]; sBhh[i] = b_hh[i]; }
+  if (ids_lds) for (int i = tid; i < ids * PH; i += PT) sW1id[i] = w1[(size_t)(i % PH) * in1 + o + i / PH];      // [agent][unit]
+  for (int i = tid; i < PH; i += PT) { sB1[i] = b1[i]; sG[i] = ln_g[i]; sB[i] = ln_b[i]; sW2[i] = w2[i]; }
+  for (int i = tid; i < 3 * PH; i += PT) { sBih[i] = b_ih[i]; sBhh[i] = b_hh[i]; }
   __syncthreads();
   float* xt = sX + (size_t)wave * 16 * 68;
   const float bias2 = b2[0];
   const int n_tiles = (rows + 15) >> 4;
-  for (int T = blockIdx.x * 4 + wave; T < n_tiles; T += gridDim.x * 4) {
+  for (int T = blockIdx.x * (PT / 64) + wave; T < n_tiles; T += gridDim.x * (PT / 64)) {
     const int row0 = T << 4;
     const int arow = min(row0 + j, rows - 1);                     // the row this lane feeds as A operand
     // ---- fc1: X1[16 x 64] = obs[16 x o] W1^T
@@ -96,7 +99,7 @@ k_policy_fwd(const float* __restrict__ obs, const float* __restrict__ hid_in, co
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const int u = 16 * nt + j;
-        acc[nt][r] += sB1[u] + (ids ? sW1id[(size_t)agent * PH + u] : 0.0f);
+        acc[nt][r] += sB1[u] + (ids ? (ids_lds ? sW1id[(size_t)agent * PH + u] : w1[(size_t)u * in1 + o + agent]) : 0.0f);
         sum += acc[nt][r];
       }
       mean[r] = row_sum16(sum) * (1.0f / PH);
@@ -169,15 +172,23 @@ extern "C" int mapdn_policy_forward(const float* obs, const float* hid_in, const
   using namespace mapdn;
   if (!obs || !hid_in || !w1 || !means || !hid_out || rows < 1 || n_agents < 1 || obs_dim < 1 || id_dim < 0) return MAPDN_E_INVALID;
   const int kc1 = (obs_dim + 15) / 16;
-  const size_t lds = ((size_t)4 * kc1 * 64 + 2 * 12 * 4 * 64) * 16 + ((size_t)id_dim * PH + 4 * PH + 2 * 3 * PH + 4 * 16 * 68) * sizeof(float);
+  auto lds_for = [&](int pt, int il) { return ((size_t)4 * kc1 * 64 + 2 * 12 * 4 * 64) * 16 + ((size_t)(il ? id_dim : 0) * PH + 4 * PH + 2 * 3 * PH + (pt / 64) * 16 * 68) * sizeof(float); };
+  int pt = 512, ids_lds = 1;
+  if (lds_for(512, 1) > 160 * 1024) { if (lds_for(512, 0) <= 160 * 1024) ids_lds = 0; else pt = 256; }
+  const size_t lds = lds_for(pt, ids_lds);
   if (lds > 160 * 1024) return MAPDN_E_INVALID;
   // (per call, not once per process: the attribute belongs to the current device)
-  if (hipFuncSetAttribute((const void*)k_policy_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MAPDN_E_HIP;
+  const void* fn = pt == 512 ? (const void*)k_policy_fwd<512> : (const void*)k_policy_fwd<256>;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MAPDN_E_HIP;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int tiles = (rows + 15) / 16;
-  const int blocks = std::min((tiles + 3) / 4, cus);              // one resident workgroup per CU (its LDS is the parameter set)
-  hipLaunchKernelGGL(k_policy_fwd, dim3(blocks), dim3(256), lds, (hipStream_t)stream, obs, hid_in, w1, b1, ln_g, ln_b, w_ih, w_hh,
-                     b_ih, b_hh, w2, b2, means, hid_out, rows, n_agents, obs_dim, id_dim, ln_eps);
+  const int blocks = std::min((tiles + pt / 64 - 1) / (pt / 64), cus);   // one resident workgroup per CU (its LDS is the parameter set)
+  if (pt == 512)
+    hipLaunchKernelGGL(k_policy_fwd<512>, dim3(blocks), dim3(512), lds, (hipStream_t)stream, obs, hid_in, w1, b1, ln_g, ln_b, w_ih, w_hh,
+                       b_ih, b_hh, w2, b2, means, hid_out, rows, n_agents, obs_dim, id_dim, ln_eps, ids_lds);
+  else
+    hipLaunchKernelGGL(k_policy_fwd<256>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, obs, hid_in, w1, b1, ln_g, ln_b, w_ih, w_hh,
+                       b_ih, b_hh, w2, b2, means, hid_out, rows, n_agents, obs_dim, id_dim, ln_eps, ids_lds);
   return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
 }
