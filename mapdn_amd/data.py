@@ -146,6 +146,7 @@ def from_pandapower(net) -> NetSpec:
     """pandapowerNet (`pp.from_pickle(model.p)`, voltage_control_env.py:400-405) -> NetSpec: what pd2ppc would build for
     runpp's defaults.  Converted: buses (0..n-1, all in service), lines (line switches: an OPEN switch takes the line
     out, as pandapower does), two-winding transformers (trafo_to_pi), loads / sgens with `scaling` and `in_service`,
+    non-consecutive bus indices (mapped to the positions of the sorted index, pd2ppc's bus lookup),
     shunts (step, in_service), one ext_grid.  Refused loudly, never guessed: voltage-dependent loads
     (const_z_percent / const_i_percent: the constant-Z share would be a time-varying shunt), closed bus-bus switches
     (bus fusion), generators, three-winding transformers, impedances, wards, dc lines, storage."""
@@ -160,8 +161,13 @@ def from_pandapower(net) -> NetSpec:
         raise NotImplementedError("exactly one in-service ext_grid expected")
     bus = net.bus.sort_index()
     bus_index = bus.index.to_numpy()
-    if not np.array_equal(bus_index, np.arange(len(bus_index))):
-        raise NotImplementedError("bus indices must be 0..n-1")
+    # pandapower bus indices -> consecutive positions of the sorted index (pd2ppc's bus lookup; the env reads every
+    # result table through `.sort_index()`, voltage_control_env.py:219,370,536,584, so sorted order is its bus order too)
+    if np.array_equal(bus_index, np.arange(len(bus_index))):
+        rb = lambda a: np.asarray(a, dtype=np.int64)
+    else:
+        lut = {int(b): i for i, b in enumerate(bus_index)}
+        rb = lambda a: np.array([lut[int(x)] for x in np.asarray(a)], dtype=np.int64)
     if "in_service" in bus and not bus["in_service"].to_numpy(bool).all():
         raise NotImplementedError("out-of-service buses are not converted")
     vn = bus["vn_kv"].to_numpy(np.float64)
@@ -193,31 +199,32 @@ def from_pandapower(net) -> NetSpec:
     kw = dict(
         name=str(net["name"] if "name" in net and net["name"] else "net"), bus_vn_kv=vn,
         bus_zone=np.array([zid(z) for z in bus["zone"].to_numpy()]),
-        line_from_bus=line["from_bus"].to_numpy(), line_to_bus=line["to_bus"].to_numpy(),
+        line_from_bus=rb(line["from_bus"].to_numpy()), line_to_bus=rb(line["to_bus"].to_numpy()),
         line_r_ohm_per_km=line["r_ohm_per_km"].to_numpy(), line_x_ohm_per_km=line["x_ohm_per_km"].to_numpy(),
         line_c_nf_per_km=line["c_nf_per_km"].to_numpy(), line_g_us_per_km=_col(line, "g_us_per_km", 0.0),
         line_length_km=line["length_km"].to_numpy(), line_parallel=line["parallel"].to_numpy(),
         line_in_service=line_on.astype(np.uint8),
-        load_bus=load["bus"].to_numpy(), sgen_bus=sgen["bus"].to_numpy(),
+        load_bus=rb(load["bus"].to_numpy()), sgen_bus=rb(sgen["bus"].to_numpy()),
         sgen_zone=np.array([zid(z) for z in sgen["name"].to_numpy()]),
         load_scaling=_col(load, "scaling", 1.0) * on(load), sgen_scaling=_col(sgen, "scaling", 1.0) * on(sgen),
-        ext_grid_bus=int(net.ext_grid["bus"].iloc[0]), ext_grid_vm_pu=float(net.ext_grid["vm_pu"].iloc[0]),
+        ext_grid_bus=int(rb([net.ext_grid["bus"].iloc[0]])[0]), ext_grid_vm_pu=float(net.ext_grid["vm_pu"].iloc[0]),
         sn_mva=float(net.sn_mva), f_hz=float(net.f_hz))
     if trafo is not None:
         t = trafo.sort_index().copy()
         t["in_service"] = trafo_on
+        t["hv_bus"] = rb(t["hv_bus"].to_numpy()); t["lv_bus"] = rb(t["lv_bus"].to_numpy())
         # runpp calculate_voltage_angles="auto": True only if a line touches a bus above 70 kV
         hv_buses = set(np.nonzero(vn > 70.0)[0].tolist())
-        touched = set(line["from_bus"].to_numpy().tolist()) | set(line["to_bus"].to_numpy().tolist())
+        touched = set(rb(line["from_bus"].to_numpy()).tolist()) | set(rb(line["to_bus"].to_numpy()).tolist())
         kw.update(trafo_to_pi(t, vn, float(net.sn_mva), calculate_voltage_angles=bool(hv_buses & touched)))
     sh = table("shunt")
     if sh is not None:
         # build_bus._calc_shunts_and_add_on_ppc: p, q per step, referred from the shunt's vn_kv to the bus voltage
-        vn_bus = vn[sh["bus"].to_numpy(np.int64)]
+        vn_bus = vn[rb(sh["bus"].to_numpy())]
         vn_sh = _col(sh, "vn_kv", np.nan)
         vn_sh = np.where(np.isnan(vn_sh), vn_bus, vn_sh)
         f = on(sh) * _col(sh, "step", 1.0) * np.square(vn_bus / vn_sh)
-        kw.update(shunt_bus=sh["bus"].to_numpy(), shunt_p_mw=sh["p_mw"].to_numpy(np.float64) * f,
+        kw.update(shunt_bus=rb(sh["bus"].to_numpy()), shunt_p_mw=sh["p_mw"].to_numpy(np.float64) * f,
                   shunt_q_mvar=sh["q_mvar"].to_numpy(np.float64) * f)
     return NetSpec(**kw)
 

@@ -206,3 +206,26 @@ def test_env_on_the_converted_substation_net_matches_the_oracle_env():
             assert np.abs(res["p_mw"][e].cpu().numpy() - o.res.p_mw).max() < 1e-9
             assert np.abs(np.array(o.get_obs()) - obs[e].cpu().numpy()).max() < 1e-9
     env.close()
+
+
+def test_non_consecutive_bus_indices_are_mapped_to_sorted_positions():
+    """pandapower bus indices need not be 0..n-1 (pd2ppc maps them through a lookup; the env reads results via sort_index)"""
+    ref = from_pandapower(substation_net())
+    pnet = substation_net()
+    new = np.array([40, 3, 17, 25, 8, 99])                      # old bus i -> new label new[i]
+    order = np.argsort(new)                                      # sorted label order = position order
+    pnet["bus"].index = new
+    for tab, cols in (("line", ("from_bus", "to_bus")), ("load", ("bus",)), ("sgen", ("bus",)), ("ext_grid", ("bus",)),
+                      ("trafo", ("hv_bus", "lv_bus")), ("shunt", ("bus",)), ("switch", ("bus",))):
+        for c in cols:
+            pnet[tab][c] = new[pnet[tab][c].to_numpy()]
+    got = from_pandapower(pnet)
+    pos = np.empty(6, np.int64); pos[order] = np.arange(6)       # old bus i sits at position pos[i]
+    assert np.array_equal(got.line_from_bus, pos[ref.line_from_bus]) and np.array_equal(got.line_to_bus, pos[ref.line_to_bus])
+    assert np.array_equal(got.load_bus, pos[ref.load_bus]) and np.array_equal(got.sgen_bus, pos[ref.sgen_bus])
+    assert got.ext_grid_bus == pos[ref.ext_grid_bus] and np.array_equal(got.br_from_bus, pos[ref.br_from_bus])
+    assert np.array_equal(got.bus_vn_kv, ref.bus_vn_kv[order]) and np.array_equal(got.bus_zone, ref.bus_zone[order])
+    pl, ql = pnet.load["p_mw"].to_numpy(), pnet.load["q_mvar"].to_numpy()
+    ps, qs = pnet.sgen["p_mw"].to_numpy(), pnet.sgen["q_mvar"].to_numpy()
+    ra, rb = runpp_restated(ref, pl, ql, ps, qs), runpp_restated(got, pl, ql, ps, qs)
+    assert np.abs(ra.vm_pu[order] - rb.vm_pu).max() < 1e-12      # same physics, buses reported in sorted-label order
