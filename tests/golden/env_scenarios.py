@@ -21,6 +21,12 @@ SCENARIOS = {
     "c33_scaled": ("case33", dict(voltage_barrier_type="bowl", pv_scale=0.8, demand_scale=1.15, action_bias=0.1, action_scale=0.7), (2, 12, 9), 4, False, False),
     "c33_noisy": ("case33", dict(voltage_barrier_type="bowl", reset_action=True, seed=7), (3, 12, 4), 6, False, True),
     "c141_bowl": ("case141", dict(voltage_barrier_type="bowl", action_scale=0.6), (4, 12, 10), 8, True, False),
+    # round 3: the zone / obs padding logic (:246-274) at 22 agents / 9 zones and 38 agents / 22 zones, history stacking at the
+    # widest obs, and the reference's own MT19937 noise on the 141-bus net
+    "c141_l2": ("case141", dict(voltage_barrier_type="l2", action_scale=0.6), (6, 11, 14), 5, False, False),
+    "c141_noisy": ("case141", dict(voltage_barrier_type="bowl", action_scale=0.6, reset_action=True, seed=11), (1, 12, 6), 5, False, True),
+    "c322_bowl": ("case322", dict(voltage_barrier_type="bowl"), (3, 12, 2), 6, True, False),
+    "c322_hist3": ("case322", dict(voltage_barrier_type="l1", history=3), (5, 13, 17), 5, False, False),
 }
 DIGITS = 12     # profile tables are quantised to this many significant digits so that every CSV parser reads them exactly
 

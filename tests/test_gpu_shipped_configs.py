@@ -1,0 +1,95 @@
+"""GPU (-m gpu): the SHIPPED launch of every BASELINE.json configuration, oracle-checked at its own size.
+
+`choose_nr_geometry` (csrc/capi.hip) picks the NR launch (waves, envs per workgroup, LDS residency) from the case and the
+batch size, so a geometry is only exercised by a batch of that size.  For each (case, envs per GPU) that BASELINE.json
+names — case33 x 4096, case141 x 4096, case322 x 1024 (8192 over 8 GPUs), case322 x 4096, case322 x 8192 (65536 over 8) —
+with NO geometry override:
+
+  * 64 strided envs (one per 64-env stride, so every workgroup row of lanes is hit) are replayed on the CPU oracle for
+    9 noisy calls that contain a forced unsolvable step (voltage_control_env.py:188-196), the episode-limit boundary and
+    the per-env auto-reset that follows both (the reference loop's reset() right after `done`, models/model.py:204-262);
+    reward / terminated / 11 info values / obs / bus voltages <= 1e-9, NR iteration counts of the final call exact;
+  * env g inside the big batch is bit-identical to a B = 1 handle with env_id_offset = g (a different launch geometry,
+    the same global id): results do not depend on the batch an env sits in.
+"""
+import numpy as np
+import pytest
+import torch
+
+from mapdn_amd.env import VoltageControlBatch
+from mapdn_amd.netspec import make_case
+from oracle.env_restated import INFO_KEYS, VoltageControlOracle
+
+pytestmark = pytest.mark.gpu
+
+SCALE = {"case33": 0.8, "case141": 0.6, "case322": 0.8}     # train.py:34-42
+CONFIGS = [("case33", 4096), ("case141", 4096), ("case322", 1024), ("case322", 4096), ("case322", 8192)]
+LIMIT = 6            # episode_limit: every env hits the limit at call 4 (steps starts at 1, :100) and restarts at call 5
+N_CALLS = 9
+GEOMETRY_VARS = ("MAPDN_NR_WAVES", "MAPDN_NR_LANES", "MAPDN_NR_LEAN", "MAPDN_NR_SPARSE", "MAPDN_NR_DENSE",
+                 "MAPDN_NR_REC_LDS", "MAPDN_NR_FLAT_LDS", "MAPDN_NR_G_LDS")
+
+
+def _args(case):
+    return dict(episode_limit=LIMIT, action_scale=SCALE[case], action_bias=0.0, voltage_barrier_type="bowl", seed=3)
+
+
+@pytest.mark.parametrize("case,B", CONFIGS)
+def test_default_launch_matches_oracle_at_full_size(case, B, monkeypatch):
+    for v in GEOMETRY_VARS:
+        monkeypatch.delenv(v, raising=False)
+    net, prof = make_case(case)
+    env = VoltageControlBatch(net, prof, dict(_args(case), auto_reset=True), n_envs=B, device="cuda:0", obs_dtype=torch.float64)
+    watch = list(range(7, B, B // 64))[:64]
+    assert len(watch) == 64
+    bad_env = watch[9]                                   # forced unsolvable at call 2 -> restarts at call 3
+    oracles = {e: VoltageControlOracle(net, prof, _args(case), env_id=e, do_reset=False) for e in watch}
+    obs, _ = env.reset()
+    assert env.stats()["reset_failures"] == 0
+    obs = obs.cpu().numpy()
+    for e, o in oracles.items():
+        oo, _ = o.reset()
+        assert np.abs(np.array(oo) - obs[e]).max() < 1e-9
+    # the same global ids as single-env handles (another geometry): bit-identical trajectories
+    twins = {g: VoltageControlBatch(net, prof, dict(_args(case), auto_reset=True), n_envs=1, device="cuda:0", env_id_offset=g,
+                                    obs_dtype=torch.float64) for g in (watch[0], bad_env, watch[-1])}
+    for g, tw in twins.items():
+        o1, _ = tw.reset()
+        assert torch.equal(o1[0], torch.as_tensor(obs[g], device="cuda:0"))
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(17)
+    pending = {e: False for e in watch}
+    n_term = {e: 0 for e in watch}
+    for t in range(N_CALLS):
+        act = (torch.rand(B, net.n_sgen, device="cuda:0", generator=gen, dtype=torch.float64) * 2 - 1) * SCALE[case]
+        if t == 2:
+            act[bad_env] = 60.0
+        r, term, info = env.step(act)
+        obs = env.get_obs()
+        vm = env.results(("vm_pu",))["vm_pu"]
+        mask = env.auto_reset_mask().cpu().numpy()
+        for g, tw in twins.items():
+            r1, t1, i1 = tw.step(act[g:g + 1])
+            assert torch.equal(r1[0], r[g]) and torch.equal(t1[0], term[g]) and torch.equal(i1[0], info[g]), (t, g)
+            assert torch.equal(tw.get_obs()[0], obs[g]), (t, g)
+        acpu, rcpu, tcpu, icpu, ocpu, vcpu = act.cpu().numpy(), r.cpu().numpy(), term.cpu().numpy(), info.cpu().numpy(), obs.cpu().numpy(), vm.cpu().numpy()
+        for e, o in oracles.items():
+            if pending[e]:                               # this call was the env's reset()
+                assert mask[e] and rcpu[e] == 0.0 and not tcpu[e] and (icpu[e] == 0).all(), (t, e)
+                oo, _ = o.reset()
+                assert np.abs(np.array(oo) - ocpu[e]).max() < 1e-9, (t, e)
+                pending[e] = False
+                continue
+            assert not mask[e]
+            ro, to, io = o.step(acpu[e])
+            assert abs(ro - rcpu[e]) < 1e-9 and to == bool(tcpu[e]), (t, e, ro, rcpu[e])
+            assert max(abs(io[k] - icpu[e, c]) for c, k in enumerate(INFO_KEYS)) < 1e-9, (t, e)
+            assert np.abs(vcpu[e] - o.res.vm_pu).max() < 1e-9, (t, e)
+            assert np.abs(np.array(o.get_obs()) - ocpu[e]).max() < 1e-9, (t, e)
+            if to:
+                pending[e] = True; n_term[e] += 1
+    assert n_term[bad_env] == 2 and all(n == 1 for e, n in n_term.items() if e != bad_env)
+    st = env.stats()
+    assert st["reset_failures"] == 0 and st["max_nr_iters"] <= 6
+    env.close()
+    for tw in twins.values():
+        tw.close()
