@@ -472,6 +472,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
           load_rec(min(r + 2, R - 1), Tq[(u + 2) % 3]);
         }
         SCHED_FENCE();
+        STAMP2(200 + 10 * K);
         // (2) shadow: previous row's bookkeeping; this row's child-independent part
         //     A_kp = V_k conj(Y_kp V_p), A_pk = V_p conj(Y_pk V_k), A_kk = |V_k|^2 conj(Y_kk), A_ks = V_k conj(Y_k,slack V_slack)
         note_mismatch(pFp, pFq, pLive);
@@ -488,6 +489,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const double base_r = (akk_r + aks_r) + akp_r, base_i = (akk_i + aks_i) + akp_i;
         const double m = (fl & S_CARRY_IN) ? 1.0 : 0.0;    // register carry (same worker, previous row) masked by a 0/1 factor
         SCHED_FENCE();
+        STAMP2(201 + 10 * K);
         // (3) the dependent chain: children (carry + LDS slots, canonical order) -> S, mismatch -> pivot -> factors -> contribution
         double aS0, aS1, aD0 = 0.0, aD1 = 0.0, aD2 = 0.0, aD3 = 0.0, aR0 = 0.0, aR1 = 0.0;
         if (gmax == 0u) {
@@ -554,6 +556,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
           cS0 = apk_r; cS1 = apk_i;
           if (flu & SU_W_ANY) cs[(size_t)(slots & 1023u) * (4 * L)] = d2{apk_r, apk_i};
         }
+        STAMP2(202 + 10 * K);
         if (W > 1) lds_barrier();
         STAMP(100 + K);
         ++r;
@@ -581,6 +584,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         if (gmax >= 2u) g1 = cs[((size_t)((chs >> 10) & 1023u) * 4 + 3) * L];
         load_recf(min(r + 2, R - 1), Tq[(u + 2) % 3]);
         SCHED_FENCE();
+        STAMP2(230);
         const double Fp = T.s.x - T.sb.x, Fq = T.s.y - T.sb.y;       // shadow: the flat-start mismatch does not depend on children
         note_mismatch(Fp, Fq, (fl & S_LIVE) != 0);
         const double m = (fl & S_CARRY_IN) ? 1.0 : 0.0;
@@ -608,6 +612,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         SCHED_FENCE();
         const unsigned k = kp & 0xffffu;
         if (HL) sH[(size_t)k * L] = d2{h0, h1}; else bst2(d2{h0, h1}, rs, voE + k * bb, sF_H);
+        STAMP2(232);
         if (W > 1) lds_barrier();
         STAMP(102);
         ++r;
@@ -676,9 +681,11 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         ixq[(u + 3) % 4] = load_ix(max(r - 3, 0));
         load_f(max(r - 2, 0), ixq[(u + 2) % 4], fq[(u + 2) % 4]);
         SCHED_FENCE();
+        STAMP2(240);
         // (2) shadow: the previous row's voltage update
         apply_update(py0, py1, pvk, pk, pLive);
         SCHED_FENCE();
+        STAMP2(241);
         // (3) x_k = h_k - G_k x_parent
         const bool cout = (fl & S_CARRY_OUT) != 0;
         const double p0 = cout ? x0 : (xr ? q.x : 0.0), p1 = cout ? x1 : (xr ? q.y : 0.0);
@@ -687,6 +694,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         x0 = y0; x1 = y1;
         if (flu & SU_XW_ANY) xs[(size_t)((slots >> 10) & 1023u) * L] = d2{y0, y1};   // TRASH unless S_X_OUT
         py0 = y0; py1 = y1; pvk = vk; pk = k; pLive = (fl & S_LIVE) != 0;
+        STAMP2(242);
         if (W > 1) lds_barrier();
         STAMP(110 + SRC);
         --r;

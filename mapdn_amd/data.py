@@ -144,8 +144,8 @@ def trafo_to_pi(trafo, bus_vn_kv: np.ndarray, net_sn_mva: float, calculate_volta
 
 def from_pandapower(net) -> NetSpec:
     """pandapowerNet (`pp.from_pickle(model.p)`, voltage_control_env.py:400-405) -> NetSpec: what pd2ppc would build for
-    runpp's defaults.  Converted: buses (0..n-1, all in service), lines (line switches: an OPEN switch takes the line
-    out, as pandapower does), two-winding transformers (trafo_to_pi), loads / sgens with `scaling` and `in_service`,
+    runpp's defaults.  Converted: buses (0..n-1, all in service), lines (an open line / trafo switch takes the branch out
+    when that is exact — no shunt terms, or open at both ends — and is refused otherwise), two-winding transformers (trafo_to_pi), loads / sgens with `scaling` and `in_service`,
     non-consecutive bus indices (mapped to the positions of the sorted index, pd2ppc's bus lookup),
     shunts (step, in_service), one ext_grid.  Refused loudly, never guessed: voltage-dependent loads
     (const_z_percent / const_i_percent: the constant-Z share would be a time-varying shunt), closed bus-bus switches
@@ -184,13 +184,32 @@ def from_pandapower(net) -> NetSpec:
         et = sw["et"].to_numpy()
         if np.any((et == "b") & closed):
             raise NotImplementedError("closed bus-bus switches (bus fusion) are not converted")
+        # An OPEN line / trafo switch: runpp's default (neglect_open_switch_branches=False, build_branch._switch_branches)
+        # re-terminates the open end on an auxiliary bus, so the branch stays energised from its closed end and still draws
+        # its charging / magnetising current.  That is the same as taking the branch out ONLY if it has no shunt terms, or
+        # if it is open at both ends; anything else is refused rather than approximated.
+        sw_bus = sw["bus"].to_numpy()
+        el_all = sw["element"].to_numpy()
         pos = {idx: i for i, idx in enumerate(line.index)}
-        for el in sw["element"].to_numpy()[(et == "l") & ~closed]:
-            line_on[pos[int(el)]] = False                       # a line with an open switch at either end carries nothing
+        line_c = line["c_nf_per_km"].to_numpy(np.float64); line_g = _col(line, "g_us_per_km", 0.0)
+        for el in np.unique(el_all[(et == "l") & ~closed]):
+            i = pos[int(el)]
+            ends = set(sw_bus[(et == "l") & ~closed & (el_all == el)].tolist())
+            if len(ends) < 2 and line_on[i] and (line_c[i] != 0.0 or line_g[i] != 0.0):
+                raise NotImplementedError(f"line {int(el)} has an open switch at one end and non-zero c_nf_per_km / g_us_per_km: pandapower keeps "
+                                          "it energised from the closed end (auxiliary bus); not converted")
+            line_on[i] = False
         if trafo is not None:
-            tpos = {idx: i for i, idx in enumerate(trafo.sort_index().index)}
-            for el in sw["element"].to_numpy()[(et == "t") & ~closed]:
-                trafo_on[tpos[int(el)]] = False
+            ts = trafo.sort_index()
+            tpos = {idx: i for i, idx in enumerate(ts.index)}
+            t_i0 = _col(ts, "i0_percent", 0.0); t_pfe = _col(ts, "pfe_kw", 0.0)
+            for el in np.unique(el_all[(et == "t") & ~closed]):
+                i = tpos[int(el)]
+                ends = set(sw_bus[(et == "t") & ~closed & (el_all == el)].tolist())
+                if len(ends) < 2 and trafo_on[i] and (t_i0[i] != 0.0 or t_pfe[i] != 0.0):
+                    raise NotImplementedError(f"trafo {int(el)} has an open switch at one end and a magnetising branch (i0_percent / pfe_kw): "
+                                              "pandapower keeps it energised from the closed end; not converted")
+                trafo_on[i] = False
     load, sgen = net.load, net.sgen
     for col in ("const_z_percent", "const_i_percent"):
         if col in load and np.any(_col(load, col, 0.0) != 0.0):
@@ -229,18 +248,123 @@ def from_pandapower(net) -> NetSpec:
     return NetSpec(**kw)
 
 
+# ------------------------------------------------------------------------------------------------
+# model.p WITHOUT pandapower: a restricted unpickler.
+#
+# `pp.from_pickle(model.p)` (voltage_control_env.py:400-405) reads what pandapower 2.x `to_pickle` wrote: a plain dict
+# net-key -> value, where every table is {"DF": DataFrame.to_dict("split"), "dtypes": {column: numpy dtype}} (io_utils.
+# to_dict_with_coord_transform) and the rest are scalars / dicts (name, f_hz, sn_mva, version, std_types, _options ...).
+# Nets pickled as objects (pickle.dump(net)) carry `pandapower.auxiliary.pandapowerNet` (a dict subclass) holding real
+# pandas DataFrames.  Both forms are data: no pandapower CODE is needed to read them.  The unpickler below resolves only
+#   * numpy's array / dtype / scalar reconstructors and pandas' container classes (pandas.core.*, pandas._libs.*),
+#   * plain builtin containers,
+#   * `pandapower.*` names, which are mapped to INERT stand-ins (a dict subclass for the net, an attribute bag for
+#     anything else, e.g. controller objects inside net.controller) — their code is never imported or run,
+# and refuses every other global (os, subprocess, builtins.eval ...): a pickle is a program, model.p is downloaded data.
+# ------------------------------------------------------------------------------------------------
+class InertNet(dict):
+    """attribute-style dict standing in for pandapower.auxiliary.pandapowerNet / ADict (tables are pandas DataFrames)"""
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError as e:
+            raise AttributeError(name) from e
+
+    def __setstate__(self, state):               # ADict pickles as a dict subclass: items arrive through SETITEMS; any
+        if isinstance(state, dict):              # extra instance state is merged as items as well
+            self.update(state)
+        elif isinstance(state, tuple) and len(state) == 2:
+            for part in state:
+                if isinstance(part, dict):
+                    self.update(part)
+
+
+class _InertObject:
+    """stand-in for any other pandapower class found in a pickle (controllers, std-type helpers): keeps the state, runs nothing"""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        self.__dict__["_state"] = state
+
+
+_NUMPY_OK = {("numpy", "dtype"), ("numpy", "ndarray"), ("numpy", "float64"), ("numpy", "int64"), ("numpy", "bool_"),
+             ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "_reconstruct"),
+             ("numpy._core.multiarray", "scalar"), ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer")}
+_BUILTINS_OK = {"dict", "list", "tuple", "set", "frozenset", "slice", "range", "complex", "bytearray", "object", "bytes", "str",
+                "int", "float", "bool"}
+_MISC_OK = {("collections", "OrderedDict"), ("collections", "defaultdict"), ("copyreg", "_reconstructor"), ("copy_reg", "_reconstructor"),
+            ("datetime", "datetime"), ("datetime", "date"), ("datetime", "timedelta"), ("datetime", "timezone"),
+            ("_codecs", "encode"), ("__builtin__", "object"), ("__builtin__", "dict"), ("__builtin__", "list"), ("__builtin__", "set"),
+            ("__builtin__", "tuple"), ("__builtin__", "slice"), ("__builtin__", "long"), ("__builtin__", "unicode")}
+_PANDAS_PREFIXES = ("pandas.core.frame", "pandas.core.series", "pandas.core.internals", "pandas.core.indexes", "pandas.core.index",
+                    "pandas.core.arrays", "pandas.core.dtypes", "pandas.core.generic", "pandas._libs", "pandas.indexes", "pandas.tseries")
+
+
+def _restricted_unpickler(f):
+    import importlib
+    import pickle
+
+    class U(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module == "pandapower" or module.startswith("pandapower."):
+                return InertNet if name in ("pandapowerNet", "ADict") else _InertObject
+            if (module, name) in _NUMPY_OK or (module, name) in _MISC_OK or (module == "builtins" and name in _BUILTINS_OK):
+                if module == "__builtin__":
+                    module = "builtins"
+                    name = {"long": "int", "unicode": "str"}.get(name, name)
+                if module == "copy_reg":
+                    module = "copyreg"
+                return getattr(importlib.import_module(module), name)
+            if module.startswith(_PANDAS_PREFIXES) and not name.startswith("__"):
+                import pandas.compat.pickle_compat as pc          # old pandas module paths -> current classes (data classes only)
+                module, name = pc._class_locations_map.get((module, name), (module, name)) if hasattr(pc, "_class_locations_map") else (module, name)
+                return getattr(importlib.import_module(module), name)
+            raise pickle.UnpicklingError(f"model.p references {module}.{name}: not a numpy / pandas / builtin data class — refused "
+                                         "(mapdn_amd.data reads pandapower pickles as data, it never imports or runs their code)")
+    return U(f, encoding="latin1")
+
+
+def read_pandapower_pickle(path: str) -> InertNet:
+    """`pp.from_pickle(path)` (voltage_control_env.py:400-405) without pandapower: the net as an attribute-style dict of
+    pandas DataFrames + scalars, from either on-disk form (see above).  Only what io_utils.get_raw_data_from_pickle does to
+    the tables is done here (DataFrame from the "split" dict, column dtypes restored); pandapower's convert_format
+    (renaming the columns of nets saved by versions < 2.0, kW/kVA units) is NOT replayed — such a net is refused."""
+    import pandas as pd
+    with open(path, "rb") as f:
+        raw = _restricted_unpickler(f).load()
+    if not isinstance(raw, dict):
+        raise ValueError(f"{path}: not a pandapower net pickle (top level is {type(raw).__name__})")
+    net = InertNet()
+    for key, item in raw.items():
+        if isinstance(item, dict) and "DF" in item:
+            d = item["DF"]
+            df = pd.DataFrame(data=d.get("data"), index=d.get("index"), columns=d.get("columns")) if isinstance(d, dict) else pd.DataFrame(d)
+            for col, dt in (item.get("dtypes") or {}).items():
+                if col in df.columns:
+                    try:
+                        df[col] = df[col].astype(dt)
+                    except (TypeError, ValueError):
+                        pass                       # object columns with None (names, std_type): left as they are, like pandapower
+            net[key] = df
+        else:
+            net[key] = item
+    if "sn_mva" not in net or "bus" not in net or ("sn_kva" in net and "sn_mva" not in net):
+        raise NotImplementedError(f"{path}: no sn_mva / bus table — a net saved by pandapower < 2.0 (kW / kVA columns) needs "
+                                  "pandapower's convert_format; re-save it with pandapower >= 2.0")
+    return net
+
+
 def load_scenario(data_path: str, pv_scale: float = 1.0, demand_scale: float = 1.0):
-    """(NetSpec, Profiles) of a scenario directory: netspec.npz (or model.p with pandapower) + the CSVs."""
+    """(NetSpec, Profiles) of a scenario directory: netspec.npz or the reference's model.p (read as data by the restricted
+    unpickler above — pandapower is not needed) + the three CSVs."""
     npz = os.path.join(data_path, "netspec.npz")
     if os.path.exists(npz):
         net = load_netspec(npz)
     elif os.path.exists(os.path.join(data_path, "model.p")):
-        try:
-            import pandapower as pp
-        except ImportError as e:
-            raise NotImplementedError("model.p is a pandapower pickle and pandapower is not installed; "
-                                      "export a netspec.npz with mapdn_amd.data.save_netspec") from e
-        net = from_pandapower(pp.from_pickle(os.path.join(data_path, "model.p")))
+        net = from_pandapower(read_pandapower_pickle(os.path.join(data_path, "model.p")))
     else:
         raise FileNotFoundError(f"no netspec.npz / model.p in {data_path}")
     return net, load_profiles_csv(data_path, pv_scale, demand_scale)
