@@ -40,16 +40,18 @@ def algorithmic_bytes_per_env_step(env):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
+def _oracle_args(case):
+    return dict(episode_limit=240, action_scale=SCALE[case], action_bias=0.0, voltage_barrier_type="bowl", seed=0)
+
+
 def _cpu_worker(args):
     """One oracle env on one core for `seconds`: sequential step()+get_obs() (restated pandapower runpp + env logic)."""
     case, seconds, env_id = args
-    os.environ["OMP_NUM_THREADS"] = "1"
     import numpy as np
     from mapdn_amd.netspec import make_case
     from oracle.env_restated import VoltageControlOracle
     net, prof = make_case(case)
-    a = dict(episode_limit=240, action_scale=SCALE[case], action_bias=0.0, voltage_barrier_type="bowl", seed=0)
-    env = VoltageControlOracle(net, prof, a, env_id=env_id)
+    env = VoltageControlOracle(net, prof, _oracle_args(case), env_id=env_id)
     rng = np.random.default_rng(env_id)
     for _ in range(3):
         env.step(rng.uniform(-SCALE[case], SCALE[case], net.n_sgen)); env.get_obs()
@@ -63,31 +65,118 @@ def _cpu_worker(args):
     return n, time.perf_counter() - t0
 
 
-def cpu_baseline(case, seconds=10.0):
-    """Restated pandapower-equivalent CPU path (oracle/: numpy + scipy SuperLU): (1) one env on one core, (2) one env
-    per host core, all cores at once (multiprocessing; SURVEY.md 8(d) "batched across all cores").  pandapower 2.7.0
-    itself is not installable offline, hence kind='port'.  Called BEFORE this process touches the GPU
-    (workers are forked)."""
+class BatchedOracleShard:
+    """E oracle envs stepped together: the E power flows of a step are ONE batched-numpy Newton-Raphson (oracle/batched_np.py),
+    everything around it (clip, reward, info, profile advance, obs) stays the per-env restatement of the reference's env code."""
+
+    def __init__(self, case, n_envs, first_env_id=0):
+        from mapdn_amd.netspec import make_case
+        from oracle import env_restated
+        from oracle.batched_np import BatchedRunpp
+        self.er = env_restated
+        self.real_runpp = env_restated.runpp_restated
+        net, prof = make_case(case)
+        self.net = net
+        self.envs = [env_restated.VoltageControlOracle(net, prof, _oracle_args(case), env_id=first_env_id + e) for e in range(n_envs)]
+        self.solver = BatchedRunpp(net)
+
+    def step(self, actions):
+        import numpy as np
+        envs = self.envs
+        qs = np.stack([e._clip_reactive_power(np.asarray(a, dtype=np.float64), e.sgen_p) for e, a in zip(envs, actions)])
+        res = self.solver(np.stack([e.load_p for e in envs]), np.stack([e.load_q for e in envs]),
+                          np.stack([e.sgen_p for e in envs]), qs)
+        out = []
+        for e, a, r in zip(envs, actions, res):
+            self.er.runpp_restated = lambda *x, _r=r, **k: _r          # the env's own runpp call returns its share of the batch
+            try:
+                rew, term, info = e.step(a)
+            finally:
+                self.er.runpp_restated = self.real_runpp
+            e.get_obs()
+            if term:
+                e.reset()                                               # (rare) the restart's power flow: the one-env solver
+            out.append((rew, term, info))
+        return out
+
+
+def _cpu_worker_batched(args):
+    case, seconds, shard, envs_per_shard = args
+    import numpy as np
+    sh = BatchedOracleShard(case, envs_per_shard, first_env_id=shard * envs_per_shard)
+    rng = np.random.default_rng(1000 + shard)
+    ns = sh.net.n_sgen
+    sh.step(rng.uniform(-SCALE[case], SCALE[case], (envs_per_shard, ns)))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        sh.step(rng.uniform(-SCALE[case], SCALE[case], (envs_per_shard, ns)))
+        n += envs_per_shard
+    return n, time.perf_counter() - t0
+
+
+def effective_cores():
+    """(cores in the affinity mask, CPU quota of the cgroup in cores or None).  os.sched_getaffinity alone over-reports on a
+    quota-limited container: the kernel then throttles every process (round 2 saw 256 'cores' deliver 15x one core)."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),):
+        try:
+            quota = parse(open(path).read())
+        except (OSError, ValueError, IndexError):
+            pass
+    if quota is None:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / p if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    return aff, quota
+
+
+def _run_pool(target, arglist, timeout=900):
     import multiprocessing as mp
-    cores = len(os.sched_getaffinity(0))
-    n1, dt1 = _cpu_worker((case, seconds * 0.4, 0))
     ctx = mp.get_context("fork")
     q = ctx.Queue()
     t0 = time.perf_counter()
-    procs = [ctx.Process(target=lambda e=e: q.put(_cpu_worker((case, seconds * 0.6, e))), daemon=True) for e in range(cores)]
+    procs = [ctx.Process(target=lambda a=a: q.put(target(a)), daemon=True) for a in arglist]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    res = [q.get(timeout=timeout) for _ in procs]
     for p in procs:
         p.join()
-    wall = time.perf_counter() - t0
-    n_all = sum(r[0] for r in res)
-    busy = max(r[1] for r in res)
-    return {"value": n_all / busy, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    return res, time.perf_counter() - t0
+
+
+def cpu_baseline(case, seconds=10.0, envs_per_shard=64):
+    """Restated pandapower-equivalent CPU path (oracle/: numpy + scipy; pandapower 2.7.0 itself is not installable offline,
+    SURVEY.md 8(c), hence kind='port'), three ways as SURVEY.md 8(d)(2) asks:
+      (1) one env, one core: scipy sparse NR (SuperLU) per step;
+      (2) one such env per core, all cores at once;
+      (3) the batched-numpy form: a shard of `envs_per_shard` envs per core whose power flows are one vectorised NR.
+    `value` is the best all-core figure.  Cores = min(affinity mask, cgroup CPU quota).  Called BEFORE this process touches
+    the GPU (workers are forked); BLAS / OpenMP pools are pinned to one thread so that processes do not oversubscribe."""
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ[v] = "1"
+    aff, quota = effective_cores()
+    cores = max(1, min(aff, int(quota)) if quota else aff)
+    (n1, dt1), = _run_pool(_cpu_worker, [(case, seconds * 0.2, 0)])[0]
+    res2, wall2 = _run_pool(_cpu_worker, [(case, seconds * 0.3, e) for e in range(cores)])
+    res3, wall3 = _run_pool(_cpu_worker_batched, [(case, seconds * 0.5, e, envs_per_shard) for e in range(cores)])
+    n2, busy2 = sum(r[0] for r in res2), max(r[1] for r in res2)
+    n3, busy3 = sum(r[0] for r in res3), max(r[1] for r in res3)
+    v2, v3 = n2 / busy2, n3 / busy3
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ.pop(v, None)
+    return {"value": max(v2, v3), "unit": "env-steps/s", "cores": cores, "kind": "port",
             "single_core_value": n1 / dt1,
-            "sample": f"{cores} processes (one {case} oracle env each, one per host core) x {busy:.1f} s = {n_all} sequential "
-                      f"step()+get_obs(); before that 1 env on 1 core: {n1} in {dt1:.1f} s; numpy/scipy restatement of "
-                      f"pandapower runpp + env logic; pool wall {wall:.1f} s incl. start-up"}
+            "all_cores_one_env_per_process": {"value": v2, "per_process": v2 / cores, "processes": cores},
+            "all_cores_batched_numpy": {"value": v3, "per_process": v3 / cores, "processes": cores, "envs_per_process": envs_per_shard},
+            "affinity_cores": aff, "cgroup_cpu_quota_cores": quota,
+            "parallel_efficiency_vs_single_core": v2 / cores / (n1 / dt1),
+            "sample": f"{case}: (1) 1 env on 1 core, scipy SuperLU NR: {n1} step()+get_obs() in {dt1:.1f} s; (2) {cores} processes x 1 env: "
+                      f"{n2} in {busy2:.1f} s (pool wall {wall2:.1f} s); (3) {cores} processes x {envs_per_shard} envs, batched-numpy NR: "
+                      f"{n3} in {busy3:.1f} s (pool wall {wall3:.1f} s).  cores = min(affinity {aff}, cgroup quota {quota}); "
+                      f"numpy/scipy restatement of pandapower runpp + env logic"}
 
 
 # ------------------------------------------------------------------------------------------------ live PMC traffic
@@ -172,6 +261,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm); 'gloo' only to "
                                                         "exercise the N>1 path on a box with fewer GPUs than ranks")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the timed --steps block until the blocks add up to this")
     ap.add_argument("--inner", action="store_true", help="(internal) short un-instrumented loop for the PMC sub-runs")
     a = ap.parse_args()
 
@@ -235,26 +325,49 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    resets = [0]
+    _orig_reset = env.reset
+
+    def counted_reset(*x, **k):
+        resets[0] += 1
+        return _orig_reset(*x, **k)
+    env.reset = counted_reset
+
+    def timed_block():
+        """EXACTLY a.steps steps between two fences (barrier + device sync on both sides); max over ranks"""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            one_step()
+        if dist is not None:                                  # end-of-rollout RCCL gather (SURVEY 8(e)), inside the timed region
+            ret = env.episode_returns()
+            allret = gather_rollout(ret if a.backend == "nccl" else ret.cpu())
+            assert allret.shape[0] == world * B
+        fence()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     env.reset()
     for _ in range(a.warmup):
         one_step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_step()
-    if dist is not None:                                      # end-of-rollout RCCL gather, inside the timed region
-        ret = env.episode_returns()
-        allret = gather_rollout(ret if a.backend == "nccl" else ret.cpu())
-        assert allret.shape[0] == world * B
-    fence()
-    dt = time.perf_counter() - t0
     if a.inner:
+        timed_block()
         env.close()
         return
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # A block of `--steps` steps can be a few milliseconds (the driver's --steps 20 is 2.5 ms): the block is repeated, each
+    # repeat fenced and timed on its own, until the timed blocks add up to >= --min-seconds (every rank runs the same number:
+    # the decision uses the max-over-ranks times).  `ms_per_step` / `value` are the MEDIAN block; min / max are reported.
+    resets[0] = 0
+    blocks = []
+    while len(blocks) < 3 or (sum(blocks) < a.min_seconds and len(blocks) < 2000):
+        blocks.append(timed_block())
+    resets_in_region = resets[0]
+    blocks_sorted = sorted(blocks)
+    dt = blocks_sorted[len(blocks) // 2]
     stats = env.stats()
 
     # ---- dominant kernel (NR solve) duration, HIP events on its launch stream, separate short pass
@@ -265,12 +378,19 @@ def main():
     nr_ms, nr_launches = env.nr_time_ms()
     env.nr_timing(False)
     kname = "k_nr_tree"
+    nr_avg_rank_ms = nr_ms / max(nr_launches, 1)
+    nr_per_rank = [nr_avg_rank_ms]
+    if dist is not None:                                      # the dominant kernel's average duration on every rank; the roofline uses the slowest
+        t = torch.zeros(world, dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        t[rank] = nr_avg_rank_ms
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        nr_per_rank = [float(x) for x in t.tolist()]
 
     if rank == 0:
         n_gpus = world
         value = n_gpus * B * a.steps / dt
         bytes_step = algorithmic_bytes_per_env_step(env)
-        nr_avg_s = nr_ms / max(nr_launches, 1) * 1e-3
+        nr_avg_s = max(nr_per_rank) * 1e-3
         achieved = bytes_step * B / nr_avg_s / 1e9
         traffic, tsrc, tdetail = None, None, None
         if world == 1 and not a.no_traffic:
@@ -287,9 +407,16 @@ def main():
             "metric": "env-steps/sec (whole node), case141 batch=4096, at 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "repeats": len(blocks), "timed_seconds_total": sum(blocks),
+            "ms_per_step_repeats": {"min": blocks_sorted[0] / a.steps * 1e3, "median": dt / a.steps * 1e3,
+                                    "max": blocks_sorted[-1] / a.steps * 1e3},
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.case} ({env.n_bus}-bus, {env.n_agents} agents), {B} parallel envs per GPU, "
-                                   f"bowl voltage barrier, step()+get_obs(), 240-step episodes with in-region resets",
+                                   f"bowl voltage barrier, step()+get_obs(), 240-step episodes; "
+                                   + (f"{resets_in_region} whole-batch reset(s) fell inside the {len(blocks)} timed block(s) "
+                                      f"(their power flows are extra work, not counted as env-steps)" if resets_in_region else
+                                      f"no episode boundary fell inside the {len(blocks)} timed block(s) of {a.steps} steps"),
+                       "resets_in_timed_region": resets_in_region,
                        "envs_per_gpu": B, "global_envs": n_gpus * B, "obs_size": env.obs_size,
                        "parallelism": f"env-batch sharded x{n_gpus}, no data-path collective; one all_gather of episode "
                                       f"returns ({a.backend}) at the end of the rollout, inside the timed region"},
@@ -297,12 +424,13 @@ def main():
             # `bound`: what the SQ counters say limits the kernel (profiles/*_nr_sq_counters.txt) — per-row latency of the
             # tree sweeps, neither roof.  The fraction is against the HBM roof as the contract prescribes (SURVEY 8(d):
             # compulsory traffic is tiny by construction); the f64 fraction is in `compute`.
-            "roofline": {"bound": "latency", "roof": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "limited_by": "latency (rows x sweeps of the tree elimination; neither roof)", "kernel": kname,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                          "traffic_detail": tdetail,
                          "algorithmic_bytes_per_launch": bytes_step * B,
                          "algorithmic_bytes_per_env_step": bytes_step, "envs_per_launch": B,
-                         "kernel_avg_ms": nr_avg_s * 1e3, "kernel_launches_timed": nr_launches},
+                         "kernel_avg_ms": nr_avg_s * 1e3, "kernel_avg_ms_per_rank": nr_per_rank, "kernel_launches_timed": nr_launches},
             # compute-side view: ~184 * nb f64 flops per NR iteration (SpMV, mismatch, Jacobian,
             # block-tree solve, update) x (iterations + 1 mismatch evaluation), against the f64 vector peak
             "compute": {"algorithmic_flops_per_env_step": flops_step, "achieved_tflops": tfl, "peak_tflops": FP64_PEAK_TFLOPS,

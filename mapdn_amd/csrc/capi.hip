@@ -25,6 +25,9 @@ struct mapdn_handle {
   std::string err;
   std::vector<void*> allocs;
   bool have_profiles = false, was_reset = false, host_only = false;
+  bool sbus_stale = true;         // Sbus / bus_ld do not reflect cur_pl / cur_ql (fresh handle, after mapdn_solve_only): the next
+                                  // injection runs the all-bus kernel; MAPDN_INJECT_FULL=1 keeps it that way (A/B, tests)
+  bool inject_full = false;
   size_t lds_bytes = 0;
   int32_t *obs_rows = nullptr, *state_rows = nullptr, *iota_idx = nullptr, *vm_row = nullptr, *va_row = nullptr;
   int32_t *obs_xptr = nullptr, *obs_xrow = nullptr;
@@ -152,6 +155,18 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   d.n_root_children = (int32_t)P.root_children.size();
   UP(load_ptr, P.load_ptr); UP(load_idx, P.load_idx); UP(sgen_ptr, P.sgen_ptr); UP(sgen_idx, P.sgen_idx);
   UP(shunt_p, P.shunt_p); UP(shunt_q, P.shunt_q); UP(load_scale, P.load_scale); UP(sgen_scale, P.sgen_scale);
+  {
+    std::vector<int32_t> sgb, sgb_of(P.nb, -1), lb;
+    for (int k = 0; k < P.nb; ++k) {
+      if (P.sgen_ptr[k + 1] > P.sgen_ptr[k]) { sgb_of[k] = (int32_t)sgb.size(); sgb.push_back(k); }
+      else if (P.load_ptr[k + 1] > P.load_ptr[k]) lb.push_back(k);
+    }
+    d.n_sgb = (int32_t)sgb.size(); d.n_lb = (int32_t)lb.size();
+    if (lb.empty()) lb.push_back(0);
+    UP(sgb_pos, sgb); UP(sgb_of_pos, sgb_of); UP(lb_pos, lb);
+    rc = dalloc(h, &d.bus_ld, (size_t)2 * d.n_sgb * d.Bp); if (rc) return rc;
+    if (const char* s_ = getenv("MAPDN_INJECT_FULL")) h->inject_full = atoi(s_) != 0;
+  }
   {
     std::vector<LineFlow> padded(P.lines);               // read 16 bytes at a time by the NR kernel's LDS staging
     if (padded.size() % 2) padded.push_back(LineFlow{});
@@ -450,6 +465,15 @@ static void nr_launch(mapdn_handle* h, int mode, double* reward, uint8_t* term, 
   (void)hipEventRecord(b, st);
 }
 
+// the injection of a step() / reset() call: PV buses only when Sbus and bus_ld are known to reflect the current loads
+static void inject_launch(mapdn_handle* h, int mode, const void* actions, int dtype, int add_noise, hipStream_t st) {
+  const Dev& d = h->d;
+  if (h->sbus_stale || h->inject_full) {
+    launch_inject(d, mode, actions, dtype, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, add_noise, st);
+    h->sbus_stale = false;
+  } else launch_inject_sgen(d, mode, actions, dtype, add_noise, st);
+}
+
 int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, int32_t max_tries, void* stream) {
   if (!h) return MAPDN_E_INVALID;
   if (!h->have_profiles) { h->err = "reset before set_profiles"; return MAPDN_E_STATE; }
@@ -461,7 +485,7 @@ int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, i
   for (int t = 0; t < max_tries; ++t) {
     launch_reset_begin(d, start_rows, t == 0, st);
     launch_advance(d, add_noise, 1, 0, st);
-    launch_inject(d, MODE_RESET, nullptr, MAPDN_F64, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, add_noise, st);
+    inject_launch(h, MODE_RESET, nullptr, MAPDN_F64, add_noise, st);
     nr_launch(h, MODE_RESET, nullptr, nullptr, nullptr, st);
     launch_advance(d, 0, 0, 1, st);              // res_bus commit of the envs that found a solvable start
   }
@@ -480,7 +504,7 @@ int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int3
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   const Dev& d = h->d;
-  launch_inject(d, MODE_STEP, actions, actions_dtype, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, add_noise, st);
+  inject_launch(h, MODE_STEP, actions, actions_dtype, add_noise, st);
   // (Running the profile advance on a side stream beside the NR kernel was measured: the fork/join events
   // cost more than the ~6 us they hide, 29.5 M vs 31.5 M env-steps/s, so the step stays on one stream.)
   nr_launch(h, MODE_STEP, reward, terminated, info, st);
@@ -501,7 +525,7 @@ int mapdn_step_obs(mapdn_handle* h, const void* actions, int32_t actions_dtype, 
   hipStream_t st = (hipStream_t)stream;
   const Dev& d = h->d;
   const int C = h->plan.n_agents * h->plan.obs_size;
-  launch_inject(d, MODE_STEP, actions, actions_dtype, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, add_noise, st);
+  inject_launch(h, MODE_STEP, actions, actions_dtype, add_noise, st);
   nr_launch(h, MODE_STEP, reward, terminated, info, st);
   launch_advance(d, add_noise, 1, 1, st);        // next profile row + res_bus commit in one wide launch
   launch_gather(d, d.gbuf, h->obs_rows, h->obs_scale, 1.0, h->obs_xptr, h->obs_xrow, obs, obs_dtype, C, st);
@@ -605,6 +629,7 @@ int mapdn_solve_only(mapdn_handle* h, const double* p_load, const double* q_load
   HIPCHK(h, hipMemsetAsync(d.active, 1, d.B, st));
   if (d.Bp > d.B) HIPCHK(h, hipMemsetAsync(d.active + d.B, 0, d.Bp - d.B, st));
   launch_inject(d, MODE_SOLVE, nullptr, MAPDN_F64, h->t_pl, h->t_ql, h->t_pv, h->t_q, 0, st);
+  h->sbus_stale = true;                          // Sbus now holds the caller's loads, not cur_pl / cur_ql
   nr_launch(h, MODE_SOLVE, nullptr, nullptr, nullptr, st);
   if (vm_pu) transpose_out(h, d.nrbuf, 1.0, h->vm_row, vm_pu, d.nb, st);
   if (va_degree) transpose_out(h, d.nrbuf, 180.0 / M_PI, h->va_row, va_degree, d.nb, st);

@@ -22,6 +22,9 @@
 #define MAPDN_NR_PF 2
 #endif
 
+// the 64-bit form of llvm.amdgcn.update.dpp (clang's __builtin_amdgcn_update_dpp is 32-bit only)
+extern "C" __device__ double __mapdn_update_dpp_f64(double, double, int, int, int, bool) __asm("llvm.amdgcn.update.dpp.f64");
+
 namespace mapdn {
 
 // =================================================================================================
@@ -128,6 +131,8 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
       P += p * d.load_scale[li]; Q += q * d.load_scale[li];
     } else { P += pl[o] * d.load_scale[li]; Q += ql[o] * d.load_scale[li]; }   // pd2ppc: PD = sum p_mw * scaling
   }
+  if (mode != MODE_SOLVE && d.sgb_of_pos[k] >= 0)   // load part of the injection at a PV bus, kept for k_inject_sgen
+    ((double2*)d.bus_ld)[(size_t)d.sgb_of_pos[k] * d.Bp + e] = make_double2(P, Q);
   for (int i = d.sgen_ptr[k]; i < d.sgen_ptr[k + 1]; ++i) {
     const int j = d.sgen_idx[i];
     const size_t o = (size_t)j * d.Bp + e;
@@ -155,6 +160,86 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
     double2* sb = (double2*)((char*)d.nrbuf + d.sb_off) + (size_t)d.sb_index[k] * d.Bp + e;
     *sb = make_double2(-P / d.sn, -Q / d.sn);
   }
+}
+
+// K1'  inject, step()/reset() form.  Between two steps only the sgen q changes: the loads of the next step are written by
+//      k_advance at the end of the previous one, which also leaves the finished Sbus entry of every bus WITHOUT sgens and,
+//      for the buses with sgens, the load part of the injection (bus_ld).  So this launch has one thread per
+//      (PV bus, env) — 22 rows instead of 141 on the 141-bus feeder: q = a sqrt(s_max^2 - p^2) of the bus's sgens and
+//      Sbus = -((loads) - (sgens)) / sn, the same expressions in the same order as k_inject (bit-identical).
+//      An env that auto-resets in this call (rare) refreshes ALL its loads here, its threads striding over the load buses.
+template <typename AT>
+__global__ void __launch_bounds__(256)
+k_inject_sgen(Dev d, int mode, const AT* __restrict__ actions, int add_noise) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int jb = blockIdx.y;                     // PV-bus number
+  if (e >= d.B) return;
+  const int k = d.sgb_pos[jb];                   // its elimination position (n == slack: q only, no Sbus row)
+  bool act, ar = false;
+  if (mode == MODE_STEP) {
+    const bool dn = d.done[e] != 0;
+    ar = dn && d.auto_reset;
+    act = !dn || ar;
+  } else act = d.pending[e] != 0;
+  const uint32_t draw = mode == MODE_STEP ? d.draw[e] : d.adv_draw[e];
+  int64_t ar_row = 0;
+  if (ar) {
+    const int64_t start = sample_start_row(d, e, draw);
+    ar_row = start + 1;                          // t = self.steps == 1 (:100, :473)
+    if (jb == 0) d.start_row[e] = start;
+  }
+  if (jb == 0) {
+    d.active[e] = act ? 1 : 0;
+    if (mode == MODE_STEP) {
+      d.resetting[e] = ar ? 1 : 0;
+      d.adv_row[e] = (act && !ar) ? d.start_row[e] + d.steps[e] : -1; d.adv_draw[e] = draw;
+    }
+  }
+  if (!act) return;                              // frozen: q_new, Sbus stay as they are
+  double2* const bl = (double2*)d.bus_ld + (size_t)jb * d.Bp + e;
+  double2* const sbp = (double2*)((char*)d.nrbuf + d.sb_off) + e;
+  double P, Q;
+  if (ar) {
+    auto load_sum = [&](int kk, double& Ps, double& Qs) {
+      Ps = 0.0; Qs = 0.0;
+      for (int i = d.load_ptr[kk]; i < d.load_ptr[kk + 1]; ++i) {
+        const int li = d.load_idx[i];
+        const size_t o = (size_t)li * d.Bp + e;
+        const double p = profile_value(d, e, ar_row, draw, STREAM_LOAD_P, li, d.ns, add_noise);
+        const double q = profile_value(d, e, ar_row, draw, STREAM_LOAD_Q, li, d.ns + d.nl, add_noise);
+        d.cur_pl[o] = p; d.cur_ql[o] = q;
+        Ps += p * d.load_scale[li]; Qs += q * d.load_scale[li];
+      }
+    };
+    load_sum(k, P, Q);
+    *bl = make_double2(P, Q);
+    for (int i = jb; i < d.n_lb; i += d.n_sgb) {   // the buses with loads but no sgens, shared out over this env's threads
+      const int kk = d.lb_pos[i];
+      double Ps, Qs;
+      load_sum(kk, Ps, Qs);
+      if (kk < d.n) sbp[(size_t)d.sb_index[kk] * d.Bp] = make_double2(-Ps / d.sn, -Qs / d.sn);
+    }
+  } else { const double2 v = *bl; P = v.x; Q = v.y; }
+  for (int i = d.sgen_ptr[k]; i < d.sgen_ptr[k + 1]; ++i) {
+    const int j = d.sgen_idx[i];
+    const size_t o = (size_t)j * d.Bp + e;
+    double p;
+    if (ar) { p = profile_value(d, e, ar_row, draw, STREAM_PV, j, 0, add_noise); d.cur_pv[o] = p; d.cur_q[o] = 0.0; }
+    else p = d.cur_pv[o];
+    const double sm = d.smax[j];
+    const double lim = sqrt(sm * sm - p * p);
+    double q;
+    if (mode == MODE_STEP && !ar) q = lim * (double)actions[(size_t)e * d.ns + j];
+    else if (d.reset_action) {
+      uint32_t x[4];
+      philox4x32_10((uint32_t)(d.env_id_offset + e), draw, STREAM_ACTION, (uint32_t)(j >> 1), d.seed_lo, d.seed_hi, x);
+      const double u = ((j & 1) ? u53(x[2], x[3]) : u53(x[0], x[1])) * (1.0 / 9007199254740992.0);
+      q = lim * (d.action_low + (d.action_high - d.action_low) * u);
+    } else q = 0.0;                              // base-net q_mvar (deepcopy of base_powergrid, :106)
+    d.q_new[o] = q;
+    P -= p * d.sgen_scale[j]; Q -= q * d.sgen_scale[j];
+  }
+  if (k < d.n) sbp[(size_t)d.sb_index[k] * d.Bp] = make_double2(-P / d.sn, -Q / d.sn);
 }
 
 // =================================================================================================
@@ -251,7 +336,15 @@ __device__ __forceinline__ double rows_max(double v) {
   return fmax(__hiloint2double((int)b.x, (int)a.x), __hiloint2double((int)b.y, (int)a.y));
 }
 
+__device__ __forceinline__ double bld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+// v_mov_b64_dpp row_newbcast:N — every lane of a 16-lane row receives the value lane N of its row holds (gfx90a+: VALU rate, no LDS)
+template <int N> __device__ __forceinline__ double rowb(double v) { return __mapdn_update_dpp_f64(0.0, v, 0x150 + N, 0xf, 0xf, false); }
+
 struct Rec { u32x4 ix; d2 ykk, ykp, ypk, cks, sb; };    // per-(worker,row) constants + the env's scheduled injection
+struct RecQ { double q; d2 sb; };                       // packed: this lane's qword of the worker's StepRec (see RB in k_nr_tree)
+struct RecFQ { double q, f; d2 sb; };                   // ... and of its flat-start step
 struct RecF { u32x4 ix; d2 s, i01, i23, ap, sb; };      // flat-start form: host-factorised constants (Schedule::flat)
 struct BwdF { d2 h, g01, g23; };                        // factors of one step when they come from global memory
 
@@ -312,6 +405,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     const d2 v0 = {vroot, 0.0}, z2 = {0.0, 0.0};
     for (unsigned k = t; k < n + 2; k += Wt) sV[(size_t)k * L] = v0;
     for (unsigned i = threadIdx.x; i < (unsigned)d.nr_nclist; i += 64u * W) s_clist[i] = d.clist[i];
+    if (HL && t == 0) sH[(size_t)n * L] = z2;    // the slack entry of the h / x array: the x an elimination root reads
     if (t == 0) {                                // the ZERO slots (second-to-last of each kind) read as 0 forever
 #pragma unroll
       for (int i = 0; i < 4; ++i) cs[((size_t)(d.nr_cslots - 2) * 4 + i) * L] = z2;
@@ -384,6 +478,27 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   const bool flatL = RES == 1 ? true : RES == 2 ? false : d.nr_flat_lds != 0;
   const char* recT = s_rec + voT;                  // this worker's records / flat steps in LDS
   const char* flatT = s_flat + voF;
+  // RB ("record broadcast", 16 or 32 envs per workgroup: a worker is one or two whole 16-lane DPP rows).  The 16 lanes of a
+  // worker need the SAME 80-byte record; read as five 16-byte broadcast loads that is 5 KB returned per wave and row, and with
+  // one wave per SIMD the LDS return path (~35 B/clk) is what the issue phase of a row waits for (profiles/r03_base_stamps_fine:
+  // 508 of 1 380 cycles of a full row).  Instead lane j of every 16-lane row reads qword j of its worker's record — ONE
+  // ds_read_b64 / buffer_load_dwordx2 per row, 0.5 KB per wave — and a field is taken where it is used with
+  // v_mov_b64_dpp row_newbcast:j (VALU rate, no LDS).  StepRec = qwords (flags,slots) (chs,kp) ykk ykp ypk cks; a flat-start
+  // step = the 12 doubles of Schedule::flat.
+  constexpr bool RB = false && (L % 16) == 0;      // measured (profiles/r03_*): v_mov_b64_dpp costs ~12 cycles each, more than the broadcast reads it replaces (flat row 870 -> 1050 cycles) — kept for reference, off
+  const unsigned j16 = lane & 15u;
+  const unsigned offR = (j16 < 10u ? j16 : 9u) * 8u, offF = (j16 < 12u ? j16 : 11u) * 8u;
+  auto load_q = [&](int row) -> double {
+    if (recL) return *(const double*)(recT + (unsigned)row * TB + offR);
+    return bld1(rsT, voT + offR, row_s(row, TB));
+  };
+  auto load_fq = [&](int row) -> double {
+    if (flatL) return *(const double*)(flatT + (unsigned)row * FB + offF);
+    return bld1(rsF, voF + offF, row_s(row, FB));
+  };
+  auto q_lo = [&](double q) { return (uint32_t)__double2loint(q); };
+  auto q_hi = [&](double q) { return (uint32_t)__double2hiint(q); };
+  auto q_ix = [&](double q) -> u32x4 { const double a = rowb<0>(q), b = rowb<1>(q); return u32x4{q_lo(a), q_hi(a), q_lo(b), q_hi(b)}; };
   auto load_ix = [&](int row) -> u32x4 {
     if (recL) return *(const u32x4*)(recT + (unsigned)row * TB);
     return bldu4(rsT, voT, row_s(row, TB));
@@ -412,6 +527,19 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     }
     o.sb = bld2(rs, voS, row_s(row, pb));
   };
+  // what the rings of the sweeps hold per prefetched row: the packed form (RB) or the expanded record
+  using RingRec = std::conditional_t<RB, RecQ, Rec>;
+  using RingRecF = std::conditional_t<RB, RecFQ, RecF>;
+  using RingIx = std::conditional_t<RB, double, u32x4>;
+  auto ring_load = [&](int row, RingRec& o) {
+    if constexpr (RB) { o.q = load_q(row); o.sb = bld2(rs, voS, row_s(row, pb)); } else load_rec(row, o);
+  };
+  auto ring_loadf = [&](int row, RingRecF& o) {
+    if constexpr (RB) { o.q = load_q(row); o.f = load_fq(row); o.sb = bld2(rs, voS, row_s(row, pb)); } else load_recf(row, o);
+  };
+  auto ring_load_ix = [&](int row) -> RingIx { if constexpr (RB) return load_q(row); else return load_ix(row); };
+  auto ring_ix = [&](const auto& o) -> u32x4 { if constexpr (RB) return q_ix(o.q); else return o.ix; };
+  auto ringix_ix = [&](const RingIx& o) -> u32x4 { if constexpr (RB) return q_ix(o); else return o; };
   auto uni = [&](unsigned x) { return __builtin_amdgcn_readfirstlane(x); };
 
   // ---------------------------------------------------------------------------------------------------------------
@@ -419,7 +547,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // instructions.  Every row is therefore laid out by hand (sched_barrier fences keep the compiler from undoing it):
   //   (1) issue the LDS reads that depend on the previous row (children's contributions / parent's x) and the prefetches
   //   (2) SHADOW: work that does not depend on them — this row's child-independent Jacobian terms, the convergence
-  //       bookkeeping / voltage update DEFERRED from the previous row — runs while those reads are in flight
+  //       bookkeeping DEFERRED from the previous row — runs while those reads are in flight
   //   (3) the dependent chain (sums -> pivot -> factors -> contribution) and its LDS write, then the row barrier
   // Only (3) sits between two barriers of the inter-row dependency chain.
   // Absent children / parents are the ZERO slot, unread outputs go to the TRASH slot / node; whole groups of LDS
@@ -439,18 +567,19 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // one row ahead (LDS: V is constant during a forward sweep); unrolled by 3 so that ring indices are compile-time.
   auto fwd_sweep = [&](auto kind) {
     constexpr int K = decltype(kind)::value;
-    Rec Tq[3]; d2 vkq[3], vpq[3];
-    load_rec(0, Tq[0]); load_rec(min(1, R - 1), Tq[1]);
-    { const unsigned kp = Tq[0].ix.w; vkq[0] = sV[(size_t)(kp & 0xffffu) * L]; vpq[0] = sV[(size_t)(kp >> 16) * L]; }
+    RingRec Tq[3]; d2 vkq[3], vpq[3];
+    ring_load(0, Tq[0]); ring_load(min(1, R - 1), Tq[1]);
+    u32x4 ixc = ring_ix(Tq[0]);                            // index words of the CURRENT row (unpacked one row ahead)
+    { const unsigned kp = ixc.w; vkq[0] = sV[(size_t)(kp & 0xffffu) * L]; vpq[0] = sV[(size_t)(kp >> 16) * L]; }
     double pFp = 0.0, pFq = 0.0; bool pLive = false;       // deferred mismatch bookkeeping of the previous row
     int r = 0;
     while (r < R) {
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         if (r >= R) break;
-        const Rec& T = Tq[u % 3];
+        const RingRec& T = Tq[u % 3];
         const d2 vk = vkq[u % 3], vp = vpq[u % 3];
-        const uint32_t fl = T.ix.x, slots = T.ix.y, chs = T.ix.z, kp = T.ix.w;
+        const uint32_t fl = ixc.x, slots = ixc.y, chs = ixc.z, kp = ixc.w;
         const uint32_t flu = uni(fl);              // the wave-uniform hints, once per row on the scalar unit
         const unsigned gmax = (flu >> SU_GMAX_SHIFT) & 3u;
         // (1) gathers first: they depend on the previous row's writes and head the critical path
@@ -466,17 +595,20 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
 #pragma unroll
           for (int i = 0; i < NP; ++i) g1[i] = c1[i * L];
         }
-        {                                          // next row's operands (LDS) and the record two rows ahead (global)
-          const unsigned kpn = Tq[(u + 1) % 3].ix.w;
+        {                                          // next row's operands (LDS) and the record two rows ahead
+          ixc = ring_ix(Tq[(u + 1) % 3]);
+          const unsigned kpn = ixc.w;
           vkq[(u + 1) % 3] = sV[(size_t)(kpn & 0xffffu) * L]; vpq[(u + 1) % 3] = sV[(size_t)(kpn >> 16) * L];
-          load_rec(min(r + 2, R - 1), Tq[(u + 2) % 3]);
+          ring_load(min(r + 2, R - 1), Tq[(u + 2) % 3]);
         }
         SCHED_FENCE();
         STAMP2(200 + 10 * K);
         // (2) shadow: previous row's bookkeeping; this row's child-independent part
         //     A_kp = V_k conj(Y_kp V_p), A_pk = V_p conj(Y_pk V_k), A_kk = |V_k|^2 conj(Y_kk), A_ks = V_k conj(Y_k,slack V_slack)
         note_mismatch(pFp, pFq, pLive);
-        const double gkk = T.ykk.x, bkk = T.ykk.y, gkp = T.ykp.x, bkp = T.ykp.y, gpk = T.ypk.x, bpk = T.ypk.y;
+        double gkk, bkk, gkp, bkp, gpk, bpk;
+        if constexpr (RB) { gkk = rowb<2>(T.q); bkk = rowb<3>(T.q); gkp = rowb<4>(T.q); bkp = rowb<5>(T.q); gpk = rowb<6>(T.q); bpk = rowb<7>(T.q); }
+        else { gkk = T.ykk.x; bkk = T.ykk.y; gkp = T.ykp.x; bkp = T.ykp.y; gpk = T.ypk.x; bpk = T.ypk.y; }
         const double ek = vk.x, fk = vk.y, ep = vp.x, fp = vp.y;
         const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
         const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
@@ -485,7 +617,11 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const double v2 = ek * ek + fk * fk;
         const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
         double aks_r = 0.0, aks_i = 0.0;           // a constant-voltage neighbour only feeds S_k
-        if (flu & SU_SLACK_ANY) { aks_r = ek * T.cks.x + fk * T.cks.y; aks_i = fk * T.cks.x - ek * T.cks.y; }
+        if (flu & SU_SLACK_ANY) {
+          double ckx, cky;
+          if constexpr (RB) { ckx = rowb<8>(T.q); cky = rowb<9>(T.q); } else { ckx = T.cks.x; cky = T.cks.y; }
+          aks_r = ek * ckx + fk * cky; aks_i = fk * ckx - ek * cky;
+        }
         const double base_r = (akk_r + aks_r) + akp_r, base_i = (akk_i + aks_i) + akp_i;
         const double m = (fl & S_CARRY_IN) ? 1.0 : 0.0;    // register carry (same worker, previous row) masked by a 0/1 factor
         SCHED_FENCE();
@@ -568,24 +704,29 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // constants of Schedule::flat; per env there is only the forward substitution of the right-hand side
   // r = F - sum of the children's t (pair 3 of the contribution slots), h = I r, t = L h.
   auto fwd_sweep_flat = [&]() {
-    RecF Tq[3];
-    load_recf(0, Tq[0]); load_recf(min(1, R - 1), Tq[1]);
+    RingRecF Tq[3];
+    ring_loadf(0, Tq[0]); ring_loadf(min(1, R - 1), Tq[1]);
     int r = 0;
     while (r < R) {
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         if (r >= R) break;
-        const RecF& T = Tq[u % 3];
-        const uint32_t fl = T.ix.x, slots = T.ix.y, chs = T.ix.z, kp = T.ix.w;
+        const RingRecF& T = Tq[u % 3];
+        const u32x4 ix = ring_ix(T);
+        const uint32_t fl = ix.x, slots = ix.y, chs = ix.z, kp = ix.w;
         const uint32_t flu = uni(fl);
         const unsigned gmax = (flu >> SU_GMAX_SHIFT) & 3u;
         d2 g0, g1;
         if (gmax >= 1u) g0 = cs[((size_t)(chs & 1023u) * 4 + 3) * L];
         if (gmax >= 2u) g1 = cs[((size_t)((chs >> 10) & 1023u) * 4 + 3) * L];
-        load_recf(min(r + 2, R - 1), Tq[(u + 2) % 3]);
+        ring_loadf(min(r + 2, R - 1), Tq[(u + 2) % 3]);
         SCHED_FENCE();
         STAMP2(230);
-        const double Fp = T.s.x - T.sb.x, Fq = T.s.y - T.sb.y;       // shadow: the flat-start mismatch does not depend on children
+        double s_r, s_i, i0, i1, i2, i3, ap_r, ap_i;
+        if constexpr (RB) { s_r = rowb<FL_SR>(T.f); s_i = rowb<FL_SI>(T.f); i0 = rowb<FL_I0>(T.f); i1 = rowb<FL_I1>(T.f); i2 = rowb<FL_I2>(T.f);
+                            i3 = rowb<FL_I3>(T.f); ap_r = rowb<FL_APR>(T.f); ap_i = rowb<FL_API>(T.f); }
+        else { s_r = T.s.x; s_i = T.s.y; i0 = T.i01.x; i1 = T.i01.y; i2 = T.i23.x; i3 = T.i23.y; ap_r = T.ap.x; ap_i = T.ap.y; }
+        const double Fp = s_r - T.sb.x, Fq = s_i - T.sb.y;           // shadow: the flat-start mismatch does not depend on children
         note_mismatch(Fp, Fq, (fl & S_LIVE) != 0);
         const double m = (fl & S_CARRY_IN) ? 1.0 : 0.0;
         SCHED_FENCE();
@@ -605,8 +746,8 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
           }
         }
         const double r0 = Fp - aR0, r1 = Fq - aR1;
-        const double h0 = T.i01.x * r0 + T.i01.y * r1, h1 = T.i23.x * r0 + T.i23.y * r1;
-        const double t0 = T.ap.y * h0 + T.ap.x * h1, t1 = T.ap.y * h1 - T.ap.x * h0;
+        const double h0 = i0 * r0 + i1 * r1, h1 = i2 * r0 + i3 * r1;
+        const double t0 = ap_i * h0 + ap_r * h1, t1 = ap_i * h1 - ap_r * h0;
         cR0 = t0; cR1 = t1;
         if (flu & SU_W_ANY) cs[((size_t)(slots & 1023u) * 4 + 3) * L] = d2{t0, t1};
         SCHED_FENCE();
@@ -620,8 +761,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     }
   };
   double dxm = 0.0;                                // largest Newton step component of this worker's nodes, per env
-  // newtonpf update of one node, DEFERRED into the shadow of the next backward row (only the x chain is between the row
-  // barriers): Va += dx_a, Vm += dx_m, V = Vm e^{jVa}, with dx_a = -y0, dx_m = -|V| y1
+  // newtonpf update of one node: Va += dx_a, Vm += dx_m, V = Vm e^{jVa}, with dx_a = -y0, dx_m = -|V| y1
   //   =>  V <- V (1 - y1) e^{-j y0}   (rotation by the small step; |V|, angle are formed at the end)
   auto apply_update = [&](double y0, double y1, d2 vk, unsigned k, bool live) {
     dxm = fmax(dxm, live ? fmax(fabs(y0), fabs(y1)) : 0.0);
@@ -638,8 +778,83 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     const double en = sc * (vk.x * c - vk.y * s), fn = sc * (vk.x * s + vk.y * c);
     sV[(size_t)k * L] = done ? vk : d2{en, fn};     // converged envs keep their state; idle steps hit the trash node
   };
-  // backward sweep.  SRC 0: first iteration, G from the flat-start table; 1: G (and h) from LDS where they live there;
-  // factors that live in global scratch are prefetched two rows ahead through a static register ring like the records.
+  // ---- backward sweep, h in LDS (HL): x-propagation + parallel update.
+  // Only x_k = h_k - G_k x_parent is a chain down the tree; the voltage update of a node needs nothing but its own x.  So the
+  // rows of the backward sweep carry the x recurrence alone — x_k replaces h_k IN PLACE in the LDS h array, a child reads
+  // its parent's x from there (no x slots; the slack entry of the array holds the 0 that elimination roots read) — and
+  // the update V <- V (1 - x1) e^{-j x0} of all nodes follows as a barrier-free pass in which every worker takes every
+  // Wt-th node: n / Wt steps at full occupancy of the lanes instead of R rows at the schedule's ~50 %.
+  // SRC 0: first iteration, G from the flat-start table; 1: G from LDS (GL) or from the factor blocks in global scratch,
+  // prefetched two rows ahead through a static register ring (their address needs the row's node, read three rows ahead).
+  auto bwd_xprop = [&](auto src) {
+    constexpr int SRC = decltype(src)::value;
+    constexpr bool gG = (SRC == 1) && !GL;         // G comes from the factor blocks in global memory
+    RingIx ixq[4]; d2 g01q[4], g23q[4]; double fqq[4];
+    auto load_g = [&](int row, const RingIx& ixr, int slot) {
+      if constexpr (SRC == 0) {
+        if constexpr (RB) fqq[slot] = load_fq(row);
+        else if (flatL) { const char* p = flatT + (unsigned)row * FB; g01q[slot] = *(const d2*)(p + FL_G0 * 8); g23q[slot] = *(const d2*)(p + FL_G2 * 8); }
+        else { const unsigned sf = row_s(row, FB); g01q[slot] = bld2(rsF, voF + FL_G0 * 8u, sf); g23q[slot] = bld2(rsF, voF + FL_G2 * 8u, sf); }
+      } else if constexpr (gG) {
+        unsigned kk;
+        if constexpr (RB) kk = q_hi(rowb<1>(ixr)) & 0xffffu; else kk = ixr.w & 0xffffu;
+        const unsigned voN = voE + kk * bb;
+        g01q[slot] = bld2(rs, voN, sF_G01); g23q[slot] = bld2(rs, voN, sF_G23);
+      }
+    };
+    ixq[0] = ring_load_ix(R - 1); ixq[1] = ring_load_ix(max(R - 2, 0)); ixq[2] = ring_load_ix(max(R - 3, 0));
+    load_g(R - 1, ixq[0], 0); load_g(max(R - 2, 0), ixq[1], 1);
+    int r = R - 1;
+    while (r >= 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r < 0) break;
+        uint32_t fl, kp;
+        if constexpr (RB) { fl = q_lo(rowb<0>(ixq[u % 4])); kp = q_hi(rowb<1>(ixq[u % 4])); } else { fl = ixq[u % 4].x; kp = ixq[u % 4].w; }
+        const uint32_t flu = uni(fl);
+        const unsigned k = kp & 0xffffu, p = kp >> 16;
+        // (1) the parent's x (its h slot, already overwritten; 0 for elimination roots), this node's h and G
+        d2 q;
+        const bool xr = (flu & SU_XR_ANY) != 0;
+        if (xr) q = sH[(size_t)p * L];
+        const d2 hh = sH[(size_t)k * L];
+        d2 g01, g23;
+        if constexpr (SRC == 1 && GL) { g01 = sG[(size_t)(2 * k) * L]; g23 = sG[(size_t)(2 * k + 1) * L]; }
+        ixq[(u + 3) % 4] = ring_load_ix(max(r - 3, 0));
+        load_g(max(r - 2, 0), ixq[(u + 2) % 4], (u + 2) % 4);
+        SCHED_FENCE();
+        STAMP2(240);
+        if constexpr (SRC == 0 && RB) { const double f = fqq[u % 4]; g01 = d2{rowb<FL_G0>(f), rowb<FL_G1>(f)}; g23 = d2{rowb<FL_G2>(f), rowb<FL_G3>(f)}; }
+        else if constexpr (SRC == 0 || gG) { g01 = g01q[u % 4]; g23 = g23q[u % 4]; }
+        // (2) x_k = h_k - G_k x_parent
+        const bool cout = (fl & S_CARRY_OUT) != 0;
+        const double p0 = cout ? x0 : (xr ? q.x : 0.0), p1 = cout ? x1 : (xr ? q.y : 0.0);
+        const double y0 = hh.x - (g01.x * p0 + g01.y * p1);
+        const double y1 = hh.y - (g23.x * p0 + g23.y * p1);
+        x0 = y0; x1 = y1;
+        sH[(size_t)k * L] = d2{y0, y1};            // (idle steps: the trash node)
+        STAMP2(242);
+        if (W > 1) lds_barrier();
+        STAMP(110 + SRC);
+        --r;
+      }
+    }
+    // (3) update of every node from its x, three nodes per pass (loads first)
+    for (unsigned kb = t; kb < n; kb += 3u * Wt) {
+      unsigned kk[3]; d2 xx[3], vv[3]; bool lv[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const unsigned kx = kb + (unsigned)i * Wt;
+        lv[i] = kx < n; kk[i] = lv[i] ? kx : n + 1u;
+        xx[i] = sH[(size_t)kk[i] * L]; vv[i] = sV[(size_t)kk[i] * L];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) apply_update(xx[i].x, xx[i].y, vv[i], kk[i], lv[i]);
+      STAMP(30);
+    }
+  };
+  // backward sweep when h lives in global scratch (the lean layouts).  The update of a node is DEFERRED into the shadow of
+  // the next row (only the x chain is between the row barriers).  SRC as above.
   auto bwd_sweep = [&](auto src) {
     constexpr int SRC = decltype(src)::value;
     constexpr bool gG = (SRC == 0) || !GL;         // G comes from global memory (flat table or factor block)
@@ -681,11 +896,9 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         ixq[(u + 3) % 4] = load_ix(max(r - 3, 0));
         load_f(max(r - 2, 0), ixq[(u + 2) % 4], fq[(u + 2) % 4]);
         SCHED_FENCE();
-        STAMP2(240);
         // (2) shadow: the previous row's voltage update
         apply_update(py0, py1, pvk, pk, pLive);
         SCHED_FENCE();
-        STAMP2(241);
         // (3) x_k = h_k - G_k x_parent
         const bool cout = (fl & S_CARRY_OUT) != 0;
         const double p0 = cout ? x0 : (xr ? q.x : 0.0), p1 = cout ? x1 : (xr ? q.y : 0.0);
@@ -694,7 +907,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         x0 = y0; x1 = y1;
         if (flu & SU_XW_ANY) xs[(size_t)((slots >> 10) & 1023u) * L] = d2{y0, y1};   // TRASH unless S_X_OUT
         py0 = y0; py1 = y1; pvk = vk; pk = k; pLive = (fl & S_LIVE) != 0;
-        STAMP2(242);
         if (W > 1) lds_barrier();
         STAMP(110 + SRC);
         --r;
@@ -753,7 +965,8 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     x0 = x1 = 0.0;
     dxm = 0.0;
     STAMP(12);
-    if (first) bwd_sweep(std::integral_constant<int, 0>{}); else bwd_sweep(std::integral_constant<int, 1>{});
+    if constexpr (HL) { if (first) bwd_xprop(std::integral_constant<int, 0>{}); else bwd_xprop(std::integral_constant<int, 1>{}); }
+    else { if (first) bwd_sweep(std::integral_constant<int, 0>{}); else bwd_sweep(std::integral_constant<int, 1>{}); }
     first = false;
     if (!done) ++it;
     {                                            // size of the step just taken, per env: max over the workers
@@ -819,68 +1032,90 @@ __global__ void __launch_bounds__(256) k_reset_begin(Dev d, const int64_t* __res
 
 // =================================================================================================
 // K9b  advance (+ K6 bus commit) — _set_demand_and_pv (voltage_control_env.py:491-513): next row of the three
-//      profile tables + std/100 * |N(0,1)| noise (:498,503,508).  thread = (Philox block, env):
-//      one Philox4x32-10 call + one Box-Muller pair serves two adjacent table columns.
+//      profile tables + std/100 * |N(0,1)| noise (:498,503,508).
+//      rows [0, npv): thread = (Philox block of the PV table, env): one Philox4x32-10 call + one Box-Muller pair serves two
+//                     adjacent PV columns;
+//      rows [npv, npv + nb): thread = (bus position k, env): first the K6 commit of res_bus for the solve that just
+//                     finished (it reads the Sbus entry of bus k), then the loads of bus k for the NEXT step (element by
+//                     element through the bus's CSR list; a load takes the cosine or sine Box-Muller branch of its
+//                     Philox block) and, with them, what the next k_inject_sgen needs: the finished Sbus entry of a bus
+//                     without sgens, the load part (bus_ld) of a PV bus.  Only thread (k, env) touches Sbus[k] of the env
+//                     in this launch, so the read of the commit precedes the write.
 // =================================================================================================
-__global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_profiles) {
+__global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_profiles, int do_commit) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.B) return;
-  const int npairs = do_profiles ? ((d.ns + 1) >> 1) + 2 * ((d.nl + 1) >> 1) : 0;
-  if ((int)blockIdx.y >= npairs) {
+  const int npv = do_profiles ? ((d.ns + 1) >> 1) : 0;
+  if ((int)blockIdx.y >= npv) {
+    const int k = (int)blockIdx.y - npv;         // elimination position, n == slack
+    const size_t S = (size_t)d.Bp;
+    double2* const sbp = (double2*)((char*)d.nrbuf + d.sb_off) + e;
     // ---- K6 commit of res_bus (pandapower pfsoln/_extract_results) for envs whose solve was accepted:
     // vm_pu = |V|, va = angle(V), p_mw/q_mvar = bus demand (-Sbus*sn) + shunt*|V|^2, slack = -(V conj(I))*sn
-    if (!d.commit[e]) return;
-    const int k = (int)blockIdx.y - npairs;      // elimination position, n == slack
-    const size_t S = (size_t)d.Bp;
-    const size_t o = (size_t)d.bus_of_pos[k] * S + e;
-    double v, P, Q;
-    if (k < d.n) {
-      const double* vo = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * k) * S + e;
-      const double2 sb = ((const double2*)((const char*)d.nrbuf + d.sb_off))[(size_t)d.sb_index[k] * S + e];
-      const double ek = vo[(size_t)VO_E * S], fk = vo[(size_t)VO_F * S];
-      v = sqrt(ek * ek + fk * fk);
-      d.va[o] = atan2(fk, ek);
-      P = -sb.x * d.sn; Q = -sb.y * d.sn;
-    } else {
-      v = d.vroot; d.va[o] = 0.0;
-      double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;     // I = Y_rr V_r + sum_neighbours Y_rk V_k
-      for (int j = 0; j < d.n_root_children; ++j) {
-        const double* cb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * d.root_children[j]) * S + e;
-        const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ec = cb[(size_t)VO_E * S], fc = cb[(size_t)VO_F * S];
-        ir += g * ec - b * fc; ii += g * fc + b * ec;
+    if (do_commit && d.commit[e]) {
+      const size_t o = (size_t)d.bus_of_pos[k] * S + e;
+      double v, P, Q;
+      if (k < d.n) {
+        const double* vo = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * k) * S + e;
+        const double2 sb = sbp[(size_t)d.sb_index[k] * S];
+        const double ek = vo[(size_t)VO_E * S], fk = vo[(size_t)VO_F * S];
+        v = sqrt(ek * ek + fk * fk);
+        d.va[o] = atan2(fk, ek);
+        P = -sb.x * d.sn; Q = -sb.y * d.sn;
+      } else {
+        v = d.vroot; d.va[o] = 0.0;
+        double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;     // I = Y_rr V_r + sum_neighbours Y_rk V_k
+        for (int j = 0; j < d.n_root_children; ++j) {
+          const double* cb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * d.root_children[j]) * S + e;
+          const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ec = cb[(size_t)VO_E * S], fc = cb[(size_t)VO_F * S];
+          ir += g * ec - b * fc; ii += g * fc + b * ec;
+        }
+        P = -(d.vroot * ir) * d.sn; Q = (d.vroot * ii) * d.sn;
       }
-      P = -(d.vroot * ir) * d.sn; Q = (d.vroot * ii) * d.sn;
+      d.vm[o] = v;
+      d.res_p[o] = P + d.shunt_p[k] * v * v; d.res_q[o] = Q + d.shunt_q[k] * v * v;
     }
-    d.vm[o] = v;
-    d.res_p[o] = P + d.shunt_p[k] * v * v; d.res_q[o] = Q + d.shunt_q[k] * v * v;
+    // ---- next loads of bus k
+    if (!do_profiles) return;
+    const int l0 = d.load_ptr[k], l1 = d.load_ptr[k + 1];
+    if (l0 == l1) return;
+    const int64_t row = d.adv_row[e];
+    if (row < 0 || row >= d.T) return;             // never read outside the table
+    const uint32_t draw = d.adv_draw[e];
+    double P = 0.0, Q = 0.0;
+    for (int i = l0; i < l1; ++i) {
+      const int li = d.load_idx[i];
+      const size_t o = (size_t)li * S + e;
+      const double p = profile_value(d, e, row, draw, STREAM_LOAD_P, li, d.ns, add_noise);
+      const double q = profile_value(d, e, row, draw, STREAM_LOAD_Q, li, d.ns + d.nl, add_noise);
+      d.cur_pl[o] = p; d.cur_ql[o] = q;
+      P += p * d.load_scale[li]; Q += q * d.load_scale[li];   // pd2ppc: PD = sum p_mw * scaling
+    }
+    const int jb = d.sgb_of_pos[k];
+    if (jb >= 0) ((double2*)d.bus_ld)[(size_t)jb * S + e] = make_double2(P, Q);
+    else if (k < d.n) sbp[(size_t)d.sb_index[k] * S] = make_double2(-P / d.sn, -Q / d.sn);
     return;
   }
   const int64_t row = d.adv_row[e];
   if (row < 0 || row >= d.T) return;               // never read outside the table
-  int b = blockIdx.y;                  // pair index over [pv pairs | load_p pairs | load_q pairs]
-  const int npv = (d.ns + 1) >> 1, npl = (d.nl + 1) >> 1;
-  int stream, count, col0;
-  double* dst;
-  if (b < npv) { stream = STREAM_PV; count = d.ns; col0 = 0; dst = d.cur_pv; }
-  else if (b < npv + npl) { b -= npv; stream = STREAM_LOAD_P; count = d.nl; col0 = d.ns; dst = d.cur_pl; }
-  else { b -= npv + npl; stream = STREAM_LOAD_Q; count = d.nl; col0 = d.ns + d.nl; dst = d.cur_ql; }
+  const int b = blockIdx.y;                        // Philox block of the PV table
   const int j0 = 2 * b, j1 = 2 * b + 1;
-  const double* trow = d.table + (size_t)row * d.ncol + col0;
+  const double* trow = d.table + (size_t)row * d.ncol;
   double v0 = trow[j0];
-  double v1 = (j1 < count) ? trow[j1] : 0.0;
+  double v1 = (j1 < d.ns) ? trow[j1] : 0.0;
   if (add_noise) {
     uint32_t x[4];
-    philox4x32_10((uint32_t)(d.env_id_offset + e), d.adv_draw[e], (uint32_t)stream, (uint32_t)b, d.seed_lo, d.seed_hi, x);
+    philox4x32_10((uint32_t)(d.env_id_offset + e), d.adv_draw[e], (uint32_t)STREAM_PV, (uint32_t)b, d.seed_lo, d.seed_hi, x);
     const double u1 = (u53(x[0], x[1]) + 0.5) * (1.0 / 9007199254740992.0);
     const double u2 = u53(x[2], x[3]) * (1.0 / 9007199254740992.0);
     const double r = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincos(2.0 * M_PI * u2, &s, &c);
-    v0 += d.stdv[col0 + j0] * fabs(r * c);
-    if (j1 < count) v1 += d.stdv[col0 + j1] * fabs(r * s);
+    double sn_, cs_;
+    sincos(2.0 * M_PI * u2, &sn_, &cs_);
+    v0 += d.stdv[j0] * fabs(r * cs_);
+    if (j1 < d.ns) v1 += d.stdv[j1] * fabs(r * sn_);
   }
-  dst[(size_t)j0 * d.Bp + e] = v0;
-  if (j1 < count) dst[(size_t)j1 * d.Bp + e] = v1;
+  d.cur_pv[(size_t)j0 * d.Bp + e] = v0;
+  if (j1 < d.ns) d.cur_pv[(size_t)j1 * d.Bp + e] = v1;
 }
 
 // =================================================================================================
@@ -1009,6 +1244,8 @@ void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const
 constexpr int nr_res(int w, int l, bool h_lds) {
   return h_lds ? (((w == 1 && l == 16) || (w == 4 && l == 16) || (w == 4 && l == 8)) ? 1 : 0) : ((w == 2 && l == 16) ? 2 : 0);
 }
+// h in LDS, records and flat constants in global memory: the fat layout of nets whose schedule does not fit (case322: W = 4, L = 8)
+constexpr int nr_res_hg(int w, int l) { return (w == 4 && l == 8) ? 2 : 0; }
 // (W, L) instantiations of k_nr_tree
 #define NR_FOR_EACH(X) X(1, 8) X(1, 16) X(1, 32) X(2, 8) X(2, 16) X(2, 32) X(4, 8) X(4, 16) X(4, 32) X(8, 16)
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
@@ -1021,6 +1258,7 @@ void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* in
     if (d.nr_h_lds && d.nr_g_lds && d.nr_rec_lds && d.nr_flat_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, true, nr_res(w, l, true)>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
     else if (d.nr_h_lds && d.nr_g_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, true>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
     else if (d.nr_h_lds && d.nr_rec_lds && d.nr_flat_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, false, nr_res(w, l, true)>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
+    else if (d.nr_h_lds && !d.nr_rec_lds && !d.nr_flat_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, false, nr_res_hg(w, l)>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
     else if (d.nr_h_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, false>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
     else if (!d.nr_rec_lds && !d.nr_flat_lds) hipLaunchKernelGGL((k_nr_tree<w, l, false, false, nr_res(w, l, false)>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
     else hipLaunchKernelGGL((k_nr_tree<w, l, false, false>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
@@ -1032,6 +1270,7 @@ int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, size_t bytes) {
 #define X(w, l) if (waves == w && lanes == l) { \
     const void* fs[] = {(const void*)k_nr_tree<w, l, true, true>, (const void*)k_nr_tree<w, l, true, true, nr_res(w, l, true)>, \
                         (const void*)k_nr_tree<w, l, true, false>, (const void*)k_nr_tree<w, l, true, false, nr_res(w, l, true)>, \
+                        (const void*)k_nr_tree<w, l, true, false, nr_res_hg(w, l)>, \
                         (const void*)k_nr_tree<w, l, false, false>, (const void*)k_nr_tree<w, l, false, false, nr_res(w, l, false)>}; \
     for (const void* f : fs) if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1; \
     return 0; }
@@ -1045,10 +1284,14 @@ void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, 
 // do_profiles: next profile row + noise for the envs queued in adv_row; do_commit: res_bus commit of
 // the envs flagged by the preceding k_nr_tree launch
 void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, hipStream_t st) {
-  const int pairs = do_profiles ? ((d.ns + 1) >> 1) + 2 * ((d.nl + 1) >> 1) : 0;
-  const int rows = pairs + (do_commit ? d.nb : 0);
-  if (rows == 0) return;
-  hipLaunchKernelGGL(k_advance, dim3((d.B + 255) / 256, rows), dim3(256), 0, st, d, add_noise, do_profiles);
+  if (!do_profiles && !do_commit) return;
+  const int rows = (do_profiles ? ((d.ns + 1) >> 1) : 0) + d.nb;
+  hipLaunchKernelGGL(k_advance, dim3((d.B + 255) / 256, rows), dim3(256), 0, st, d, add_noise, do_profiles, do_commit);
+}
+void launch_inject_sgen(const Dev& d, int mode, const void* actions, int dtype, int add_noise, hipStream_t st) {
+  const dim3 grid((d.B + 255) / 256, d.n_sgb);
+  if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_inject_sgen<float>, grid, dim3(256), 0, st, d, mode, (const float*)actions, add_noise);
+  else hipLaunchKernelGGL(k_inject_sgen<double>, grid, dim3(256), 0, st, d, mode, (const double*)actions, add_noise);
 }
 void launch_gather(const Dev& d, const double* base, const int32_t* rows, const double* scales, double scale_all,
                    const int32_t* x_ptr, const int32_t* x_row, void* out, int dtype, int C, hipStream_t st) {

@@ -33,6 +33,10 @@ struct Dev {
   const int32_t *load_ptr, *load_idx, *sgen_ptr, *sgen_idx;
   const double *shunt_p, *shunt_q;
   const double *load_scale, *sgen_scale;     // [nl], [ns] element scaling * in_service (runpp sees p, q * scaling)
+  // buses with sgens ("PV buses", n_sgb of them: positions sgb_pos, inverse sgb_of_pos[nb] or -1) and buses with loads but no
+  // sgens (lb_pos, n_lb): k_inject_sgen works on the former; bus_ld [n_sgb][Bp] pairs = load part (P, Q) of their injection
+  const int32_t *sgb_pos, *sgb_of_pos, *lb_pos; int32_t n_sgb, n_lb;
+  double* bus_ld;
   const LineFlow* lines;
   const int32_t* root_children; const double* root_y; int32_t n_root_children;   // children of the slack: position, Y_root,k
   double yrr0, yrr1;
@@ -77,6 +81,8 @@ struct Dev {
 
 void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,
                    const double* pv, const double* q, int add_noise, hipStream_t st);
+// step()/reset() form of the injection: PV buses only (the rest of Sbus is kept up to date by k_advance)
+void launch_inject_sgen(const Dev& d, int mode, const void* actions, int dtype, int add_noise, hipStream_t st);
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
 int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, size_t bytes);   // -2: (waves, lanes) not instantiated
 // dynamic LDS of k_nr_tree (W waves, L envs per workgroup => Wt = W*64/L workers), in pair rows of L x 16 bytes:

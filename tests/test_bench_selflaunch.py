@@ -61,7 +61,11 @@ def test_bench_single_gpu_line_has_live_traffic_and_cpu_baseline():
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     c = j["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == len(os.sched_getaffinity(0)) and c["value"] >= c["single_core_value"] > 0
+    assert c["kind"] == "port" and 1 <= c["cores"] <= len(os.sched_getaffinity(0)) and c["value"] >= c["single_core_value"] > 0
+    assert c["all_cores_batched_numpy"]["value"] > 0 and c["all_cores_one_env_per_process"]["processes"] == c["cores"]
+    assert j["repeats"] >= 3 and j["timed_seconds_total"] >= 0.5 and j["steps"] == 20
+    assert j["ms_per_step_repeats"]["min"] <= j["ms_per_step"] <= j["ms_per_step_repeats"]["max"]
+    assert "resets_in_timed_region" in j["config"]
     ro = j["roofline"]
-    assert ro["bound"] == "latency" and ro["roof"] == "hbm" and abs(ro["frac"] - ro["achieved"] / 8000.0) < 1e-12
+    assert ro["bound"] == "hbm" and "latency" in ro["limited_by"] and abs(ro["frac"] - ro["achieved"] / 8000.0) < 1e-12
     assert ro["traffic_detail"] is not None and (ro["traffic_detail"].get("bytes") or ro["traffic_detail"].get("error"))

@@ -130,9 +130,23 @@ def test_scaling_in_service_shunt_steps_and_switches():
     assert np.array_equal(a.sgen_scaling, [1.0, 0.5])
     assert a.shunt_q_mvar[0] == -0.5 and a.shunt_p_mw[0] == 0.0               # q_mvar * step
     assert a.line_in_service.all()
-    pnet["switch"].loc[0, "closed"] = False                                     # an open line switch takes the line out
-    b = from_pandapower(pnet)
-    assert list(b.line_in_service) == [1, 1, 1, 0]
+    # An OPEN line switch: pandapower (neglect_open_switch_branches=False) keeps the line energised from its closed end, so it
+    # still draws its charging current.  Dropping the line is exact only without shunt terms or when both ends are open;
+    # anything else is refused.
+    pnet["switch"].loc[0, "closed"] = False
+    with pytest.raises(NotImplementedError, match="open switch at one end"):
+        from_pandapower(pnet)
+    both = substation_net()
+    f3, t3 = int(both.line["from_bus"].iloc[3]), int(both.line["to_bus"].iloc[3])
+    both["switch"] = pd.DataFrame({"bus": [f3, t3], "element": [3, 3], "et": ["l", "l"], "type": ["LBS", "LBS"], "closed": [False, False]})
+    assert list(from_pandapower(both).line_in_service) == [1, 1, 1, 0]           # open at both ends: out
+    bare = substation_net()
+    bare["switch"].loc[0, "closed"] = False
+    bare.line.loc[bare.line.index[3], ["c_nf_per_km"]] = 0.0
+    if "g_us_per_km" in bare.line:
+        bare.line.loc[bare.line.index[3], ["g_us_per_km"]] = 0.0
+    b = from_pandapower(bare)
+    assert list(b.line_in_service) == [1, 1, 1, 0]                               # no shunt terms: nothing flows, out
     # scaled elements enter the power flow scaled: compare with hand-scaled inputs on an unscaled copy
     pl, ql = pnet.load["p_mw"].to_numpy(), pnet.load["q_mvar"].to_numpy()
     ps, qs = pnet.sgen["p_mw"].to_numpy(), pnet.sgen["q_mvar"].to_numpy()

@@ -897,3 +897,43 @@ def test_every_nr_launch_geometry_gives_the_same_bits(case, geoms, monkeypatch):
         else:
             assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2]), (w, l, lean)
     assert ref is not None
+
+
+@pytest.mark.parametrize("case", ["case33", "case141", "case322"])
+def test_pv_bus_injection_equals_all_bus_injection(case, monkeypatch):
+    """step() / reset() inject through k_inject_sgen — PV buses only, k_advance keeps the Sbus entries of all other buses and
+    the load part of the PV buses current — while MAPDN_INJECT_FULL=1 keeps the all-bus k_inject of round 2.  Same expressions,
+    same order: bit-identical over noisy episodes with an unsolvable step, per-env auto-reset boundaries (an auto-resetting env
+    refreshes all its loads inside k_inject_sgen) and a mapdn_solve_only call in between (which leaves Sbus stale)."""
+    B, limit = 70, 5
+    kw = dict(episode_limit=limit, auto_reset=True)
+    net, prof, fast = make(case, B, **kw)
+    monkeypatch.setenv("MAPDN_INJECT_FULL", "1")
+    _, _, full = make(case, B, **kw)
+    monkeypatch.delenv("MAPDN_INJECT_FULL")
+    of, _ = fast.reset(); ou, _ = full.reset()
+    assert torch.equal(of, ou)
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(23)
+    rng = np.random.default_rng(2)
+    n_resets = 0
+    for t in range(14):
+        act = (torch.rand(B, net.n_sgen, device="cuda:0", generator=gen, dtype=torch.float64) * 2 - 1) * SCALE[case]
+        if t == 3:
+            act[11] = 60.0
+        if t == 6:                                   # a solve on explicit inputs in between: Sbus no longer reflects cur_pl / cur_ql
+            rows = rng.integers(0, prof.n_rows, B)
+            qs = rng.uniform(-0.3, 0.3, (B, net.n_sgen)) * prof.pv[rows]
+            a = fast.solve(prof.load_p[rows], prof.load_q[rows], prof.pv[rows], qs)
+            b = full.solve(prof.load_p[rows], prof.load_q[rows], prof.pv[rows], qs)
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
+        ra, ta, ia = fast.step(act); rb, tb, ib = full.step(act)
+        assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(ia, ib), t
+        assert torch.equal(fast.get_obs(), full.get_obs()) and torch.equal(fast.get_state(), full.get_state()), t
+        ma = fast.auto_reset_mask(); assert torch.equal(ma, full.auto_reset_mask())
+        n_resets += int(ma.sum().item())
+        fa, fb = fast.results(), full.results()
+        assert all(torch.equal(fa[k], fb[k]) for k in fa), t
+        la, lb = fast.loads(), full.loads()
+        assert torch.equal(la[0], lb[0]) and torch.equal(la[1], lb[1])
+    assert n_resets >= 2 * B
+    fast.close(); full.close()

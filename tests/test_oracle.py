@@ -151,3 +151,53 @@ def test_barriers():
     assert abs(b[0] - (2 * 0.1 - 0.095)) < 1e-12 and abs(b[2] - (-0.01 / np.sqrt(2 * np.pi * 0.01) + 0.04)) < 1e-12
     bump = BARRIERS["bump"](np.array([0.5, 1.0, 2.0, 3.5]))
     assert abs(bump[0] - np.exp(-1 / (1 - 0.5 ** 4))) < 1e-15 and bump[1] == 0 and abs(bump[2] - np.exp(-1)) < 1e-15 and bump[3] == 0
+
+
+@pytest.mark.parametrize("case", ["case33", "case141", "case322"])
+def test_batched_numpy_newton_matches_the_one_env_solver(case):
+    """oracle/batched_np.py (bench.py's batched CPU baseline): same Newton iterates as runpp_restated — identical iteration
+    counts and convergence flags per env (one env of the batch is driven past loadability), |dV| at rounding level."""
+    from oracle.batched_np import BatchedRunpp
+    from oracle.pp_restated import runpp_restated
+    net, prof = make_case(case)
+    rng = np.random.default_rng(4)
+    B = 12
+    rows = rng.integers(0, prof.n_rows, B)
+    pv = prof.pv[rows]
+    qs = rng.uniform(-0.6, 0.6, (B, net.n_sgen)) * np.sqrt(prof.s_max() ** 2 - pv ** 2)
+    pl, ql = prof.load_p[rows].copy(), prof.load_q[rows]
+    pl[5] *= 40.0
+    res = BatchedRunpp(net)(pl, ql, pv, qs)
+    for e in range(B):
+        r = runpp_restated(net, pl[e], ql[e], pv[e], qs[e])
+        assert r.converged == res[e].converged and r.iterations == res[e].iterations
+        if r.converged:
+            assert np.abs(r.V - res[e].V).max() < 1e-12
+            assert np.abs(r.pl_mw - res[e].pl_mw).max() < 1e-9 and np.abs(r.p_mw - res[e].p_mw).max() < 1e-9
+    assert not res[5].converged and res[5].iterations == 10
+
+
+def test_batched_oracle_shard_steps_like_independent_oracle_envs():
+    """bench.py's BatchedOracleShard (env logic per env, power flows batched) against plain oracle envs"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from oracle.env_restated import VoltageControlOracle
+    case, E = "case33", 5
+    sh = bench.BatchedOracleShard(case, E, first_env_id=3)
+    net, prof = make_case(case)
+    plain = [VoltageControlOracle(net, prof, bench._oracle_args(case), env_id=3 + e) for e in range(E)]
+    rng = np.random.default_rng(0)
+    for t in range(6):
+        act = rng.uniform(-0.8, 0.8, (E, net.n_sgen))
+        if t == 3:
+            act[2] = 60.0                       # unsolvable -> terminates -> both sides reset that env
+        out = sh.step(act)
+        for e, o in enumerate(plain):
+            r, term, info = o.step(act[e])
+            o.get_obs()
+            if term:
+                o.reset()
+            assert abs(r - out[e][0]) < 1e-9 and term == out[e][1]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU call 1: full GPU suite (new shipped-config / literature / reference-fixture tests), baseline bench, cycle stamps
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r03_c1
+OUT=$R/gpurun_out/${1:-r03_c2}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
