@@ -141,8 +141,12 @@ const char* mapdn_last_error(const mapdn_handle* h);
  * Nets beyond that and nets with buses not connected to the ext_grid return MAPDN_E_TOPOLOGY.
  * device == -1 builds a host-only handle (plan, dims, ybus/obs-index export; no device calls).
  * Tuning knobs read from the environment at create time (defaults are chosen per topology):
- *   MAPDN_NR_WAVES (1/2/4/8), MAPDN_NR_LANES (4/8/16/32)   waves and envs per NR workgroup
- *   MAPDN_NR_H_LDS, MAPDN_NR_LINE_LDS (0/1)                keep the h factors / net.line constants in LDS
+ *   MAPDN_NR_WAVES (1/2/4/8), MAPDN_NR_LANES (8/16/32)     waves and envs per NR workgroup
+ *   MAPDN_NR_LEAN (0/1)                                    1: only voltages + hand-off slots in LDS (several workgroups per CU)
+ *   MAPDN_NR_H_LDS, MAPDN_NR_G_LDS, MAPDN_NR_REC_LDS,      keep the h / G factors, the step records, the flat-start constants,
+ *   MAPDN_NR_FLAT_LDS, MAPDN_NR_LINE_LDS (0/1)             the net.line constants in LDS (default: whatever fits, in that order)
+ *   MAPDN_INJECT_FULL (0/1)                                1: step() / reset() rebuild Sbus on every bus (k_inject) instead of on
+ *                                                          the PV buses only (k_inject_sgen); same bits, for A/B runs and tests
  *   MAPDN_NR_CHECK_DX (default 1e-7)                       Newton-step size below which the next sweep is
  *                                                          first tried mismatch-only (never changes results)
  *   MAPDN_NR_CHECK_QUAD (default 1)                        safety factor of the second predictor, ||F||^3/||F_prev||^2 < tol / factor
@@ -199,7 +203,10 @@ int mapdn_get_loads(mapdn_handle* h, double* load_p, double* load_q, void* strea
 int mapdn_get_start_rows(mapdn_handle* h, int64_t* start_rows, void* stream);
 
 /* sum_rewards of the running episode (voltage_control_env.py:203) for every env: device f64 [B] */
-/* uint8 [n_envs]: 1 for the envs that the last mapdn_step call (re)started (auto_reset == 1), else 0. */
+/* uint8 [n_envs]: 1 for the envs that the last mapdn_step call (re)started (auto_reset == 1), else 0.  An env whose restart
+ * power flow does not solve is NOT reported here: it stays frozen (reward 0, terminated 1) and draws a new start on the next
+ * call, like the reference's `while not solvable` loop (voltage_control_env.py:108); until then its load / PV tables already
+ * hold the rejected start's values while res_bus still holds the previous episode's voltages. */
 int mapdn_get_auto_reset_mask(mapdn_handle* h, uint8_t* mask, void* stream);
 
 int mapdn_get_returns(mapdn_handle* h, double* returns, void* stream);
@@ -254,6 +261,10 @@ int mapdn_policy_forward(const float* obs, const float* hid_in, const float* w1,
                          const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                          const float* w2, const float* b2, float* means, float* hid_out, int32_t rows, int32_t n_agents,
                          int32_t obs_dim, int32_t id_dim, float ln_eps, void* stream);
+
+/* 1 when mapdn_policy_forward has a launch shape for this observation width (the parameter set and a tile's activations must
+ * fit the 160 KB LDS of a CU: obs_dim up to ~2 400 columns without ids), else 0 — callers then keep their own forward. */
+int mapdn_policy_forward_fits(int32_t obs_dim, int32_t id_dim);
 
 /* counters (host, synchronises the given stream): number of envs whose last reset exhausted
  * max_tries; mean / max NR iterations of the last solve */

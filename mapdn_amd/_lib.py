@@ -31,6 +31,7 @@ EXPORTS = (
     "mapdn_step", "mapdn_get_start_rows", "mapdn_get_returns", "mapdn_get_obs", "mapdn_get_state", "mapdn_get_results", "mapdn_get_loads",
     "mapdn_solve_only", "mapdn_get_ybus_dense", "mapdn_get_obs_index", "mapdn_get_schedule", "mapdn_get_flat_factors", "mapdn_stats", "mapdn_nr_timing",
     "mapdn_nr_time_ms", "mapdn_get_auto_reset_mask", "mapdn_dense_solve", "mapdn_step_obs", "mapdn_get_sparse_program", "mapdn_policy_forward",
+    "mapdn_policy_forward_fits",
 )
 
 _pd = C.POINTER(C.c_double)
@@ -125,6 +126,7 @@ def load():
     lib.mapdn_get_flat_factors.argtypes = [vp, _pd, _pi]
     lib.mapdn_get_sparse_program.argtypes = [vp, C.c_int32, _pi, _pi, _pi, _pi]
     lib.mapdn_policy_forward.argtypes = [vp] * 14 + [C.c_int32] * 4 + [C.c_float, vp]
+    lib.mapdn_policy_forward_fits.argtypes = [C.c_int32, C.c_int32]
     lib.mapdn_dense_solve.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, vp]
     lib.mapdn_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int32), vp]
     lib.mapdn_nr_timing.argtypes = [vp, C.c_int32]

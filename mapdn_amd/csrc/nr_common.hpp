@@ -217,10 +217,11 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
     return;
   }
   if (d.resetting[e]) {                           // auto_reset: this call was the env's reset(); no transition to report
-    reward[e] = 0.0; terminated[e] = 0;
+    reward[e] = 0.0;
     for (int c = 0; c < MAPDN_N_INFO; ++c) info[(size_t)e * MAPDN_N_INFO + c] = 0.0;
     d.draw[e] = bk_draw + 1;                      // (a start that does not solve is re-drawn by the next call, :108)
-    if (conv) { d.steps[e] = 1; d.sum_rewards[e] = 0.0; d.done[e] = 0; }
+    if (conv) { terminated[e] = 0; d.steps[e] = 1; d.sum_rewards[e] = 0.0; d.done[e] = 0; }
+    else { terminated[e] = 1; d.resetting[e] = 0; }   // the restart did not solve: still frozen, NOT reported as restarted
     return;
   }
   double tot[10];

@@ -165,18 +165,32 @@ k_policy_fwd(const float* __restrict__ obs, const float* __restrict__ hid_in, co
 
 }  // namespace mapdn
 
+// launch shape of k_policy_fwd for an observation width: threads per workgroup (512 / 256), whether the one-hot id columns of
+// fc1 are staged in LDS, and the dynamic LDS — or false when no variant fits the 160 KB of a CU (very wide observations)
+static bool policy_geometry(int obs_dim, int id_dim, int& pt, int& ids_lds, size_t& lds) {
+  using namespace mapdn;
+  const int kc1 = (obs_dim + 15) / 16;
+  auto lds_for = [&](int p, int il) { return ((size_t)4 * kc1 * 64 + 2 * 12 * 4 * 64) * 16 + ((size_t)(il ? id_dim : 0) * PH + 4 * PH + 2 * 3 * PH + (p / 64) * 16 * 68) * sizeof(float); };
+  for (int p : {512, 256})
+    for (int il : {1, 0})
+      if (lds_for(p, il) <= (size_t)160 * 1024) { pt = p; ids_lds = il; lds = lds_for(p, il); return true; }
+  return false;
+}
+
+extern "C" int mapdn_policy_forward_fits(int32_t obs_dim, int32_t id_dim) {
+  int pt, il; size_t lds;
+  return obs_dim >= 1 && id_dim >= 0 && policy_geometry(obs_dim, id_dim, pt, il, lds) ? 1 : 0;
+}
+
 extern "C" int mapdn_policy_forward(const float* obs, const float* hid_in, const float* w1, const float* b1, const float* ln_g,
                                     const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                                     const float* w2, const float* b2, float* means, float* hid_out, int32_t rows, int32_t n_agents,
                                     int32_t obs_dim, int32_t id_dim, float ln_eps, void* stream) {
   using namespace mapdn;
   if (!obs || !hid_in || !w1 || !means || !hid_out || rows < 1 || n_agents < 1 || obs_dim < 1 || id_dim < 0) return MAPDN_E_INVALID;
-  const int kc1 = (obs_dim + 15) / 16;
-  auto lds_for = [&](int pt, int il) { return ((size_t)4 * kc1 * 64 + 2 * 12 * 4 * 64) * 16 + ((size_t)(il ? id_dim : 0) * PH + 4 * PH + 2 * 3 * PH + (pt / 64) * 16 * 68) * sizeof(float); };
   int pt = 512, ids_lds = 1;
-  if (lds_for(512, 1) > 160 * 1024) { if (lds_for(512, 0) <= 160 * 1024) ids_lds = 0; else pt = 256; }
-  const size_t lds = lds_for(pt, ids_lds);
-  if (lds > 160 * 1024) return MAPDN_E_INVALID;
+  size_t lds = 0;
+  if (!policy_geometry(obs_dim, id_dim, pt, ids_lds, lds)) return MAPDN_E_INVALID;   // callers ask mapdn_policy_forward_fits first
   // (per call, not once per process: the attribute belongs to the current device)
   const void* fn = pt == 512 ? (const void*)k_policy_fwd<512> : (const void*)k_policy_fwd<256>;
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MAPDN_E_HIP;

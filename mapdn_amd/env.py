@@ -442,8 +442,8 @@ class VoltageControl(MultiAgentEnv):
             obs, state = self._b.reset(reset_time=reset_time)
             if self._b.stats()["reset_failures"] == 0:
                 return self._obs_list(obs), state[0].cpu().numpy()
-            if not reset_time:
-                break
+            # (reset_time=False keeps the time stamp, but every pass still draws new noise and a new initial action, :118-122,
+            # so it can succeed at the same stamp: keep looping like the reference, up to the same cap)
         raise RuntimeError("reset(): no solvable start found (the reference would keep looping at voltage_control_env.py:108)")
 
     def manual_reset(self, day, hour, interval):

@@ -133,6 +133,7 @@ class DDPGNet(nn.Module):
             raise KeyError(alg)                                    # models/model_registry.py:14-25
         self.args, self.alg = args, alg
         self.n_, self.obs_dim, self.act_dim, self.hid_dim = args.agent_num, args.obs_size, args.action_dim, args.hid_size
+        self._fused_fits = None                   # does the one-launch HIP policy forward have a launch shape for this obs width?
         n, o, a = self.n_, self.obs_dim, self.act_dim
         ids = n if args.agent_id else 0
         self.batchnorm = nn.BatchNorm1d(n)
@@ -177,9 +178,14 @@ class DDPGNet(nn.Module):
         """the one-launch HIP forward (libmapdn_hip.so: mapdn_policy_forward) covers the reference's default agent — shared
         parameters, LayerNorm, ReLU, hidden size 64, one action — for inference on the GPU in fp32"""
         a = self.args
-        return (not torch.is_grad_enabled() and obs.is_cuda and obs.dtype == torch.float32 and last_hid.dtype == torch.float32
+        if not (not torch.is_grad_enabled() and obs.is_cuda and obs.dtype == torch.float32 and last_hid.dtype == torch.float32
                 and a.shared_params and a.layernorm and a.hid_activation == "relu" and self.hid_dim == 64 and self.act_dim == 1
-                and os.environ.get("MAPDN_FUSED_POLICY", "1") != "0")
+                and os.environ.get("MAPDN_FUSED_POLICY", "1") != "0"):
+            return False
+        if self._fused_fits is None:              # the parameter set + activations of one tile must fit a CU's LDS (wide observations,
+            from . import _lib                    # e.g. history > 1 on the 322-bus net, do not): those keep the PyTorch modules
+            self._fused_fits = bool(_lib.load().mapdn_policy_forward_fits(self.obs_dim, self.n_ if a.agent_id else 0))
+        return self._fused_fits
 
     def _fused_policy(self, obs: torch.Tensor, last_hid: torch.Tensor):
         from . import _lib
@@ -188,7 +194,11 @@ class DDPGNet(nn.Module):
         obs_c, hid_c = obs.contiguous(), last_hid.contiguous()
         means = torch.empty(b, n, 1, dtype=torch.float32, device=obs.device)
         hid = torch.empty(b, n, self.hid_dim, dtype=torch.float32, device=obs.device)
-        P = lambda t: t.detach().contiguous().data_ptr()
+        keep = []                                  # contiguous views stay referenced until the launch is enqueued
+
+        def P(t):
+            keep.append(t.detach().contiguous())
+            return keep[-1].data_ptr()
         ids = n if self.args.agent_id else 0
         with torch.cuda.device(obs.device):
             _lib.check(_lib.load().mapdn_policy_forward(
