@@ -25,7 +25,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SCALE = {"case33": 0.8, "case141": 0.6, "case322": 0.8}     # reference train.py:34-42
+SCALE = {"case33": 0.8, "case141": 0.6, "case322": 0.8, "case141_deep": 0.6}     # reference train.py:34-42 (+ the depth-stress topology)
 HBM_PEAK_GBS = 8000.0                                         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 FP64_PEAK_TFLOPS = 78.6                                       # MI355X f64 vector peak
 NR_KERNEL = "k_nr"                                            # substring of the dominant kernel's name

@@ -7,9 +7,17 @@ envs per GPU through the HIP hot path, GPU-resident replay, DDPG updates, all on
         examples/train_ddpg.py --case case322 --envs 8192          # 65536 envs, DP learner over RCCL
 
 Mirrors train.py of the reference (env args from args/env_args/var_voltage_control.yaml, per-scenario
-action scale train.py:34-42, `model.pt` checkpoint train.py:119).  With --envs 1 the update schedule
-is the reference's; with B envs one batched step inserts B transitions, so batch size / buffer size
-are scaled by the flags below.  Prints one JSON line per episode on rank 0.
+action scale train.py:34-42, `model.pt` checkpoint train.py:119).
+
+Update intensity.  The reference (one env) runs 10 value + 1 policy update of batch 32 every 60 env-steps
+(models/model.py:39-52, args/default.yaml): 11 * 32 / 60 = 5.87 sampled transitions per env-step.  With B envs one
+batched step inserts B transitions, so
+  --intensity reference (default): the same 11 updates per 60 batched steps on batches of 32 * B transitions — a
+        contiguous replay window of 32 consecutive steps of every env, i.e. per env exactly the reference's window —
+        = 5.87 sampled transitions per env-step, the reference's ratio;
+  --intensity light: batches of --batch-size transitions (round 2's setting: 11 * 4096 / (60 * B) per env-step);
+  --updates-per-env-step X: batches of 32 * B, update epochs scaled so that X transitions are sampled per env-step.
+Prints one JSON line per episode on rank 0 (and appends it to --log).
 """
 import argparse
 import json
@@ -31,7 +39,10 @@ def main():
     ap.add_argument("--envs", type=int, default=8192, help="envs per GPU")
     ap.add_argument("--episodes", type=int, default=3)
     ap.add_argument("--max-steps", type=int, default=240)
-    ap.add_argument("--batch-size", type=int, default=4096, help="transitions per update (contiguous replay window)")
+    ap.add_argument("--batch-size", type=int, default=4096, help="transitions per update with --intensity light")
+    ap.add_argument("--intensity", default="reference", choices=["reference", "light"])
+    ap.add_argument("--updates-per-env-step", type=float, default=None, help="sampled transitions per env-step (reference: 5.87)")
+    ap.add_argument("--log", default=None, help="append the JSON lines to this file as well")
     ap.add_argument("--replay-steps", type=int, default=64, help="replay capacity in batched steps (x envs transitions)")
     ap.add_argument("--update-freq", type=int, default=60)
     ap.add_argument("--voltage-barrier", default="bowl")
@@ -54,9 +65,20 @@ def main():
     env_args = dict(episode_limit=a.max_steps, action_scale=SCALE[a.case], action_bias=0.0,
                     voltage_barrier_type=a.voltage_barrier, seed=0)
     env = VoltageControlBatch(net, prof, env_args, n_envs=a.envs, device=dev, env_id_offset=rank * a.envs, copy=True)
+    ref_ratio = 11 * 32 / 60.0
+    v_ep, p_ep = 10, 1
+    if a.intensity == "light" and a.updates_per_env_step is None:
+        batch = a.batch_size
+    else:
+        batch = 32 * a.envs                                       # 32 consecutive steps of every env
+        if a.updates_per_env_step is not None:
+            total = a.updates_per_env_step * a.update_freq * a.envs / batch
+            p_ep = max(1, round(total / 11)); v_ep = max(1, round(total - p_ep))
+    ratio = (v_ep + p_ep) * batch / (a.update_freq * a.envs)
     args = make_alg_args(env.n_agents, env.obs_size, env.n_actions, SCALE[a.case], 0.0, max_steps=a.max_steps,
-                         batch_size=a.batch_size, replay_buffer_size=a.envs * a.replay_steps,
-                         behaviour_update_freq=a.update_freq, target_update_freq=2 * a.update_freq, num_eval_episodes=a.envs)
+                         batch_size=batch, replay_buffer_size=a.envs * max(a.replay_steps, 2 * batch // a.envs),
+                         behaviour_update_freq=a.update_freq, target_update_freq=2 * a.update_freq, num_eval_episodes=a.envs,
+                         value_update_epochs=v_ep, policy_update_epochs=p_ep)
     trainer = PGTrainer(args, a.alg, env, device=dev)
     for ep in range(a.episodes):
         torch.cuda.synchronize(dev)
@@ -67,6 +89,8 @@ def main():
         dt = time.perf_counter() - t0
         if rank == 0:
             line = {"episode": ep, "alg": a.alg, "case": a.case, "n_gpus": world, "envs_per_gpu": a.envs,
+                    "intensity": a.intensity, "batch_size": batch, "value_epochs": v_ep, "policy_epochs": p_ep,
+                    "sampled_transitions_per_env_step": ratio, "reference_ratio": ref_ratio,
                     "env_steps_per_s": world * a.envs * a.max_steps / dt, "seconds": dt,
                     "replay_transitions": len(trainer.replay_buffer),
                     "hbm_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
@@ -74,6 +98,9 @@ def main():
                 "mean_train_reward", "mean_train_value_loss", "mean_train_policy_loss", "mean_train_totally_controllable_ratio",
                 "mean_train_q_loss")})
             print(json.dumps(line), flush=True)
+            if a.log:
+                with open(a.log, "a") as f:
+                    f.write(json.dumps(line) + "\n")
     if a.save and rank == 0:
         trainer.save(a.save)
     env.close()

@@ -28,6 +28,7 @@ struct mapdn_handle {
   bool sbus_stale = true;         // Sbus / bus_ld do not reflect cur_pl / cur_ql (fresh handle, after mapdn_solve_only): the next
                                   // injection runs the all-bus kernel; MAPDN_INJECT_FULL=1 keeps it that way (A/B, tests)
   bool inject_full = false;
+  uint32_t sb_base = 0, sb_bytes = 0;   // the two Sbus buffers of nrbuf: d.sb_off / d.sb_off_alt alternate between them
   size_t lds_bytes = 0;
   int32_t *obs_rows = nullptr, *state_rows = nullptr, *iota_idx = nullptr, *vm_row = nullptr, *va_row = nullptr;
   int32_t *obs_xptr = nullptr, *obs_xrow = nullptr;
@@ -156,14 +157,16 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   UP(load_ptr, P.load_ptr); UP(load_idx, P.load_idx); UP(sgen_ptr, P.sgen_ptr); UP(sgen_idx, P.sgen_idx);
   UP(shunt_p, P.shunt_p); UP(shunt_q, P.shunt_q); UP(load_scale, P.load_scale); UP(sgen_scale, P.sgen_scale);
   {
-    std::vector<int32_t> sgb, sgb_of(P.nb, -1), lb;
+    std::vector<int32_t> sgb, sgb_of(P.nb, -1), lb, ldb;
     for (int k = 0; k < P.nb; ++k) {
+      if (P.load_ptr[k + 1] > P.load_ptr[k]) ldb.push_back(k);
       if (P.sgen_ptr[k + 1] > P.sgen_ptr[k]) { sgb_of[k] = (int32_t)sgb.size(); sgb.push_back(k); }
       else if (P.load_ptr[k + 1] > P.load_ptr[k]) lb.push_back(k);
     }
-    d.n_sgb = (int32_t)sgb.size(); d.n_lb = (int32_t)lb.size();
+    d.n_sgb = (int32_t)sgb.size(); d.n_lb = (int32_t)lb.size(); d.n_ldb = (int32_t)ldb.size();
     if (lb.empty()) lb.push_back(0);
-    UP(sgb_pos, sgb); UP(sgb_of_pos, sgb_of); UP(lb_pos, lb);
+    if (ldb.empty()) ldb.push_back(0);
+    UP(sgb_pos, sgb); UP(sgb_of_pos, sgb_of); UP(lb_pos, lb); UP(ldb_pos, ldb);
     rc = dalloc(h, &d.bus_ld, (size_t)2 * d.n_sgb * d.Bp); if (rc) return rc;
     if (const char* s_ = getenv("MAPDN_INJECT_FULL")) h->inject_full = atoi(s_) != 0;
   }
@@ -238,12 +241,13 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   // a single buffer resource addresses it
   auto alloc_nrbuf = [&](size_t fb_rows, size_t nblk, const std::vector<int32_t>& sbi) -> int {
     const size_t sb_off = fb_rows * Bp * 16;
-    const size_t vout_off = sb_off + nblk * Bp * 16;
+    const size_t vout_off = sb_off + 2 * nblk * Bp * 16;        // two Sbus buffers
     const size_t bytes = vout_off + (size_t)VOF * (P.n + 1) * Bp * sizeof(double);
     if (bytes >= (size_t)0xFFFFFFFFu) { h->err = "env batch too large: NR scratch exceeds the 4 GiB one buffer resource addresses; use fewer envs per handle"; return MAPDN_E_INVALID; }
     rc = dalloc(h, &d.nrbuf, bytes / sizeof(double)); if (rc) return rc;
     d.nrbuf_bytes = (uint32_t)bytes;
-    d.sb_off = (uint32_t)sb_off;
+    d.sb_off = (uint32_t)sb_off; d.sb_off_alt = (uint32_t)(sb_off + nblk * Bp * 16);
+    h->sb_base = d.sb_off; h->sb_bytes = (uint32_t)(nblk * Bp * 16);
     d.r_vout = (uint32_t)(vout_off / (Bp * sizeof(double)));
     rc = dupload(h, &d.sb_index, sbi); if (rc) return rc;
     std::vector<double> row(Bp, d.vroot);   // slack entry of Vout: V = vroot + 0j (angle 0 from the memset)
@@ -484,10 +488,10 @@ int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, i
   const Dev& d = h->d;
   for (int t = 0; t < max_tries; ++t) {
     launch_reset_begin(d, start_rows, t == 0, st);
-    launch_advance(d, add_noise, 1, 0, st);
+    launch_advance(d, add_noise, 1, 0, d.sb_off, st);   // the advance precedes the solve here: it fills the buffer the solve reads
     inject_launch(h, MODE_RESET, nullptr, MAPDN_F64, add_noise, st);
     nr_launch(h, MODE_RESET, nullptr, nullptr, nullptr, st);
-    launch_advance(d, 0, 0, 1, st);              // res_bus commit of the envs that found a solvable start
+    launch_advance(d, 0, 0, 1, d.sb_off, st);    // res_bus commit of the envs that found a solvable start
   }
   HIPCHK(h, hipGetLastError());
   h->was_reset = true;
@@ -508,7 +512,8 @@ int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int3
   // (Running the profile advance on a side stream beside the NR kernel was measured: the fork/join events
   // cost more than the ~6 us they hide, 29.5 M vs 31.5 M env-steps/s, so the step stays on one stream.)
   nr_launch(h, MODE_STEP, reward, terminated, info, st);
-  launch_advance(d, add_noise, 1, 1, st);        // next profile row + res_bus commit in one wide launch
+  launch_advance(d, add_noise, 1, 1, d.sb_off_alt, st);   // next profile row (-> the Sbus buffer of the next solve) + res_bus commit
+  std::swap(h->d.sb_off, h->d.sb_off_alt);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
 }
@@ -527,7 +532,8 @@ int mapdn_step_obs(mapdn_handle* h, const void* actions, int32_t actions_dtype, 
   const int C = h->plan.n_agents * h->plan.obs_size;
   inject_launch(h, MODE_STEP, actions, actions_dtype, add_noise, st);
   nr_launch(h, MODE_STEP, reward, terminated, info, st);
-  launch_advance(d, add_noise, 1, 1, st);        // next profile row + res_bus commit in one wide launch
+  launch_advance(d, add_noise, 1, 1, d.sb_off_alt, st);   // next profile row (-> the Sbus buffer of the next solve) + res_bus commit
+  std::swap(h->d.sb_off, h->d.sb_off_alt);
   launch_gather(d, d.gbuf, h->obs_rows, h->obs_scale, 1.0, h->obs_xptr, h->obs_xrow, obs, obs_dtype, C, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;

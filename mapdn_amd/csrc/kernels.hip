@@ -157,8 +157,10 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
     P -= p * d.sgen_scale[j]; Q -= q * d.sgen_scale[j];
   }
   if (k < d.n) {   // scheduled injection as an (re, im) pair, stored in the order the NR workers consume it
-    double2* sb = (double2*)((char*)d.nrbuf + d.sb_off) + (size_t)d.sb_index[k] * d.Bp + e;
-    *sb = make_double2(-P / d.sn, -Q / d.sn);
+    const size_t o = (size_t)d.sb_index[k] * d.Bp + e;
+    const double2 v = make_double2(-P / d.sn, -Q / d.sn);
+    ((double2*)((char*)d.nrbuf + d.sb_off))[o] = v;
+    if (mode != MODE_SOLVE) ((double2*)((char*)d.nrbuf + d.sb_off_alt))[o] = v;   // both Sbus buffers (see k_advance) are current afterwards
   }
 }
 
@@ -217,7 +219,11 @@ k_inject_sgen(Dev d, int mode, const AT* __restrict__ actions, int add_noise) {
       const int kk = d.lb_pos[i];
       double Ps, Qs;
       load_sum(kk, Ps, Qs);
-      if (kk < d.n) sbp[(size_t)d.sb_index[kk] * d.Bp] = make_double2(-Ps / d.sn, -Qs / d.sn);
+      if (kk < d.n) {                             // a restarting env is not advanced by this call's k_advance: both Sbus buffers
+        const double2 v = make_double2(-Ps / d.sn, -Qs / d.sn);
+        sbp[(size_t)d.sb_index[kk] * d.Bp] = v;
+        ((double2*)((char*)d.nrbuf + d.sb_off_alt))[(size_t)d.sb_index[kk] * d.Bp + e] = v;
+      }
     }
   } else { const double2 v = *bl; P = v.x; Q = v.y; }
   for (int i = d.sgen_ptr[k]; i < d.sgen_ptr[k + 1]; ++i) {
@@ -1032,58 +1038,60 @@ __global__ void __launch_bounds__(256) k_reset_begin(Dev d, const int64_t* __res
 
 // =================================================================================================
 // K9b  advance (+ K6 bus commit) — _set_demand_and_pv (voltage_control_env.py:491-513): next row of the three
-//      profile tables + std/100 * |N(0,1)| noise (:498,503,508).
+//      profile tables + std/100 * |N(0,1)| noise (:498,503,508), and the commit of res_bus for the solve that just finished.
 //      rows [0, npv): thread = (Philox block of the PV table, env): one Philox4x32-10 call + one Box-Muller pair serves two
 //                     adjacent PV columns;
-//      rows [npv, npv + nb): thread = (bus position k, env): first the K6 commit of res_bus for the solve that just
-//                     finished (it reads the Sbus entry of bus k), then the loads of bus k for the NEXT step (element by
-//                     element through the bus's CSR list; a load takes the cosine or sine Box-Muller branch of its
-//                     Philox block) and, with them, what the next k_inject_sgen needs: the finished Sbus entry of a bus
-//                     without sgens, the load part (bus_ld) of a PV bus.  Only thread (k, env) touches Sbus[k] of the env
-//                     in this launch, so the read of the commit precedes the write.
+//      rows [npv, npv + n_ldb): thread = (bus with loads, env): the loads of the bus for the NEXT step, element by element
+//                     through the bus's CSR list (a load takes the cosine or sine Box-Muller branch of its Philox block),
+//                     and with them what the next k_inject_sgen needs — the finished Sbus entry of a bus without sgens,
+//                     the load part (bus_ld) of a PV bus;
+//      then nb rows:  thread = (bus position, env): the K6 commit.
+//      Sbus is DOUBLE-BUFFERED: the commit reads the buffer the solve used (d.sb_off) while the load rows of the same launch
+//      write the buffer of the next solve (`sb_write_off`: the other one in step(), the same one in reset(), where the
+//      advance comes before the solve); the host flips the buffers after every step.
 // =================================================================================================
-__global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_profiles, int do_commit) {
+__global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.B) return;
   const int npv = do_profiles ? ((d.ns + 1) >> 1) : 0;
-  if ((int)blockIdx.y >= npv) {
-    const int k = (int)blockIdx.y - npv;         // elimination position, n == slack
-    const size_t S = (size_t)d.Bp;
-    double2* const sbp = (double2*)((char*)d.nrbuf + d.sb_off) + e;
+  const int nld = do_profiles ? d.n_ldb : 0;
+  const size_t S = (size_t)d.Bp;
+  if ((int)blockIdx.y >= npv + nld) {
     // ---- K6 commit of res_bus (pandapower pfsoln/_extract_results) for envs whose solve was accepted:
     // vm_pu = |V|, va = angle(V), p_mw/q_mvar = bus demand (-Sbus*sn) + shunt*|V|^2, slack = -(V conj(I))*sn
-    if (do_commit && d.commit[e]) {
-      const size_t o = (size_t)d.bus_of_pos[k] * S + e;
-      double v, P, Q;
-      if (k < d.n) {
-        const double* vo = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * k) * S + e;
-        const double2 sb = sbp[(size_t)d.sb_index[k] * S];
-        const double ek = vo[(size_t)VO_E * S], fk = vo[(size_t)VO_F * S];
-        v = sqrt(ek * ek + fk * fk);
-        d.va[o] = atan2(fk, ek);
-        P = -sb.x * d.sn; Q = -sb.y * d.sn;
-      } else {
-        v = d.vroot; d.va[o] = 0.0;
-        double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;     // I = Y_rr V_r + sum_neighbours Y_rk V_k
-        for (int j = 0; j < d.n_root_children; ++j) {
-          const double* cb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * d.root_children[j]) * S + e;
-          const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ec = cb[(size_t)VO_E * S], fc = cb[(size_t)VO_F * S];
-          ir += g * ec - b * fc; ii += g * fc + b * ec;
-        }
-        P = -(d.vroot * ir) * d.sn; Q = (d.vroot * ii) * d.sn;
+    if (!d.commit[e]) return;
+    const int k = (int)blockIdx.y - npv - nld;     // elimination position, n == slack
+    const size_t o = (size_t)d.bus_of_pos[k] * S + e;
+    double v, P, Q;
+    if (k < d.n) {
+      const double* vo = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * k) * S + e;
+      const double2 sb = ((const double2*)((const char*)d.nrbuf + d.sb_off))[(size_t)d.sb_index[k] * S + e];
+      const double ek = vo[(size_t)VO_E * S], fk = vo[(size_t)VO_F * S];
+      v = sqrt(ek * ek + fk * fk);
+      d.va[o] = atan2(fk, ek);
+      P = -sb.x * d.sn; Q = -sb.y * d.sn;
+    } else {
+      v = d.vroot; d.va[o] = 0.0;
+      double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;     // I = Y_rr V_r + sum_neighbours Y_rk V_k
+      for (int j = 0; j < d.n_root_children; ++j) {
+        const double* cb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * d.root_children[j]) * S + e;
+        const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ec = cb[(size_t)VO_E * S], fc = cb[(size_t)VO_F * S];
+        ir += g * ec - b * fc; ii += g * fc + b * ec;
       }
-      d.vm[o] = v;
-      d.res_p[o] = P + d.shunt_p[k] * v * v; d.res_q[o] = Q + d.shunt_q[k] * v * v;
+      P = -(d.vroot * ir) * d.sn; Q = (d.vroot * ii) * d.sn;
     }
-    // ---- next loads of bus k
-    if (!do_profiles) return;
-    const int l0 = d.load_ptr[k], l1 = d.load_ptr[k + 1];
-    if (l0 == l1) return;
-    const int64_t row = d.adv_row[e];
-    if (row < 0 || row >= d.T) return;             // never read outside the table
-    const uint32_t draw = d.adv_draw[e];
+    d.vm[o] = v;
+    d.res_p[o] = P + d.shunt_p[k] * v * v; d.res_q[o] = Q + d.shunt_q[k] * v * v;
+    return;
+  }
+  const int64_t row = d.adv_row[e];
+  if (row < 0 || row >= d.T) return;               // never read outside the table
+  const uint32_t draw = d.adv_draw[e];
+  if ((int)blockIdx.y >= npv) {
+    // ---- next loads of one bus
+    const int k = d.ldb_pos[(int)blockIdx.y - npv];
     double P = 0.0, Q = 0.0;
-    for (int i = l0; i < l1; ++i) {
+    for (int i = d.load_ptr[k]; i < d.load_ptr[k + 1]; ++i) {
       const int li = d.load_idx[i];
       const size_t o = (size_t)li * S + e;
       const double p = profile_value(d, e, row, draw, STREAM_LOAD_P, li, d.ns, add_noise);
@@ -1093,11 +1101,9 @@ __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_pr
     }
     const int jb = d.sgb_of_pos[k];
     if (jb >= 0) ((double2*)d.bus_ld)[(size_t)jb * S + e] = make_double2(P, Q);
-    else if (k < d.n) sbp[(size_t)d.sb_index[k] * S] = make_double2(-P / d.sn, -Q / d.sn);
+    else if (k < d.n) ((double2*)((char*)d.nrbuf + sb_write_off))[(size_t)d.sb_index[k] * S + e] = make_double2(-P / d.sn, -Q / d.sn);
     return;
   }
-  const int64_t row = d.adv_row[e];
-  if (row < 0 || row >= d.T) return;               // never read outside the table
   const int b = blockIdx.y;                        // Philox block of the PV table
   const int j0 = 2 * b, j1 = 2 * b + 1;
   const double* trow = d.table + (size_t)row * d.ncol;
@@ -1105,7 +1111,7 @@ __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_pr
   double v1 = (j1 < d.ns) ? trow[j1] : 0.0;
   if (add_noise) {
     uint32_t x[4];
-    philox4x32_10((uint32_t)(d.env_id_offset + e), d.adv_draw[e], (uint32_t)STREAM_PV, (uint32_t)b, d.seed_lo, d.seed_hi, x);
+    philox4x32_10((uint32_t)(d.env_id_offset + e), draw, (uint32_t)STREAM_PV, (uint32_t)b, d.seed_lo, d.seed_hi, x);
     const double u1 = (u53(x[0], x[1]) + 0.5) * (1.0 / 9007199254740992.0);
     const double u2 = u53(x[2], x[3]) * (1.0 / 9007199254740992.0);
     const double r = sqrt(-2.0 * log(u1));
@@ -1283,10 +1289,10 @@ void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, 
 }
 // do_profiles: next profile row + noise for the envs queued in adv_row; do_commit: res_bus commit of
 // the envs flagged by the preceding k_nr_tree launch
-void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, hipStream_t st) {
-  if (!do_profiles && !do_commit) return;
-  const int rows = (do_profiles ? ((d.ns + 1) >> 1) : 0) + d.nb;
-  hipLaunchKernelGGL(k_advance, dim3((d.B + 255) / 256, rows), dim3(256), 0, st, d, add_noise, do_profiles, do_commit);
+void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off, hipStream_t st) {
+  const int rows = (do_profiles ? ((d.ns + 1) >> 1) + d.n_ldb : 0) + (do_commit ? d.nb : 0);
+  if (rows == 0) return;
+  hipLaunchKernelGGL(k_advance, dim3((d.B + 255) / 256, rows), dim3(256), 0, st, d, add_noise, do_profiles, do_commit, sb_write_off);
 }
 void launch_inject_sgen(const Dev& d, int mode, const void* actions, int dtype, int add_noise, hipStream_t st) {
   const dim3 grid((d.B + 255) / 256, d.n_sgb);

@@ -15,8 +15,9 @@ enum { STREAM_PV = 0, STREAM_LOAD_P = 1, STREAM_LOAD_Q = 2, STREAM_ACTION = 3, S
 //                                step works on): the LU factors (G0,G1) (G2,G3) (h0,h1) written in the forward sweep and
 //                                read back in the backward sweep — only for the factors that do not fit in LDS
 //                                (nr_h_lds / nr_g_lds)
-//   Sbus           [nblk] pair rows   (Re, Im) of the scheduled injection, stored in SCHEDULE order (k_inject writes
-//                                entry sb_index[k]; the NR workers prefetch theirs by (worker,row)); idle steps stay 0
+//   Sbus           2 x [nblk] pair rows   (Re, Im) of the scheduled injection, stored in SCHEDULE order (k_inject writes
+//                                entry sb_index[k]; the NR workers prefetch theirs by (worker,row)); idle steps stay 0;
+//                                two buffers, flipped by the host after every step (k_advance fills the next one)
 //   Vout           [n+1][4] rows of Bp doubles   per position (n == slack): e f |V| angle — the solution (k_nr_tree)
 // Voltages and everything that crosses workers live in LDS during the solve.
 enum { NB_G01 = 0, NB_G23, NB_H, NBP };
@@ -35,7 +36,7 @@ struct Dev {
   const double *load_scale, *sgen_scale;     // [nl], [ns] element scaling * in_service (runpp sees p, q * scaling)
   // buses with sgens ("PV buses", n_sgb of them: positions sgb_pos, inverse sgb_of_pos[nb] or -1) and buses with loads but no
   // sgens (lb_pos, n_lb): k_inject_sgen works on the former; bus_ld [n_sgb][Bp] pairs = load part (P, Q) of their injection
-  const int32_t *sgb_pos, *sgb_of_pos, *lb_pos; int32_t n_sgb, n_lb;
+  const int32_t *sgb_pos, *sgb_of_pos, *lb_pos, *ldb_pos; int32_t n_sgb, n_lb, n_ldb;   // ldb_pos: every bus with loads (k_advance)
   double* bus_ld;
   const LineFlow* lines;
   const int32_t* root_children; const double* root_y; int32_t n_root_children;   // children of the slack: position, Y_root,k
@@ -59,7 +60,8 @@ struct Dev {
   uint8_t *done, *pending, *active, *commit, *bad_start, *resetting;   // resetting: (re)started by this step call (auto_reset)
   int64_t* adv_row; uint32_t* adv_draw;
   // ---- NR scratch (see NB_* / VO_*): row offsets of the Sbus and Vout regions
-  double* nrbuf; uint32_t nrbuf_bytes; uint32_t sb_off, r_vout;   // sb_off: byte offset of the Sbus region
+  double* nrbuf; uint32_t nrbuf_bytes; uint32_t sb_off, r_vout;   // sb_off: byte offset of the Sbus region the solve reads
+  uint32_t sb_off_alt;                                            // ... of the other Sbus buffer (double-buffered, see k_advance)
   const int32_t* sb_index;                                           // [n] Sbus entry (schedule step) of elimination position k
   int32_t* iters; uint8_t* conv;
   // ---- NR schedule (k_nr_tree): W waves per workgroup, L envs per workgroup (64/L lane-group workers per wave), R rows
@@ -110,7 +112,7 @@ int nr_dense_prepare(const Dev& d);
 void launch_nr_dense(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
 int dense_solve_debug(const double* A, const double* b, double* x, int n, int batch, hipStream_t st);
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);
-void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, hipStream_t st);
+void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off, hipStream_t st);
 void launch_gather(const Dev& d, const double* base, const int32_t* rows, const double* scales, double scale_all,
                    const int32_t* x_ptr, const int32_t* x_row, void* out, int dtype, int C, hipStream_t st);
 void launch_to_envminor(const Dev& d, const double* src, double* dst, int n, hipStream_t st);

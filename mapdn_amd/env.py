@@ -427,6 +427,25 @@ class VoltageControl(MultiAgentEnv):
         self.n_agents = b.n_agents                                    # :81
         self.s_max = prof.s_max(1.2)
         print(f"This is the s_max: \n{self.s_max}")                  # :521
+        # ---- latency path of the drop-in call pattern (utilities/tester.py:48-55: numpy action in, Python scalars + list of numpy
+        # out, once per step).  reward | info[11] | terminated | obs live in ONE device buffer (the batch object's output tensors
+        # are views of it) mirrored by ONE pinned host buffer: a step() is one async H2D of the action, the four kernels, one
+        # async D2H of the packed outputs and a single stream synchronisation; the get_obs() that follows costs nothing.
+        n, o1 = b.n_agents, b._obs_size1
+        self._pk_off = dict(reward=0, info=8, term=8 + 8 * N_INFO, obs=8 + 8 * N_INFO + 8)
+        nbytes = self._pk_off["obs"] + 8 * n * o1
+        self._pk_dev = torch.zeros(nbytes, dtype=torch.uint8, device=b.device)
+        self._pk_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+        self._pk_np = self._pk_host.numpy()
+        po = self._pk_off
+        b._reward = self._pk_dev[po["reward"]:po["reward"] + 8].view(torch.float64)
+        b._info = self._pk_dev[po["info"]:po["info"] + 8 * N_INFO].view(torch.float64).view(1, N_INFO)
+        b._term = self._pk_dev[po["term"]:po["term"] + 1].view(torch.bool)
+        b._obs[torch.float64] = self._pk_dev[po["obs"]:].view(torch.float64).view(1, n, o1)
+        self._act_host = torch.zeros(1, b.n_sgen, dtype=torch.float64).pin_memory()
+        self._act_dev = torch.zeros(1, b.n_sgen, dtype=torch.float64, device=b.device)
+        self._packed = b.fused_step and os.environ.get("MAPDN_DROPIN_PACKED", "1") != "0"
+        self._host_obs_valid = False
         agents_obs, state = self.reset()
         self.obs_size = agents_obs[0].shape[0]                        # :87
         self.state_size = state.shape[0]
@@ -436,6 +455,7 @@ class VoltageControl(MultiAgentEnv):
     def reset(self, reset_time=True):
         """reset (:96-135): the reference re-draws until the start is solvable (`while not solvable`, :108); so does this
         (the library tries `max_reset_tries` starts per call), giving up loudly after 100 calls instead of spinning forever."""
+        self._host_obs_valid = False
         self.steps = 1
         self.sum_rewards = 0
         for _ in range(100):
@@ -447,6 +467,7 @@ class VoltageControl(MultiAgentEnv):
         raise RuntimeError("reset(): no solvable start found (the reference would keep looping at voltage_control_env.py:108)")
 
     def manual_reset(self, day, hour, interval):
+        self._host_obs_valid = False
         self.steps = 1
         self.sum_rewards = 0
         obs, state = self._b.manual_reset(day, hour, interval)
@@ -456,11 +477,23 @@ class VoltageControl(MultiAgentEnv):
         return self._obs_list(obs), state[0].cpu().numpy()
 
     def step(self, actions, add_noise=True):
-        a = torch.as_tensor(np.asarray(actions, dtype=np.float64).reshape(1, -1))
-        r, t, info = self._b.step(a, add_noise=add_noise)
-        reward = float(r[0].item())
-        terminated = bool(t[0].item())
-        vals = info[0].cpu().numpy()
+        if self._packed:
+            self._act_host.numpy()[0, :] = np.asarray(actions, dtype=np.float64).reshape(-1)
+            self._act_dev.copy_(self._act_host, non_blocking=True)
+            self._b.step(self._act_dev, add_noise=add_noise)          # enqueues only; outputs land in the packed device buffer
+            self._pk_host.copy_(self._pk_dev, non_blocking=True)
+            torch.cuda.current_stream(self._b.device).synchronize()   # the one synchronisation of the step
+            po, h = self._pk_off, self._pk_np
+            reward = float(h[po["reward"]:po["reward"] + 8].view(np.float64)[0])
+            terminated = bool(h[po["term"]])
+            vals = h[po["info"]:po["info"] + 8 * N_INFO].view(np.float64).copy()
+            self._host_obs_valid = self.history == 1                  # (history > 1 stacks frames on the device: get_obs() goes there)
+        else:
+            a = torch.as_tensor(np.asarray(actions, dtype=np.float64).reshape(1, -1))
+            r, t, info = self._b.step(a, add_noise=add_noise)
+            reward = float(r[0].item())
+            terminated = bool(t[0].item())
+            vals = info[0].cpu().numpy()
         self.steps += 1
         self.sum_rewards += reward
         if terminated:
@@ -472,6 +505,10 @@ class VoltageControl(MultiAgentEnv):
         return [o[i].copy() for i in range(o.shape[0])]
 
     def get_obs(self):
+        if self._packed and self._host_obs_valid and self._b._obs_fresh == torch.float64:   # the obs of the last step() is on the host
+            n, o1 = self.n_agents, self._b._obs_size1
+            o = self._pk_np[self._pk_off["obs"]:].view(np.float64).reshape(n, o1)
+            return [o[i].copy() for i in range(n)]
         return self._obs_list(self._b.get_obs())
 
     def get_obs_agent(self, agent_id):

@@ -443,52 +443,43 @@ class PGTrainer:
         if a.target and self.steps % a.target_update_freq == 0:
             self.behaviour_net.update_target()
 
-    # ---- rollouts (models/model.py:197-302) -------------------------------------------------------
+    # ---- rollouts (models/model.py:197-302): episodes run through the package's one rollout loop (rollout.BatchedRollout) ----
     def _episode(self, stat, train: bool):
         env, net, a = self.env, self.behaviour_net, self.args
         B, dv = env.n_envs, self.device
         prefix = "mean_train_" if train else "mean_test_"
-        own = (lambda t: t) if getattr(env, "copy", False) else (lambda t: t.clone())    # copy=True envs already hand out fresh tensors
-        obs, _ = env.reset()
-        obs = own(obs.float())
-        last_hid = net.init_hidden(B)
         avail = env.get_avail_actions().to(dv)
-        alive = torch.ones(B, dtype=torch.bool, device=dv)
-        info_sum = torch.zeros(len(INFO_KEYS), dtype=torch.float64, device=dv)
-        rew_sum = torch.zeros((), dtype=torch.float64, device=dv)
-        n_alive = torch.zeros((), dtype=torch.float64, device=dv)
-        for t in range(a.max_steps):
-            with torch.no_grad():
-                if train:
-                    action, action_pol, _, _, hid = net.get_actions(obs, "train", True, avail, False, last_hid)
-                else:
-                    action, action_pol, _, _, hid = net.get_actions(obs, "test", False, avail, False, last_hid)
-                actual = translate_action(action.squeeze(-1), a.action_scale, a.action_bias)      # util.py:123-132
-            reward, done, info = env.step(actual)
-            next_obs = own(env.get_obs().float())
-            w = alive.double()
-            info_sum += (info.double() * w.unsqueeze(-1)).sum(0); rew_sum += (reward.double() * w).sum(); n_alive += w.sum()
+
+        def policy(obs, last_hid):
             if train:
-                trans = dict(state=obs, action=action_pol, reward=reward.float().unsqueeze(-1).expand(B, net.n_).contiguous(),
-                             next_state=next_obs, done=done.view(B, 1).float(),
-                             last_step=(done | (t == a.max_steps - 1)).view(B, 1).float(), action_avail=avail,
-                             last_hid=last_hid, hid=hid, valid=alive.clone())
-                self.transition_update(trans, stat)
-                self.steps += 1
-            alive = alive & ~done.bool()
-            obs, last_hid = next_obs, hid
-            if t % 16 == 15:                                    # the only host sync: once per 16 steps
-                flag = alive.any().to(torch.int32)
-                if self._dist is not None:                      # data-parallel ranks must agree: `steps` drives the update
-                    if self._dist.get_backend() != "nccl":      # schedule and every update is a collective
-                        flag = flag.cpu()
-                    self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX)
-                if not bool(flag):
-                    break
-        denom = n_alive.clamp(min=1.0)
-        for k, v in zip(INFO_KEYS, (info_sum / denom).tolist()):
-            stat[prefix + k] = stat.get(prefix + k, 0.0) + v if not train else v
-        stat[prefix + "reward"] = (stat.get(prefix + "reward", 0.0) if not train else 0.0) + float(rew_sum / denom)
+                action, action_pol, _, _, hid = net.get_actions(obs, "train", True, avail, False, last_hid)
+            else:
+                action, action_pol, _, _, hid = net.get_actions(obs, "test", False, avail, False, last_hid)
+            return action, hid, (action_pol, last_hid, hid)
+
+        def on_step(t, obs, action, reward, done, info, next_obs, alive, aux):
+            action_pol, last_hid, hid = aux
+            trans = dict(state=obs, action=action_pol, reward=reward.float().unsqueeze(-1).expand(B, net.n_).contiguous(),
+                         next_state=next_obs, done=done.view(B, 1).float(),
+                         last_step=(done | (t == a.max_steps - 1)).view(B, 1).float(), action_avail=avail,
+                         last_hid=last_hid, hid=hid, valid=alive.clone())
+            self.transition_update(trans, stat)
+            self.steps += 1
+
+        def agree(flag):                                        # data-parallel ranks must agree on the early exit: `steps` drives
+            if self._dist is None:                              # the update schedule and every update is a collective
+                return flag
+            if self._dist.get_backend() != "nccl":
+                flag = flag.cpu()
+            self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX)
+            return flag
+
+        from .rollout import BatchedRollout
+        ro = BatchedRollout(env, policy, a.max_steps, on_step=on_step if train else None, store_window=False, all_alive_reduce=agree,
+                            action_scale=a.action_scale, action_bias=a.action_bias)
+        _, ep = ro.run(prefix=prefix, hidden=net.init_hidden(B))
+        for k, v in ep.items():
+            stat[k] = v if train else stat.get(k, 0.0) + v
 
     def train_process(self, stat):
         self._episode(stat, train=True)

@@ -381,7 +381,7 @@ _CASES = {}
 
 
 def make_case(name: str, days: int = 10, seed: int = 0):
-    """Return (NetSpec, Profiles) for 'case33' | 'case141' | 'case322' (synthetic, deterministic).
+    """Return (NetSpec, Profiles) for 'case33' | 'case141' | 'case322' (synthetic, deterministic; + 'case141_deep', a depth stress).
 
     Load / PV totals follow reference README.md:299-303 (p_max^L 3.5/20/1.5 MW, p_max^PV 8.75/80/3.75 MW).
     """
@@ -396,6 +396,12 @@ def make_case(name: str, days: int = 10, seed: int = 0):
         pv_total = 8.75
     elif name == "case141":
         net, p_nom = _radial_case("case141", 141, 84, 22, 9, 15, 12.47, 10.0, 20.0, seed + 141, 0.05)
+        q_nom = p_nom * np.tan(np.arccos(0.95))
+        pv_total = 80.0
+    elif name == "case141_deep":
+        # the 141-bus shape on a chain-heavy topology (45-bus trunk, 8 lateral zones of 12 buses): a depth stress for the tree
+        # solver, whose sweep length is the radius of the feeder — not one of the reference's scenarios
+        net, p_nom = _radial_case("case141_deep", 141, 84, 22, 8, 45, 12.47, 10.0, 20.0, seed + 1141, 0.05)
         q_nom = p_nom * np.tan(np.arccos(0.95))
         pv_total = 80.0
     elif name == "case322":

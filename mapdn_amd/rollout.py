@@ -38,47 +38,71 @@ class TransitionWindow:
 
 
 class BatchedRollout:
-    """policy: callable (obs [B, n, obs_size] f32, hidden) -> (action [B, n] or [B, n, 1] in [-1, 1] space, hidden)."""
+    """The one rollout loop of the package (the trainer's episodes run through it too).
 
-    def __init__(self, env, policy, max_steps: int = 240):
+    policy: callable (obs [B, n, obs_size] f32, hidden) -> (action, hidden) or (action, hidden, aux); action [B, n] or [B, n, 1]
+    in [-1, 1] space; `aux` (any object) is handed to `on_step` — the learner passes the pre-noise action and the
+    hidden states a `Transition` stores (models/model.py:18).
+    on_step: optional callable(t, obs, action, reward, done, info, next_obs, alive, aux) called after every batched step
+    (the learner's `transition_update`, models/model.py:39-70).
+    store_window: keep the [T, B, ...] `TransitionWindow` (off for the learner: its replay buffer is the store).
+    all_alive_reduce: optional callable(flag int32 tensor) -> flag, for data-parallel ranks that must agree on the early exit.
+    own: how observations handed out by the env are taken over (clone for envs that reuse their output buffers)."""
+
+    def __init__(self, env, policy, max_steps: int = 240, on_step=None, store_window: bool = True, all_alive_reduce=None,
+                 action_scale=None, action_bias=None):
         self.env, self.policy, self.max_steps = env, policy, int(max_steps)
-        a = env.args
-        self.action_scale, self.action_bias = float(a["action_scale"]), float(a["action_bias"])
+        self.on_step, self.all_alive_reduce = on_step, all_alive_reduce
+        self.action_scale = float(env.args["action_scale"] if action_scale is None else action_scale)
+        self.action_bias = float(env.args["action_bias"] if action_bias is None else action_bias)
         B, n, o, dv, T = env.n_envs, env.n_agents, env.obs_size, env.device, self.max_steps
-        self.win = TransitionWindow(
-            state=torch.empty(T, B, n, o, device=dv), action=torch.empty(T, B, n, 1, device=dv),
-            reward=torch.empty(T, B, n, device=dv), next_state=torch.empty(T, B, n, o, device=dv),
-            done=torch.empty(T, B, dtype=torch.bool, device=dv), last_step=torch.empty(T, B, dtype=torch.bool, device=dv))
+        self.win = None
+        if store_window:
+            self.win = TransitionWindow(
+                state=torch.empty(T, B, n, o, device=dv), action=torch.empty(T, B, n, 1, device=dv),
+                reward=torch.empty(T, B, n, device=dv), next_state=torch.empty(T, B, n, o, device=dv),
+                done=torch.empty(T, B, dtype=torch.bool, device=dv), last_step=torch.empty(T, B, dtype=torch.bool, device=dv))
+        self._own = (lambda t: t) if getattr(env, "copy", False) else (lambda t: t.clone())   # copy=True envs hand out fresh tensors
 
     @torch.no_grad()
     def run(self, prefix: str = "mean_train_", hidden=None, add_noise: bool = True):
-        """One episode for every env.  Returns (window, stat): stat[prefix + key] = mean over steps and
+        """One episode for every env.  Returns (window or None, stat): stat[prefix + key] = mean over steps and
         envs of every info key and of the reward (models/model.py:243-248,257-261), computed on device."""
         env, win, T = self.env, self.win, self.max_steps
         obs, _ = env.reset()
-        obs = obs.float().clone()
+        obs = self._own(obs.float())
         info_sum = torch.zeros(len(INFO_KEYS), dtype=torch.float64, device=env.device)
         rew_sum = torch.zeros((), dtype=torch.float64, device=env.device)
         alive_steps = torch.zeros((), dtype=torch.float64, device=env.device)
         alive = torch.ones(env.n_envs, dtype=torch.bool, device=env.device)
         t = 0
         for t in range(T):
-            action, hidden = self.policy(obs, hidden)
+            out = self.policy(obs, hidden)
+            action, hidden, aux = out if len(out) == 3 else (out[0], out[1], None)
             action = action.reshape(env.n_envs, env.n_agents, 1).float()
             actual = translate_action(action.squeeze(-1), self.action_scale, self.action_bias)
-            reward, done, info = env.step(actual, add_noise=add_noise)
-            nxt = env.get_obs().float()
-            win.state[t].copy_(obs); win.action[t].copy_(action)
-            win.reward[t].copy_(reward.float().unsqueeze(-1).expand(-1, env.n_agents))
-            win.next_state[t].copy_(nxt); win.done[t].copy_(done)
-            win.last_step[t].copy_(done | (t == T - 1))
+            reward, done, info = env.step(actual) if add_noise else env.step(actual, add_noise=False)
+            nxt = self._own(env.get_obs().float())
+            if win is not None:
+                win.state[t].copy_(obs); win.action[t].copy_(action)
+                win.reward[t].copy_(reward.float().unsqueeze(-1).expand(-1, env.n_agents))
+                win.next_state[t].copy_(nxt); win.done[t].copy_(done)
+                win.last_step[t].copy_(done | (t == T - 1))
             w = alive.double()                                  # frozen (already terminated) envs do not count
-            info_sum += (info * w.unsqueeze(-1)).sum(0); rew_sum += (reward * w).sum(); alive_steps += w.sum()
-            alive &= ~done
-            obs = nxt.clone()
-            if t % 16 == 15 and not bool(alive.any()):          # the only host sync, once per 16 steps
-                break
-        win.steps = t + 1
+            info_sum += (info.double() * w.unsqueeze(-1)).sum(0); rew_sum += (reward.double() * w).sum(); alive_steps += w.sum()
+            if self.on_step is not None:
+                with torch.enable_grad():
+                    self.on_step(t, obs, action, reward, done, info, nxt, alive, aux)
+            alive = alive & ~done.bool()
+            obs = nxt
+            if t % 16 == 15:                                    # the only host sync, once per 16 steps
+                flag = alive.any().to(torch.int32)
+                if self.all_alive_reduce is not None:
+                    flag = self.all_alive_reduce(flag)
+                if not bool(flag):
+                    break
+        if win is not None:
+            win.steps = t + 1
         denom = torch.clamp(alive_steps, min=1.0)
         stat = {prefix + k: float(v) for k, v in zip(INFO_KEYS, (info_sum / denom).tolist())}
         stat[prefix + "reward"] = float(rew_sum / denom)

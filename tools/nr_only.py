@@ -11,7 +11,7 @@ ap.add_argument("--case", default="case141"); ap.add_argument("--envs", type=int
 ap.add_argument("--iters", type=int, default=50)
 a = ap.parse_args()
 net, prof = make_case(a.case)
-scale = {"case33": 0.8, "case141": 0.6, "case322": 0.8}[a.case]
+scale = {"case33": 0.8, "case141": 0.6, "case322": 0.8, "case141_deep": 0.6}[a.case]
 env = VoltageControlBatch(net, prof, dict(episode_limit=240, action_scale=scale, action_bias=0.0), n_envs=a.envs, device="cuda:0")
 rng = np.random.default_rng(0)
 rows = rng.integers(0, prof.n_rows, a.envs)

@@ -12,7 +12,7 @@ ap.add_argument("--rows", action="store_true")
 ap.add_argument("--step", action="store_true", help="stamp a step() launch (with the fused reward / commit epilogue) instead of solve-only")
 a = ap.parse_args()
 net, prof = make_case(a.case)
-scale = {"case33": 0.8, "case141": 0.6, "case322": 0.8}[a.case]
+scale = {"case33": 0.8, "case141": 0.6, "case322": 0.8, "case141_deep": 0.6}[a.case]
 env = VoltageControlBatch(net, prof, dict(episode_limit=240, action_scale=scale, action_bias=0.0, voltage_barrier_type="bowl"), n_envs=a.envs, device="cuda:0")
 rng = np.random.default_rng(0)
 rows = rng.integers(0, prof.n_rows, a.envs)
