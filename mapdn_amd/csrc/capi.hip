@@ -29,6 +29,7 @@ struct mapdn_handle {
                                   // injection runs the all-bus kernel; MAPDN_INJECT_FULL=1 keeps it that way (A/B, tests)
   bool inject_full = false;
   uint32_t sb_base = 0, sb_bytes = 0;   // the two Sbus buffers of nrbuf: d.sb_off / d.sb_off_alt alternate between them
+  std::vector<int32_t> ld_dest_host;
   size_t lds_bytes = 0;
   int32_t *obs_rows = nullptr, *state_rows = nullptr, *iota_idx = nullptr, *vm_row = nullptr, *va_row = nullptr;
   int32_t *obs_xptr = nullptr, *obs_xrow = nullptr;
@@ -157,16 +158,17 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   UP(load_ptr, P.load_ptr); UP(load_idx, P.load_idx); UP(sgen_ptr, P.sgen_ptr); UP(sgen_idx, P.sgen_idx);
   UP(shunt_p, P.shunt_p); UP(shunt_q, P.shunt_q); UP(load_scale, P.load_scale); UP(sgen_scale, P.sgen_scale);
   {
-    std::vector<int32_t> sgb, sgb_of(P.nb, -1), lb, ldb;
+    std::vector<int32_t> sgb, sgb_of(P.nb, -1), lb, mlb;
     for (int k = 0; k < P.nb; ++k) {
-      if (P.load_ptr[k + 1] > P.load_ptr[k]) ldb.push_back(k);
+      if (P.load_ptr[k + 1] - P.load_ptr[k] > 1) mlb.push_back(k);
       if (P.sgen_ptr[k + 1] > P.sgen_ptr[k]) { sgb_of[k] = (int32_t)sgb.size(); sgb.push_back(k); }
       else if (P.load_ptr[k + 1] > P.load_ptr[k]) lb.push_back(k);
     }
-    d.n_sgb = (int32_t)sgb.size(); d.n_lb = (int32_t)lb.size(); d.n_ldb = (int32_t)ldb.size();
+    d.n_sgb = (int32_t)sgb.size(); d.n_lb = (int32_t)lb.size(); d.n_mlb = (int32_t)mlb.size();
     if (lb.empty()) lb.push_back(0);
-    if (ldb.empty()) ldb.push_back(0);
-    UP(sgb_pos, sgb); UP(sgb_of_pos, sgb_of); UP(lb_pos, lb); UP(ldb_pos, ldb);
+    if (mlb.empty()) mlb.push_back(0);
+    UP(sgb_pos, sgb); UP(sgb_of_pos, sgb_of); UP(lb_pos, lb); UP(mlb_pos, mlb);
+    h->ld_dest_host.assign(std::max(P.nl, 1), 2);             // filled once the Sbus order (sb_index) is known, see alloc_nrbuf
     rc = dalloc(h, &d.bus_ld, (size_t)2 * d.n_sgb * d.Bp); if (rc) return rc;
     if (const char* s_ = getenv("MAPDN_INJECT_FULL")) h->inject_full = atoi(s_) != 0;
   }
@@ -250,6 +252,17 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     h->sb_base = d.sb_off; h->sb_bytes = (uint32_t)(nblk * Bp * 16);
     d.r_vout = (uint32_t)(vout_off / (Bp * sizeof(double)));
     rc = dupload(h, &d.sb_index, sbi); if (rc) return rc;
+    {   // ld_dest: a load alone on its bus goes straight to the Sbus entry (kind 0) / bus_ld row (kind 1) of that bus
+      std::vector<int32_t> sgb_of(P.nb, -1); int nsg = 0;
+      for (int k = 0; k < P.nb; ++k) if (P.sgen_ptr[k + 1] > P.sgen_ptr[k]) sgb_of[k] = nsg++;
+      for (int k = 0; k < P.nb; ++k) {
+        if (P.load_ptr[k + 1] - P.load_ptr[k] != 1) continue;
+        const int li = P.load_idx[P.load_ptr[k]];
+        if (sgb_of[k] >= 0) h->ld_dest_host[li] = (sgb_of[k] << 2) | 1;
+        else if (k < P.n) h->ld_dest_host[li] = (sbi[k] << 2) | 0;
+      }
+      rc = dupload(h, &d.ld_dest, h->ld_dest_host); if (rc) return rc;
+    }
     std::vector<double> row(Bp, d.vroot);   // slack entry of Vout: V = vroot + 0j (angle 0 from the memset)
     double* rootv = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * P.n) * Bp;
     HIPCHK(h, hipMemcpy(rootv + (size_t)VO_E * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));

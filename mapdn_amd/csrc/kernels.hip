@@ -1041,10 +1041,10 @@ __global__ void __launch_bounds__(256) k_reset_begin(Dev d, const int64_t* __res
 //      profile tables + std/100 * |N(0,1)| noise (:498,503,508), and the commit of res_bus for the solve that just finished.
 //      rows [0, npv): thread = (Philox block of the PV table, env): one Philox4x32-10 call + one Box-Muller pair serves two
 //                     adjacent PV columns;
-//      rows [npv, npv + n_ldb): thread = (bus with loads, env): the loads of the bus for the NEXT step, element by element
-//                     through the bus's CSR list (a load takes the cosine or sine Box-Muller branch of its Philox block),
-//                     and with them what the next k_inject_sgen needs — the finished Sbus entry of a bus without sgens,
-//                     the load part (bus_ld) of a PV bus;
+//      rows of the load_p / load_q tables likewise (two loads per thread); a load that is alone on its bus IS that bus's load
+//                     sum, so the thread also stores what the next k_inject_sgen / solve needs — the finished Sbus half of a
+//                     bus without sgens, the load part (bus_ld) of a PV bus;
+//      n_mlb rows:    thread = (bus with several loads, env): that bus's load sum in the canonical CSR order;
 //      then nb rows:  thread = (bus position, env): the K6 commit.
 //      Sbus is DOUBLE-BUFFERED: the commit reads the buffer the solve used (d.sb_off) while the load rows of the same launch
 //      write the buffer of the next solve (`sb_write_off`: the other one in step(), the same one in reset(), where the
@@ -1053,14 +1053,16 @@ __global__ void __launch_bounds__(256) k_reset_begin(Dev d, const int64_t* __res
 __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.B) return;
-  const int npv = do_profiles ? ((d.ns + 1) >> 1) : 0;
-  const int nld = do_profiles ? d.n_ldb : 0;
+  const int npv = (d.ns + 1) >> 1, npl = (d.nl + 1) >> 1;
+  const int npairs = do_profiles ? npv + 2 * npl : 0;
+  const int nmb = do_profiles ? d.n_mlb : 0;
   const size_t S = (size_t)d.Bp;
-  if ((int)blockIdx.y >= npv + nld) {
+  double2* const sbw = (double2*)((char*)d.nrbuf + sb_write_off) + e;
+  if ((int)blockIdx.y >= npairs + nmb) {
     // ---- K6 commit of res_bus (pandapower pfsoln/_extract_results) for envs whose solve was accepted:
     // vm_pu = |V|, va = angle(V), p_mw/q_mvar = bus demand (-Sbus*sn) + shunt*|V|^2, slack = -(V conj(I))*sn
     if (!d.commit[e]) return;
-    const int k = (int)blockIdx.y - npv - nld;     // elimination position, n == slack
+    const int k = (int)blockIdx.y - npairs - nmb;  // elimination position, n == slack
     const size_t o = (size_t)d.bus_of_pos[k] * S + e;
     double v, P, Q;
     if (k < d.n) {
@@ -1087,41 +1089,59 @@ __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_pr
   const int64_t row = d.adv_row[e];
   if (row < 0 || row >= d.T) return;               // never read outside the table
   const uint32_t draw = d.adv_draw[e];
-  if ((int)blockIdx.y >= npv) {
-    // ---- next loads of one bus
-    const int k = d.ldb_pos[(int)blockIdx.y - npv];
+  if ((int)blockIdx.y >= npairs) {
+    // ---- a bus with SEVERAL loads: its load sum needs one thread (canonical order of the CSR list); the values themselves
+    // are the ones the pair threads store, recomputed element by element
+    const int k = d.mlb_pos[(int)blockIdx.y - npairs];
     double P = 0.0, Q = 0.0;
     for (int i = d.load_ptr[k]; i < d.load_ptr[k + 1]; ++i) {
       const int li = d.load_idx[i];
-      const size_t o = (size_t)li * S + e;
       const double p = profile_value(d, e, row, draw, STREAM_LOAD_P, li, d.ns, add_noise);
       const double q = profile_value(d, e, row, draw, STREAM_LOAD_Q, li, d.ns + d.nl, add_noise);
-      d.cur_pl[o] = p; d.cur_ql[o] = q;
       P += p * d.load_scale[li]; Q += q * d.load_scale[li];   // pd2ppc: PD = sum p_mw * scaling
     }
     const int jb = d.sgb_of_pos[k];
     if (jb >= 0) ((double2*)d.bus_ld)[(size_t)jb * S + e] = make_double2(P, Q);
-    else if (k < d.n) ((double2*)((char*)d.nrbuf + sb_write_off))[(size_t)d.sb_index[k] * S + e] = make_double2(-P / d.sn, -Q / d.sn);
+    else if (k < d.n) sbw[(size_t)d.sb_index[k] * S] = make_double2(-P / d.sn, -Q / d.sn);
     return;
   }
-  const int b = blockIdx.y;                        // Philox block of the PV table
+  int b = blockIdx.y;                              // pair index over [pv pairs | load_p pairs | load_q pairs]
+  int stream, count, col0, comp = 0;
+  double* dst;
+  if (b < npv) { stream = STREAM_PV; count = d.ns; col0 = 0; dst = d.cur_pv; }
+  else if (b < npv + npl) { b -= npv; stream = STREAM_LOAD_P; count = d.nl; col0 = d.ns; dst = d.cur_pl; }
+  else { b -= npv + npl; stream = STREAM_LOAD_Q; count = d.nl; col0 = d.ns + d.nl; dst = d.cur_ql; comp = 1; }
   const int j0 = 2 * b, j1 = 2 * b + 1;
-  const double* trow = d.table + (size_t)row * d.ncol;
+  const double* trow = d.table + (size_t)row * d.ncol + col0;
   double v0 = trow[j0];
-  double v1 = (j1 < d.ns) ? trow[j1] : 0.0;
+  double v1 = (j1 < count) ? trow[j1] : 0.0;
   if (add_noise) {
     uint32_t x[4];
-    philox4x32_10((uint32_t)(d.env_id_offset + e), draw, (uint32_t)STREAM_PV, (uint32_t)b, d.seed_lo, d.seed_hi, x);
+    philox4x32_10((uint32_t)(d.env_id_offset + e), draw, (uint32_t)stream, (uint32_t)b, d.seed_lo, d.seed_hi, x);
     const double u1 = (u53(x[0], x[1]) + 0.5) * (1.0 / 9007199254740992.0);
     const double u2 = u53(x[2], x[3]) * (1.0 / 9007199254740992.0);
     const double r = sqrt(-2.0 * log(u1));
     double sn_, cs_;
     sincos(2.0 * M_PI * u2, &sn_, &cs_);
-    v0 += d.stdv[j0] * fabs(r * cs_);
-    if (j1 < d.ns) v1 += d.stdv[j1] * fabs(r * sn_);
+    v0 += d.stdv[col0 + j0] * fabs(r * cs_);
+    if (j1 < count) v1 += d.stdv[col0 + j1] * fabs(r * sn_);
   }
-  d.cur_pv[(size_t)j0 * d.Bp + e] = v0;
-  if (j1 < d.ns) d.cur_pv[(size_t)j1 * d.Bp + e] = v1;
+  dst[(size_t)j0 * d.Bp + e] = v0;
+  if (j1 < count) dst[(size_t)j1 * d.Bp + e] = v1;
+  if (stream == STREAM_PV) return;
+  // ---- a load that is ALONE on its bus is the bus's whole load sum (0 + p * scaling, as k_inject forms it): its P (this thread)
+  // and Q (the thread of the other stream) halves go straight to where the next k_inject_sgen / solve reads them —
+  // ld_dest[li] = entry << 2 | kind: kind 0 Sbus entry of the next solve, 1 bus_ld row of a PV bus, 2 nothing (bus with several
+  // loads: the rows above; loads on the slack bus)
+  auto route = [&](int li, double v) {
+    const int dd = d.ld_dest[li];
+    const double ps = v * d.load_scale[li];
+    double* base;
+    if ((dd & 3) == 0) { base = (double*)(sbw + (size_t)(dd >> 2) * S); base[comp] = -ps / d.sn; }
+    else if ((dd & 3) == 1) { base = (double*)((double2*)d.bus_ld + (size_t)(dd >> 2) * S + e); base[comp] = ps; }
+  };
+  route(j0, v0);
+  if (j1 < count) route(j1, v1);
 }
 
 // =================================================================================================
@@ -1290,7 +1310,7 @@ void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, 
 // do_profiles: next profile row + noise for the envs queued in adv_row; do_commit: res_bus commit of
 // the envs flagged by the preceding k_nr_tree launch
 void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off, hipStream_t st) {
-  const int rows = (do_profiles ? ((d.ns + 1) >> 1) + d.n_ldb : 0) + (do_commit ? d.nb : 0);
+  const int rows = (do_profiles ? ((d.ns + 1) >> 1) + 2 * ((d.nl + 1) >> 1) + d.n_mlb : 0) + (do_commit ? d.nb : 0);
   if (rows == 0) return;
   hipLaunchKernelGGL(k_advance, dim3((d.B + 255) / 256, rows), dim3(256), 0, st, d, add_noise, do_profiles, do_commit, sb_write_off);
 }

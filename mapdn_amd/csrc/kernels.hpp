@@ -36,7 +36,8 @@ struct Dev {
   const double *load_scale, *sgen_scale;     // [nl], [ns] element scaling * in_service (runpp sees p, q * scaling)
   // buses with sgens ("PV buses", n_sgb of them: positions sgb_pos, inverse sgb_of_pos[nb] or -1) and buses with loads but no
   // sgens (lb_pos, n_lb): k_inject_sgen works on the former; bus_ld [n_sgb][Bp] pairs = load part (P, Q) of their injection
-  const int32_t *sgb_pos, *sgb_of_pos, *lb_pos, *ldb_pos; int32_t n_sgb, n_lb, n_ldb;   // ldb_pos: every bus with loads (k_advance)
+  const int32_t *sgb_pos, *sgb_of_pos, *lb_pos, *mlb_pos, *ld_dest; int32_t n_sgb, n_lb, n_mlb;   // mlb_pos: buses with several loads;
+                                                   // ld_dest[nl]: where a load that is alone on its bus goes (see k_advance)
   double* bus_ld;
   const LineFlow* lines;
   const int32_t* root_children; const double* root_y; int32_t n_root_children;   // children of the slack: position, Y_root,k
