@@ -377,6 +377,12 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   }
   UP(sched, h->sched.steps); d.sched_bytes = (uint32_t)(h->sched.steps.size() * sizeof(StepRec));
   UP(clist, h->sched.clist);
+  UP(mm_ptr, h->sched.mm_ptr); UP(mm_child, h->sched.mm_child);
+  UP(mm_recs, h->sched.mm_recs); d.mm_recs_bytes = (uint32_t)(h->sched.mm_recs.size() * sizeof(StepRec)); d.mm_np = h->sched.mm_np;
+  if (h->sched.R * Wt > 0xffff) { h->err = "NR schedule has more than 65535 steps"; return MAPDN_E_INVALID; }
+  // the predicted-final mismatch evaluation as a barrier-free pass over all nodes instead of a tree sweep (needs the h array in LDS)
+  d.nr_mm_pass = h_lds ? 1 : 0;
+  if (const char* s_ = getenv("MAPDN_NR_MM_PASS")) d.nr_mm_pass = (atoi(s_) != 0 && h_lds) ? 1 : 0;
   UP(flat, h->sched.flat); d.flat_bytes = (uint32_t)(h->sched.flat.size() * sizeof(double));
   {  // NR scratch: factor blocks (one per (worker,row) step) | Sbus (schedule order) | Vout
     const size_t nblk = (size_t)Wt * h->sched.R;

@@ -859,6 +859,74 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       STAMP(30);
     }
   };
+  // ---- mismatch-only evaluation as a PASS (HL): what the K = 1 forward sweep computes — S_k = V_k conj(sum_j Y_kj V_j), F_k = S_k -
+  // Sbus_k and the verdict — has no elimination in it, so it needs no tree order: (1) every node's term in its PARENT's sum,
+  // A_pk = V_p conj(Y_pk V_k), goes to the node's entry of the h array (dead between a backward and a forward sweep); barrier;
+  // (2) every node adds its own terms and its children's entries in the sweeps' canonical order (chain child first, then
+  // ascending: the same expressions in the same order as fwd_sweep, so the verdict is bit-identical to the sweep's).  Every
+  // worker takes every Wt-th node: ~2 x n / Wt barrier-free steps instead of R rows.
+  auto mismatch_pass = [&]() {
+    // records of this worker, one per turn, streamed from global memory (L2) one turn ahead: no dependent address chains
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<StepRec*>(d.mm_recs), 0, d.mm_recs_bytes, 0x00020000);
+    const int NPs = d.mm_np;
+    const unsigned voP = t * (unsigned)NPs * TB;
+    // (1) A_pk = V_p conj(Y_pk V_k) of every node -> its entry of the h array
+    {
+      u32x4 ixn = bldu4(rsP, voP, 0u); d2 ypn = bld2(rsP, voP + 48u, 0u);
+      for (int j = 0; j < NPs; ++j) {
+        const u32x4 ix = ixn; const d2 ypk = ypn;
+        const unsigned sn = row_s(min(j + 1, NPs - 1), TB);
+        ixn = bldu4(rsP, voP, sn); ypn = bld2(rsP, voP + 48u, sn);
+        const unsigned k = ix.w & 0xffffu, pp = ix.w >> 16;
+        const d2 vk = sV[(size_t)k * L], vp = sV[(size_t)pp * L];
+        const double ek = vk.x, fk = vk.y, ep = vp.x, fp = vp.y, gpk = ypk.x, bpk = ypk.y;
+        const double ur = gpk * ek - bpk * fk, ui = gpk * fk + bpk * ek;
+        const double apk_r = ep * ur + fp * ui, apk_i = fp * ur - ep * ui;
+        sH[(size_t)k * L] = d2{apk_r, apk_i};
+      }
+    }
+    if (W > 1) lds_barrier();
+    // (2) S_k, F_k, verdict.  The index words run two turns ahead, the constants and the Sbus entry (whose address needs the index
+    // word) one turn ahead.
+    {
+      const unsigned voSb = d.sb_off + e * 16u;
+      auto cl = [&](int j) { return row_s(min(j, NPs - 1), TB); };
+      u32x4 ixA = bldu4(rsP, voP, 0u), ixB = bldu4(rsP, voP, cl(1));
+      d2 ykkN = bld2(rsP, voP + 16u, 0u), ykpN = bld2(rsP, voP + 32u, 0u), cksN = bld2(rsP, voP + 64u, 0u);
+      d2 sbN = bld2(rs, voSb + (ixA.z >> 16) * pb, 0u);
+      for (int j = 0; j < NPs; ++j) {
+        const u32x4 ix = ixA;
+        const d2 ykk = ykkN, ykp = ykpN, cks = cksN, sb = sbN;
+        const unsigned k = ix.w & 0xffffu, pp = ix.w >> 16;
+        const int nch = (int)((ix.x >> 8) & 255u);
+        const d2 vk = sV[(size_t)k * L], vp = sV[(size_t)pp * L];
+        const d2 a0 = sH[(size_t)(ix.y & 0xffffu) * L], a1 = sH[(size_t)(ix.y >> 16) * L], a2 = sH[(size_t)(ix.z & 0xffffu) * L];
+        {
+          const unsigned s1 = cl(j + 1);
+          ykkN = bld2(rsP, voP + 16u, s1); ykpN = bld2(rsP, voP + 32u, s1); cksN = bld2(rsP, voP + 64u, s1);
+          sbN = bld2(rs, voSb + (ixB.z >> 16) * pb, 0u);
+          ixA = ixB; ixB = bldu4(rsP, voP, cl(j + 2));
+        }
+        const double gkk = ykk.x, bkk = ykk.y, gkp = ykp.x, bkp = ykp.y;
+        const double ek = vk.x, fk = vk.y, ep = vp.x, fp = vp.y;
+        const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
+        const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
+        const double v2 = ek * ek + fk * fk;
+        const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
+        const double aks_r = ek * cks.x + fk * cks.y, aks_i = fk * cks.x - ek * cks.y;
+        const double base_r = (akk_r + aks_r) + akp_r, base_i = (akk_i + aks_i) + akp_i;
+        double aS0 = nch > 0 ? a0.x : 0.0, aS1 = nch > 0 ? a0.y : 0.0;   // the children in canonical order, the first one opening the sum
+        if (nch > 1) { aS0 += a1.x; aS1 += a1.y; }
+        if (nch > 2) { aS0 += a2.x; aS1 += a2.y; }
+        if (__any(nch > 3)) {                                            // rare: junctions with more than three children
+          const int c_lo = d.mm_ptr[k];
+          for (int q = 3; q < nch; ++q) { const d2 a = sH[(size_t)d.mm_child[c_lo + q] * L]; aS0 += a.x; aS1 += a.y; }
+        }
+        const double sr = base_r + aS0, si = base_i + aS1;
+        note_mismatch(sr - sb.x, si - sb.y, (ix.x & 1u) != 0);
+      }
+    }
+  };
   // backward sweep when h lives in global scratch (the lean layouts).  The update of a node is DEFERRED into the shadow of
   // the next row (only the x chain is between the row barriers).  SRC as above.
   auto bwd_sweep = [&](auto src) {
@@ -934,7 +1002,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     cS0 = cS1 = cD0 = cD1 = cD2 = cD3 = cR0 = cR1 = 0.0;
     STAMP(10);
     if (first) fwd_sweep_flat();
-    else if (light) fwd_sweep(std::integral_constant<int, 1>{});
+    else if (light) { if (HL && d.nr_mm_pass) mismatch_pass(); else fwd_sweep(std::integral_constant<int, 1>{}); }
     else fwd_sweep(std::integral_constant<int, 0>{});
     if constexpr (L == 16) {                     // AND of the workers' verdicts, per env: in the wave by row swaps, across
       fmx = rows_max(fmx);                       // the W waves through W LDS entries (instead of Wt)

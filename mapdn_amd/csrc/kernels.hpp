@@ -69,6 +69,10 @@ struct Dev {
   int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots, nr_nclist, nr_h_lds, nr_g_lds, nr_line_lds, nr_rec_lds, nr_flat_lds;
   const StepRec* sched; uint32_t sched_bytes; const int32_t* clist;
   const double* flat; uint32_t flat_bytes;   // Schedule::flat, [Wt][R][FLAT_N]
+  // mismatch pass (k_nr_tree): per (worker, turn) a record with the node, its parent, its first three children in canonical
+  // order, its Sbus entry and its Y constants (Schedule::mm_recs); further children of a junction from mm_ptr / mm_child
+  const int32_t *mm_ptr, *mm_child; int32_t nr_mm_pass, mm_np;
+  const StepRec* mm_recs; uint32_t mm_recs_bytes;   // Schedule::mm_recs
   // a Newton step whose largest component (|dtheta|, |d|V|/|V||) is below this predicts convergence: the next
   // forward sweep is first run in its mismatch-only form (k_nr_tree)
   double nr_check_dx;

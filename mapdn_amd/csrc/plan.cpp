@@ -546,6 +546,32 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw) {
       for (int w = w0; w < w0 + Sw; ++w) S.steps[(size_t)w * R + r].flags |= (gmax << SU_GMAX_SHIFT) | any;
     }
   if (S.clist.empty()) S.clist.push_back(0);
+  // ---- canonical child lists (independent of W: the same order the records above encode)
+  S.mm_ptr.assign(1, 0); S.mm_child.clear();
+  for (int k = 0; k < n; ++k) {
+    const int cc = chain_child(k);
+    if (cc >= 0) S.mm_child.push_back(cc);
+    for (int ch : children[k]) if (ch != cc) S.mm_child.push_back(ch);
+    S.mm_ptr.push_back((int32_t)S.mm_child.size());
+  }
+  if (S.mm_child.empty()) S.mm_child.push_back(0);
+  S.mm_np = (n + W - 1) / W;
+  S.mm_recs.assign((size_t)W * S.mm_np, StepRec{});
+  for (int w = 0; w < W; ++w)
+    for (int j = 0; j < S.mm_np; ++j) {
+      StepRec& T = S.mm_recs[(size_t)w * S.mm_np + j];
+      const int kx = w + j * W;
+      const bool live = kx < n;
+      const int k = live ? kx : n - 1;               // (a repeated node rewrites the same value; its verdict is masked)
+      const int c_lo = S.mm_ptr[k], nch = live ? S.mm_ptr[k + 1] - c_lo : 0;
+      auto child = [&](int q) { return (uint32_t)(q < nch ? S.mm_child[c_lo + q] : n + 1); };   // absent: the trash node
+      T.flags = (live ? 1u : 0u) | ((uint32_t)std::min(nch, 255) << 8);
+      T.slots = child(0) | (child(1) << 16);
+      T.chs = child(2) | ((uint32_t)S.step_of_node[k] << 16);
+      T.kp = (uint32_t)k | ((uint32_t)P.par[k] << 16);
+      const double* c = &P.yc[(size_t)k * 8];
+      T.ykk[0] = c[0]; T.ykk[1] = c[1]; T.ykp[0] = c[2]; T.ykp[1] = c[3]; T.ypk[0] = c[4]; T.ypk[1] = c[5]; T.cks[0] = c[6]; T.cks[1] = c[7];
+    }
   // ---- flat-start factorisation (same formulas as k_nr_tree's forward step with V == vroot everywhere)
   {
     const double v = P.vroot, v2 = v * v;

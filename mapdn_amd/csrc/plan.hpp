@@ -80,6 +80,15 @@ struct Schedule {
   // the Jacobian of the FIRST Newton iteration — and with it the whole block LU — is the same for all envs
   // and is factorised here once; only the right-hand side (mismatch against the env's Sbus) is per env.
   std::vector<double> flat;
+  // Mismatch-only evaluation without a tree sweep (k_nr_tree's mismatch pass): per node the children in the CANONICAL sum
+  // order of the sweeps (chain child first, then ascending position), CSR by node position
+  std::vector<int32_t> mm_ptr, mm_child;   // [n + 1], [n - #roots]
+  // ... and the same as 80-byte records (StepRec layout) in the order the pass consumes them: worker t takes nodes t, t + W,
+  // t + 2W, ... (record [t][j] = node t + j W):  flags = live | number of children << 8,  slots = child 0 | child 1 << 16,
+  // chs = child 2 | Sbus entry << 16,  kp = node | parent << 16; ykk, ykp, ypk, cks as in a step record.  Children 3.. of a
+  // junction come from mm_child.
+  int32_t mm_np = 0;                       // records per worker
+  std::vector<StepRec> mm_recs;            // [W][mm_np]
 };
 // per-step layout of Schedule::flat
 enum { FL_SR = 0, FL_SI, FL_I0, FL_I1, FL_I2, FL_I3, FL_APR, FL_API, FL_G0, FL_G1, FL_G2, FL_G3, FLAT_N };

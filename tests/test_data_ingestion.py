@@ -243,3 +243,102 @@ def test_non_consecutive_bus_indices_are_mapped_to_sorted_positions():
     ps, qs = pnet.sgen["p_mw"].to_numpy(), pnet.sgen["q_mvar"].to_numpy()
     ra, rb = runpp_restated(ref, pl, ql, ps, qs), runpp_restated(got, pl, ql, ps, qs)
     assert np.abs(ra.vm_pu[order] - rb.vm_pu).max() < 1e-12      # same physics, buses reported in sorted-label order
+
+
+# ------------------------------------------------------------------------------------------------ model.p without pandapower
+def _same_netspec(a, b):
+    import dataclasses
+    for f in dataclasses.fields(a):
+        x, y = getattr(a, f.name), getattr(b, f.name)
+        assert np.array_equal(np.asarray(x), np.asarray(y)), f.name
+
+
+def _write_pp2_pickle(net, path):
+    """what pandapower 2.x `to_pickle` writes (io_utils.to_dict_with_coord_transform): a plain dict, every table as
+    {"DF": DataFrame.to_dict("split"), "dtypes": {column: numpy dtype}}; protocol 2"""
+    import pickle
+    save = {}
+    for k, v in net.items():
+        save[k] = {"DF": v.to_dict("split"), "dtypes": {c: dt for c, dt in zip(v.columns, v.dtypes)}} if isinstance(v, pd.DataFrame) else v
+    save["version"] = "2.7.0"
+    save["std_types"] = {"line": {}, "trafo": {}, "trafo3w": {}}
+    save["_options"] = {"calculate_voltage_angles": "auto"}
+    with open(path, "wb") as f:
+        pickle.dump(save, f, protocol=2)
+
+
+def test_model_p_reads_without_pandapower_dict_of_tables_form(tmp_path):
+    """the file layout of pandapower 2.x to_pickle (the reference's model.p, voltage_control_env.py:400-405), read as data"""
+    from mapdn_amd.data import read_pandapower_pickle
+    pnet = substation_net()
+    p = str(tmp_path / "model.p")
+    _write_pp2_pickle(pnet, p)
+    got = read_pandapower_pickle(p)
+    assert got.sn_mva == 10.0 and list(got.bus["zone"]) == list(pnet.bus["zone"]) and got.line["from_bus"].dtype == pnet.line["from_bus"].dtype
+    _same_netspec(from_pandapower(got), from_pandapower(pnet))
+
+
+def test_model_p_reads_without_pandapower_object_form(tmp_path):
+    """a net pickled as an object: class path pandapower.auxiliary.pandapowerNet (written in a subprocess under the stand-in
+    package, so that `import pandapower` keeps failing here), tables = real pandas DataFrames.  The unpickler maps the class
+    to an inert attribute dict; no pandapower module is imported."""
+    import subprocess
+    from mapdn_amd.data import InertNet, read_pandapower_pickle, save_netspec
+    from mapdn_amd.netspec import make_case
+    net, _ = make_case("case33")
+    npz, p = str(tmp_path / "netspec.npz"), str(tmp_path / "model.p")
+    save_netspec(net, npz)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, pickle; sys.path[:0] = [%r, %r]; import pandapower as pp; net = pp.from_pickle(%r);"
+            "assert type(net).__module__ == 'pandapower.auxiliary';"
+            "net.pop('_branch_pu'); pickle.dump(net, open(%r, 'wb'), protocol=4)" % (root, os.path.join(root, "oracle", "pp_stub"), p, p))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert b"pandapower.auxiliary" in open(p, "rb").read()[:4000] or b"pandapower.auxiliary" in open(p, "rb").read()
+    assert "pandapower" not in sys.modules
+    got = read_pandapower_pickle(p)
+    assert isinstance(got, InertNet) and "pandapower" not in sys.modules
+    a = from_pandapower(got)
+    for k in ("bus_vn_kv", "bus_zone", "line_from_bus", "line_to_bus", "line_r_ohm_per_km", "line_x_ohm_per_km", "line_c_nf_per_km",
+              "line_length_km", "load_bus", "sgen_bus", "sgen_zone"):
+        assert np.array_equal(getattr(a, k), getattr(net, k)), k
+    assert a.ext_grid_bus == net.ext_grid_bus and a.sn_mva == net.sn_mva
+
+
+def test_model_p_with_code_in_it_is_refused(tmp_path):
+    """a pickle is a program: anything that is not a numpy / pandas / builtin data class is refused, pandapower classes are
+    replaced by inert stand-ins (their code never runs)"""
+    import pickle
+    from mapdn_amd.data import read_pandapower_pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > /dev/null",))
+    p = str(tmp_path / "model.p")
+    with open(p, "wb") as f:
+        pickle.dump({"bus": Evil(), "sn_mva": 1.0}, f, protocol=2)
+    with pytest.raises(pickle.UnpicklingError, match="refused"):
+        read_pandapower_pickle(p)
+    with open(p, "wb") as f:                                    # builtins.eval must not resolve either
+        f.write(b"cbuiltins\neval\n(S'1+1'\ntR.")
+    with pytest.raises(pickle.UnpicklingError, match="refused"):
+        read_pandapower_pickle(p)
+    with open(p, "wb") as f:                                    # a pre-2.0 net (kW / kVA columns) needs convert_format: refused
+        pickle.dump({"bus": {"DF": {"index": [0], "columns": ["vn_kv"], "data": [[20.0]]}, "dtypes": {}}, "sn_kva": 1000.0}, f, protocol=2)
+    with pytest.raises(NotImplementedError, match="convert_format"):
+        read_pandapower_pickle(p)
+
+
+def test_load_scenario_opens_a_directory_with_model_p(tmp_path):
+    """the reference's data directory layout: model.p + three CSVs, no netspec.npz, no pandapower"""
+    from mapdn_amd.data import load_scenario, save_profiles_csv
+    from mapdn_amd.netspec import make_case
+    _, prof = make_case("case33", days=3)
+    pnet = substation_net()
+    d = str(tmp_path)
+    _write_pp2_pickle(pnet, os.path.join(d, "model.p"))
+    from mapdn_amd.netspec import Profiles
+    small = Profiles(pv=prof.pv[:, :2], load_p=prof.load_p[:, :5], load_q=prof.load_q[:, :5], time_delta_min=3)
+    save_profiles_csv(small, d)
+    net, pr = load_scenario(d)
+    assert net.n_bus == 6 and net.n_sgen == 2 and pr.pv.shape == small.pv.shape and net.n_branch_pu == 1

@@ -937,3 +937,36 @@ def test_pv_bus_injection_equals_all_bus_injection(case, monkeypatch):
         assert torch.equal(la[0], lb[0]) and torch.equal(la[1], lb[1])
     assert n_resets >= 2 * B
     fast.close(); full.close()
+
+
+@pytest.mark.parametrize("case", ["case33", "case141", "case322"])
+def test_mismatch_pass_equals_mismatch_sweep(case, monkeypatch):
+    """The predicted-final mismatch evaluation runs as a barrier-free pass over all nodes (k_nr_tree::mismatch_pass, the default
+    when the h array is LDS-resident) instead of a mismatch-only tree sweep (MAPDN_NR_MM_PASS=0): same expressions summed in the
+    same canonical order, so iterations, flags and voltages are bit-identical — also with the predictor forced to 'always',
+    where every verdict after the first comes from the pass and a wrong prediction redoes the sweep in full."""
+    B = 96
+    net, prof = make_case(case)
+    rng = np.random.default_rng(8)
+    rows = rng.integers(0, prof.n_rows, B)
+    act = rng.uniform(-SCALE[case], SCALE[case], (B, net.n_sgen))
+    pl, ql, pv = prof.load_p[rows].copy(), prof.load_q[rows], prof.pv[rows]
+    qs = act * np.sqrt(prof.s_max() ** 2 - pv ** 2)
+    pl[11] *= 30.0                                   # one env that never converges
+    out = {}
+    for tag, mm, always in (("sweep", "0", False), ("pass", "1", False), ("sweep_always", "0", True), ("pass_always", "1", True)):
+        monkeypatch.setenv("MAPDN_NR_MM_PASS", mm)
+        if always:
+            monkeypatch.setenv("MAPDN_NR_CHECK_DX", "1e30"); monkeypatch.setenv("MAPDN_NR_CHECK_QUAD", "1e-300")
+        else:
+            monkeypatch.delenv("MAPDN_NR_CHECK_DX", raising=False); monkeypatch.delenv("MAPDN_NR_CHECK_QUAD", raising=False)
+        env = VoltageControlBatch(net, prof, args_for(case), n_envs=B, device="cuda:0")
+        out[tag] = [x.cpu().numpy() for x in env.solve(pl, ql, pv, qs)]
+        env.close()
+    vm0, va0, it0, cv0 = out["sweep"]
+    assert not cv0[11] and it0[11] == 10 and cv0[[0, 1, 50]].all()
+    ok = cv0.astype(bool)
+    for tag in ("pass", "sweep_always", "pass_always"):
+        vm, va, it, cv = out[tag]
+        assert np.array_equal(it, it0) and np.array_equal(cv, cv0), tag
+        assert np.array_equal(vm[ok], vm0[ok]) and np.array_equal(va[ok], va0[ok]), tag
