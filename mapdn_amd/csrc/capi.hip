@@ -158,16 +158,18 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   UP(load_ptr, P.load_ptr); UP(load_idx, P.load_idx); UP(sgen_ptr, P.sgen_ptr); UP(sgen_idx, P.sgen_idx);
   UP(shunt_p, P.shunt_p); UP(shunt_q, P.shunt_q); UP(load_scale, P.load_scale); UP(sgen_scale, P.sgen_scale);
   {
-    std::vector<int32_t> sgb, sgb_of(P.nb, -1), lb, mlb;
+    std::vector<int32_t> sgb, sgb_of(P.nb, -1), lb, mlo;
     for (int k = 0; k < P.nb; ++k) {
-      if (P.load_ptr[k + 1] - P.load_ptr[k] > 1) mlb.push_back(k);
       if (P.sgen_ptr[k + 1] > P.sgen_ptr[k]) { sgb_of[k] = (int32_t)sgb.size(); sgb.push_back(k); }
-      else if (P.load_ptr[k + 1] > P.load_ptr[k]) lb.push_back(k);
+      else if (P.load_ptr[k + 1] > P.load_ptr[k]) {
+        lb.push_back(k);
+        if (P.load_ptr[k + 1] - P.load_ptr[k] > 1 && k < P.n) mlo.push_back(k);
+      }
     }
-    d.n_sgb = (int32_t)sgb.size(); d.n_lb = (int32_t)lb.size(); d.n_mlb = (int32_t)mlb.size();
+    d.n_sgb = (int32_t)sgb.size(); d.n_lb = (int32_t)lb.size(); d.n_mlo = (int32_t)mlo.size();
     if (lb.empty()) lb.push_back(0);
-    if (mlb.empty()) mlb.push_back(0);
-    UP(sgb_pos, sgb); UP(sgb_of_pos, sgb_of); UP(lb_pos, lb); UP(mlb_pos, mlb);
+    if (mlo.empty()) mlo.push_back(0);
+    UP(sgb_pos, sgb); UP(sgb_of_pos, sgb_of); UP(lb_pos, lb); UP(mlo_pos, mlo);
     h->ld_dest_host.assign(std::max(P.nl, 1), 2);             // filled once the Sbus order (sb_index) is known, see alloc_nrbuf
     rc = dalloc(h, &d.bus_ld, (size_t)2 * d.n_sgb * d.Bp); if (rc) return rc;
     if (const char* s_ = getenv("MAPDN_INJECT_FULL")) h->inject_full = atoi(s_) != 0;

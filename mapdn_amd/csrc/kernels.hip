@@ -174,9 +174,10 @@ template <typename AT>
 __global__ void __launch_bounds__(256)
 k_inject_sgen(Dev d, int mode, const AT* __restrict__ actions, int add_noise) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int jb = blockIdx.y;                     // PV-bus number
+  const int jb = blockIdx.y;                     // PV-bus number; rows beyond: buses with SEVERAL loads and no sgens
   if (e >= d.B) return;
-  const int k = d.sgb_pos[jb];                   // its elimination position (n == slack: q only, no Sbus row)
+  const bool mlo_row = jb >= d.n_sgb;
+  const int k = mlo_row ? d.mlo_pos[jb - d.n_sgb] : d.sgb_pos[jb];   // elimination position (n == slack: q only, no Sbus row)
   bool act, ar = false;
   if (mode == MODE_STEP) {
     const bool dn = d.done[e] != 0;
@@ -198,8 +199,24 @@ k_inject_sgen(Dev d, int mode, const AT* __restrict__ actions, int add_noise) {
     }
   }
   if (!act) return;                              // frozen: q_new, Sbus stay as they are
-  double2* const bl = (double2*)d.bus_ld + (size_t)jb * d.Bp + e;
   double2* const sbp = (double2*)((char*)d.nrbuf + d.sb_off) + e;
+  // the load sum of a bus with several loads needs ONE thread (canonical order of its CSR list): formed here from the load
+  // values k_advance stored for this step (a restarting env forms all its sums below)
+  auto stored_load_sum = [&](int kk, double& Ps, double& Qs) {
+    Ps = 0.0; Qs = 0.0;
+    for (int i = d.load_ptr[kk]; i < d.load_ptr[kk + 1]; ++i) {
+      const int li = d.load_idx[i];
+      Ps += d.cur_pl[(size_t)li * d.Bp + e] * d.load_scale[li]; Qs += d.cur_ql[(size_t)li * d.Bp + e] * d.load_scale[li];
+    }
+  };
+  if (mlo_row) {
+    if (ar || k >= d.n) return;
+    double Ps, Qs;
+    stored_load_sum(k, Ps, Qs);
+    sbp[(size_t)d.sb_index[k] * d.Bp] = make_double2(-Ps / d.sn, -Qs / d.sn);
+    return;
+  }
+  double2* const bl = (double2*)d.bus_ld + (size_t)jb * d.Bp + e;
   double P, Q;
   if (ar) {
     auto load_sum = [&](int kk, double& Ps, double& Qs) {
@@ -225,7 +242,8 @@ k_inject_sgen(Dev d, int mode, const AT* __restrict__ actions, int add_noise) {
         ((double2*)((char*)d.nrbuf + d.sb_off_alt))[(size_t)d.sb_index[kk] * d.Bp + e] = v;
       }
     }
-  } else { const double2 v = *bl; P = v.x; Q = v.y; }
+  } else if (d.load_ptr[k + 1] - d.load_ptr[k] > 1) stored_load_sum(k, P, Q);
+  else { const double2 v = *bl; P = v.x; Q = v.y; }
   for (int i = d.sgen_ptr[k]; i < d.sgen_ptr[k + 1]; ++i) {
     const int j = d.sgen_idx[i];
     const size_t o = (size_t)j * d.Bp + e;
@@ -355,7 +373,8 @@ struct RecF { u32x4 ix; d2 s, i01, i23, ap, sb; };      // flat-start form: host
 struct BwdF { d2 h, g01, g23; };                        // factors of one step when they come from global memory
 
 // HL / GL: the h / G factors live in LDS (when they fit) instead of global scratch.  RES: 1 = step records and flat-start
-// constants are LDS-resident (compile-time: the "fat" geometry), 2 = neither is (the "lean" one), 0 = per handle (d.nr_*_lds)
+// constants are LDS-resident (compile-time: the "fat" geometry), 2 = neither is (the "lean" one), 3 = the records are, the
+// flat-start constants are not (the 322-bus feeder: W = 4, L = 8), 0 = per handle (d.nr_*_lds)
 template <int W, int L, bool HL, bool GL, int RES = 0>
 __global__ void __launch_bounds__(64 * W)
 k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ terminated, double* __restrict__ info) {
@@ -480,8 +499,8 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // address; the scalar row offset is the only thing that changes (prefetches past the ends are clamped, never
   // skipped: every step issues the same VMEM instructions and the compiler's s_waitcnt counts stay exact)
   auto row_s = [&](int row, unsigned stride) { return __builtin_amdgcn_readfirstlane((unsigned)row * stride); };
-  const bool recL = RES == 1 ? true : RES == 2 ? false : d.nr_rec_lds != 0;      // wave-uniform; compile-time when RES != 0
-  const bool flatL = RES == 1 ? true : RES == 2 ? false : d.nr_flat_lds != 0;
+  const bool recL = (RES == 1 || RES == 3) ? true : RES == 2 ? false : d.nr_rec_lds != 0;      // wave-uniform; compile-time when RES != 0
+  const bool flatL = RES == 1 ? true : (RES == 2 || RES == 3) ? false : d.nr_flat_lds != 0;
   const char* recT = s_rec + voT;                  // this worker's records / flat steps in LDS
   const char* flatT = s_flat + voF;
   // RB ("record broadcast", 16 or 32 envs per workgroup: a worker is one or two whole 16-lane DPP rows).  The 16 lanes of a
@@ -1109,10 +1128,11 @@ __global__ void __launch_bounds__(256) k_reset_begin(Dev d, const int64_t* __res
 //      profile tables + std/100 * |N(0,1)| noise (:498,503,508), and the commit of res_bus for the solve that just finished.
 //      rows [0, npv): thread = (Philox block of the PV table, env): one Philox4x32-10 call + one Box-Muller pair serves two
 //                     adjacent PV columns;
-//      rows of the load_p / load_q tables likewise (two loads per thread); a load that is alone on its bus IS that bus's load
-//                     sum, so the thread also stores what the next k_inject_sgen / solve needs — the finished Sbus half of a
-//                     bus without sgens, the load part (bus_ld) of a PV bus;
-//      n_mlb rows:    thread = (bus with several loads, env): that bus's load sum in the canonical CSR order;
+//      load rows:     thread = (pair of loads, env): their P and Q values (one Philox block of each of the two load streams);
+//                     a load that is alone on its bus IS that bus's load sum, so the thread also stores what the next
+//                     k_inject_sgen / solve needs — the finished Sbus entry of a bus without sgens, the load part (bus_ld) of
+//                     a PV bus — as one 16-byte (P, Q) store;
+//                     (the load sum of a bus with SEVERAL loads is formed by the next k_inject_sgen from the stored values);
 //      then nb rows:  thread = (bus position, env): the K6 commit.
 //      Sbus is DOUBLE-BUFFERED: the commit reads the buffer the solve used (d.sb_off) while the load rows of the same launch
 //      write the buffer of the next solve (`sb_write_off`: the other one in step(), the same one in reset(), where the
@@ -1122,8 +1142,8 @@ __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_pr
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.B) return;
   const int npv = (d.ns + 1) >> 1, npl = (d.nl + 1) >> 1;
-  const int npairs = do_profiles ? npv + 2 * npl : 0;
-  const int nmb = do_profiles ? d.n_mlb : 0;
+  const int npairs = do_profiles ? npv + npl : 0;
+  const int nmb = 0;
   const size_t S = (size_t)d.Bp;
   double2* const sbw = (double2*)((char*)d.nrbuf + sb_write_off) + e;
   if ((int)blockIdx.y >= npairs + nmb) {
@@ -1157,33 +1177,8 @@ __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_pr
   const int64_t row = d.adv_row[e];
   if (row < 0 || row >= d.T) return;               // never read outside the table
   const uint32_t draw = d.adv_draw[e];
-  if ((int)blockIdx.y >= npairs) {
-    // ---- a bus with SEVERAL loads: its load sum needs one thread (canonical order of the CSR list); the values themselves
-    // are the ones the pair threads store, recomputed element by element
-    const int k = d.mlb_pos[(int)blockIdx.y - npairs];
-    double P = 0.0, Q = 0.0;
-    for (int i = d.load_ptr[k]; i < d.load_ptr[k + 1]; ++i) {
-      const int li = d.load_idx[i];
-      const double p = profile_value(d, e, row, draw, STREAM_LOAD_P, li, d.ns, add_noise);
-      const double q = profile_value(d, e, row, draw, STREAM_LOAD_Q, li, d.ns + d.nl, add_noise);
-      P += p * d.load_scale[li]; Q += q * d.load_scale[li];   // pd2ppc: PD = sum p_mw * scaling
-    }
-    const int jb = d.sgb_of_pos[k];
-    if (jb >= 0) ((double2*)d.bus_ld)[(size_t)jb * S + e] = make_double2(P, Q);
-    else if (k < d.n) sbw[(size_t)d.sb_index[k] * S] = make_double2(-P / d.sn, -Q / d.sn);
-    return;
-  }
-  int b = blockIdx.y;                              // pair index over [pv pairs | load_p pairs | load_q pairs]
-  int stream, count, col0, comp = 0;
-  double* dst;
-  if (b < npv) { stream = STREAM_PV; count = d.ns; col0 = 0; dst = d.cur_pv; }
-  else if (b < npv + npl) { b -= npv; stream = STREAM_LOAD_P; count = d.nl; col0 = d.ns; dst = d.cur_pl; }
-  else { b -= npv + npl; stream = STREAM_LOAD_Q; count = d.nl; col0 = d.ns + d.nl; dst = d.cur_ql; comp = 1; }
-  const int j0 = 2 * b, j1 = 2 * b + 1;
-  const double* trow = d.table + (size_t)row * d.ncol + col0;
-  double v0 = trow[j0];
-  double v1 = (j1 < count) ? trow[j1] : 0.0;
-  if (add_noise) {
+  // Box-Muller pair of Philox block b of a stream: the two half-normal noise factors of columns 2b, 2b + 1
+  auto noise_pair = [&](int stream, int b, double& n0, double& n1) {
     uint32_t x[4];
     philox4x32_10((uint32_t)(d.env_id_offset + e), draw, (uint32_t)stream, (uint32_t)b, d.seed_lo, d.seed_hi, x);
     const double u1 = (u53(x[0], x[1]) + 0.5) * (1.0 / 9007199254740992.0);
@@ -1191,25 +1186,50 @@ __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_pr
     const double r = sqrt(-2.0 * log(u1));
     double sn_, cs_;
     sincos(2.0 * M_PI * u2, &sn_, &cs_);
-    v0 += d.stdv[col0 + j0] * fabs(r * cs_);
-    if (j1 < count) v1 += d.stdv[col0 + j1] * fabs(r * sn_);
-  }
-  dst[(size_t)j0 * d.Bp + e] = v0;
-  if (j1 < count) dst[(size_t)j1 * d.Bp + e] = v1;
-  if (stream == STREAM_PV) return;
-  // ---- a load that is ALONE on its bus is the bus's whole load sum (0 + p * scaling, as k_inject forms it): its P (this thread)
-  // and Q (the thread of the other stream) halves go straight to where the next k_inject_sgen / solve reads them —
-  // ld_dest[li] = entry << 2 | kind: kind 0 Sbus entry of the next solve, 1 bus_ld row of a PV bus, 2 nothing (bus with several
-  // loads: the rows above; loads on the slack bus)
-  auto route = [&](int li, double v) {
-    const int dd = d.ld_dest[li];
-    const double ps = v * d.load_scale[li];
-    double* base;
-    if ((dd & 3) == 0) { base = (double*)(sbw + (size_t)(dd >> 2) * S); base[comp] = -ps / d.sn; }
-    else if ((dd & 3) == 1) { base = (double*)((double2*)d.bus_ld + (size_t)(dd >> 2) * S + e); base[comp] = ps; }
+    n0 = fabs(r * cs_); n1 = fabs(r * sn_);
   };
-  route(j0, v0);
-  if (j1 < count) route(j1, v1);
+  int b = blockIdx.y;                              // pair index over [pv pairs | load pairs]
+  if (b < npv) {
+    const int j0 = 2 * b, j1 = 2 * b + 1;
+    const double* trow = d.table + (size_t)row * d.ncol;
+    double v0 = trow[j0], v1 = (j1 < d.ns) ? trow[j1] : 0.0;
+    if (add_noise) {
+      double n0, n1;
+      noise_pair(STREAM_PV, b, n0, n1);
+      v0 += d.stdv[j0] * n0;
+      if (j1 < d.ns) v1 += d.stdv[j1] * n1;
+    }
+    d.cur_pv[(size_t)j0 * S + e] = v0;
+    if (j1 < d.ns) d.cur_pv[(size_t)j1 * S + e] = v1;
+    return;
+  }
+  // ---- two loads: their P (stream LOAD_P) and Q (stream LOAD_Q) values.  A load that is ALONE on its bus is the bus's whole
+  // load sum (0 + p * scaling, as k_inject forms it), so the (P, Q) pair goes straight to where the next k_inject_sgen / solve
+  // reads it, as one 16-byte store — ld_dest[li] = entry << 2 | kind: kind 0 Sbus entry of the next solve, 1 bus_ld row of a
+  // PV bus, 2 nothing (bus with several loads: the rows above; loads on the slack bus)
+  b -= npv;
+  const int j0 = 2 * b, j1 = 2 * b + 1;
+  const bool has1 = j1 < d.nl;
+  const double* trp = d.table + (size_t)row * d.ncol + d.ns;
+  const double* trq = trp + d.nl;
+  double p0 = trp[j0], q0 = trq[j0], p1 = has1 ? trp[j1] : 0.0, q1 = has1 ? trq[j1] : 0.0;
+  if (add_noise) {
+    double n0, n1, m0, m1;
+    noise_pair(STREAM_LOAD_P, b, n0, n1);
+    noise_pair(STREAM_LOAD_Q, b, m0, m1);
+    p0 += d.stdv[d.ns + j0] * n0; q0 += d.stdv[d.ns + d.nl + j0] * m0;
+    if (has1) { p1 += d.stdv[d.ns + j1] * n1; q1 += d.stdv[d.ns + d.nl + j1] * m1; }
+  }
+  auto put = [&](int li, double p, double q) {
+    d.cur_pl[(size_t)li * S + e] = p; d.cur_ql[(size_t)li * S + e] = q;
+    const int dd = d.ld_dest[li];
+    const double sc = d.load_scale[li];
+    const double ps = p * sc, qs = q * sc;
+    if ((dd & 3) == 0) sbw[(size_t)(dd >> 2) * S] = make_double2(-ps / d.sn, -qs / d.sn);
+    else if ((dd & 3) == 1) ((double2*)d.bus_ld)[(size_t)(dd >> 2) * S + e] = make_double2(ps, qs);
+  };
+  put(j0, p0, q0);
+  if (has1) put(j1, p1, q1);
 }
 
 // =================================================================================================
@@ -1340,6 +1360,8 @@ constexpr int nr_res(int w, int l, bool h_lds) {
 }
 // h in LDS, records and flat constants in global memory: the fat layout of nets whose schedule does not fit (case322: W = 4, L = 8)
 constexpr int nr_res_hg(int w, int l) { return (w == 4 && l == 8) ? 2 : 0; }
+// ... records resident, flat constants in global memory: what the 322-bus feeder gets by default
+constexpr int nr_res_hr(int w, int l) { return (w == 4 && l == 8) ? 3 : 0; }
 // (W, L) instantiations of k_nr_tree
 #define NR_FOR_EACH(X) X(1, 8) X(1, 16) X(1, 32) X(2, 8) X(2, 16) X(2, 32) X(4, 8) X(4, 16) X(4, 32) X(8, 16)
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
@@ -1353,6 +1375,7 @@ void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* in
     else if (d.nr_h_lds && d.nr_g_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, true>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
     else if (d.nr_h_lds && d.nr_rec_lds && d.nr_flat_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, false, nr_res(w, l, true)>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
     else if (d.nr_h_lds && !d.nr_rec_lds && !d.nr_flat_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, false, nr_res_hg(w, l)>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
+    else if (d.nr_h_lds && d.nr_rec_lds && !d.nr_flat_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, false, nr_res_hr(w, l)>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
     else if (d.nr_h_lds) hipLaunchKernelGGL((k_nr_tree<w, l, true, false>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
     else if (!d.nr_rec_lds && !d.nr_flat_lds) hipLaunchKernelGGL((k_nr_tree<w, l, false, false, nr_res(w, l, false)>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
     else hipLaunchKernelGGL((k_nr_tree<w, l, false, false>), grid, dim3(64 * w), lds, st, d, mode, reward, term, info); \
@@ -1364,7 +1387,7 @@ int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, size_t bytes) {
 #define X(w, l) if (waves == w && lanes == l) { \
     const void* fs[] = {(const void*)k_nr_tree<w, l, true, true>, (const void*)k_nr_tree<w, l, true, true, nr_res(w, l, true)>, \
                         (const void*)k_nr_tree<w, l, true, false>, (const void*)k_nr_tree<w, l, true, false, nr_res(w, l, true)>, \
-                        (const void*)k_nr_tree<w, l, true, false, nr_res_hg(w, l)>, \
+                        (const void*)k_nr_tree<w, l, true, false, nr_res_hg(w, l)>, (const void*)k_nr_tree<w, l, true, false, nr_res_hr(w, l)>, \
                         (const void*)k_nr_tree<w, l, false, false>, (const void*)k_nr_tree<w, l, false, false, nr_res(w, l, false)>}; \
     for (const void* f : fs) if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1; \
     return 0; }
@@ -1378,12 +1401,12 @@ void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, 
 // do_profiles: next profile row + noise for the envs queued in adv_row; do_commit: res_bus commit of
 // the envs flagged by the preceding k_nr_tree launch
 void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off, hipStream_t st) {
-  const int rows = (do_profiles ? ((d.ns + 1) >> 1) + 2 * ((d.nl + 1) >> 1) + d.n_mlb : 0) + (do_commit ? d.nb : 0);
+  const int rows = (do_profiles ? ((d.ns + 1) >> 1) + ((d.nl + 1) >> 1) : 0) + (do_commit ? d.nb : 0);
   if (rows == 0) return;
   hipLaunchKernelGGL(k_advance, dim3((d.B + 255) / 256, rows), dim3(256), 0, st, d, add_noise, do_profiles, do_commit, sb_write_off);
 }
 void launch_inject_sgen(const Dev& d, int mode, const void* actions, int dtype, int add_noise, hipStream_t st) {
-  const dim3 grid((d.B + 255) / 256, d.n_sgb);
+  const dim3 grid((d.B + 255) / 256, d.n_sgb + d.n_mlo);
   if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_inject_sgen<float>, grid, dim3(256), 0, st, d, mode, (const float*)actions, add_noise);
   else hipLaunchKernelGGL(k_inject_sgen<double>, grid, dim3(256), 0, st, d, mode, (const double*)actions, add_noise);
 }

@@ -36,7 +36,7 @@ struct Dev {
   const double *load_scale, *sgen_scale;     // [nl], [ns] element scaling * in_service (runpp sees p, q * scaling)
   // buses with sgens ("PV buses", n_sgb of them: positions sgb_pos, inverse sgb_of_pos[nb] or -1) and buses with loads but no
   // sgens (lb_pos, n_lb): k_inject_sgen works on the former; bus_ld [n_sgb][Bp] pairs = load part (P, Q) of their injection
-  const int32_t *sgb_pos, *sgb_of_pos, *lb_pos, *mlb_pos, *ld_dest; int32_t n_sgb, n_lb, n_mlb;   // mlb_pos: buses with several loads;
+  const int32_t *sgb_pos, *sgb_of_pos, *lb_pos, *mlo_pos, *ld_dest; int32_t n_sgb, n_lb, n_mlo;   // mlo_pos: buses with several loads and no sgens;
                                                    // ld_dest[nl]: where a load that is alone on its bus goes (see k_advance)
   double* bus_ld;
   const LineFlow* lines;
