@@ -223,7 +223,7 @@ def measure_traffic(case, envs):
 
 
 def committed_traffic(case, envs):
-    for tag in ("r02_final", "r02_base", "r01"):
+    for tag in ("r03_final", "r02_final", "r02_base", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_traffic_{case}_b{envs}.json")
         if os.path.exists(path):
             return json.load(open(path))["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)

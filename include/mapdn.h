@@ -145,6 +145,8 @@ const char* mapdn_last_error(const mapdn_handle* h);
  *   MAPDN_NR_LEAN (0/1)                                    1: only voltages + hand-off slots in LDS (several workgroups per CU)
  *   MAPDN_NR_H_LDS, MAPDN_NR_G_LDS, MAPDN_NR_REC_LDS,      keep the h / G factors, the step records, the flat-start constants,
  *   MAPDN_NR_FLAT_LDS, MAPDN_NR_LINE_LDS (0/1)             the net.line constants in LDS (default: whatever fits, in that order)
+ *   MAPDN_NR_MM_PASS (0/1, default 1 with h in LDS)        0: the predicted-final mismatch evaluation runs as a mismatch-only tree
+ *                                                          sweep instead of the barrier-free pass over all nodes (same bits)
  *   MAPDN_INJECT_FULL (0/1)                                1: step() / reset() rebuild Sbus on every bus (k_inject) instead of on
  *                                                          the PV buses only (k_inject_sgen); same bits, for A/B runs and tests
  *   MAPDN_NR_CHECK_DX (default 1e-7)                       Newton-step size below which the next sweep is
