@@ -263,6 +263,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the timed --steps block until the blocks add up to this")
     ap.add_argument("--inner", action="store_true", help="(internal) short un-instrumented loop for the PMC sub-runs")
+    ap.add_argument("--no-other-shapes", action="store_true", help="skip the short case33 / case322 measurements appended to the default line")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -295,101 +296,123 @@ def main():
     from mapdn_amd.netspec import make_case
     from mapdn_amd.sharding import gather_rollout
 
-    net, prof = make_case(a.case)
-    B = a.envs
-    args = dict(episode_limit=240, action_scale=SCALE[a.case], action_bias=0.0, voltage_barrier_type="bowl", seed=0)
-    env = VoltageControlBatch(net, prof, args, n_envs=B, device=dev, env_id_offset=rank * B)   # weak scaling
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    scale = SCALE[a.case]
-    # fresh random actions for every step, drawn on the device BEFORE the timed region so that the
-    # (excluded) policy costs nothing inside it; a ring of `n_act` distinct action tensors
-    n_act = min(a.steps + a.warmup + 60, 256)
-    acts = torch.empty(n_act, B, env.n_sgen, dtype=torch.float32, device=dev).uniform_(-scale, scale, generator=gen)
-    steps_in_ep = [0]
-    step_no = [0]
-
-    def one_step():
-        act = acts[step_no[0] % n_act]
-        step_no[0] += 1
-        env.step(act)
-        env.get_obs()
-        steps_in_ep[0] += 1
-        if steps_in_ep[0] >= env.episode_limit - 1:           # all envs terminate together (:204)
-            env.reset()
-            steps_in_ep[0] = 0
-
     def fence():
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    resets = [0]
-    _orig_reset = env.reset
+    def measure(case, B, min_seconds, inner=False):
+        """The timed loop on one (case, envs per GPU): returns the block times (max over ranks), the env and its NR timing."""
+        net, prof = make_case(case)
+        args = dict(episode_limit=240, action_scale=SCALE[case], action_bias=0.0, voltage_barrier_type="bowl", seed=0)
+        env = VoltageControlBatch(net, prof, args, n_envs=B, device=dev, env_id_offset=rank * B)   # weak scaling
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1234 + rank)
+        scale = SCALE[case]
+        # fresh random actions for every step, drawn on the device BEFORE the timed region so that the
+        # (excluded) policy costs nothing inside it; a ring of `n_act` distinct action tensors
+        n_act = min(a.steps + a.warmup + 60, 256)
+        acts = torch.empty(n_act, B, env.n_sgen, dtype=torch.float32, device=dev).uniform_(-scale, scale, generator=gen)
+        steps_in_ep, step_no, resets = [0], [0], [0]
 
-    def counted_reset(*x, **k):
-        resets[0] += 1
-        return _orig_reset(*x, **k)
-    env.reset = counted_reset
+        def one_step():
+            act = acts[step_no[0] % n_act]
+            step_no[0] += 1
+            env.step(act)
+            env.get_obs()
+            steps_in_ep[0] += 1
+            if steps_in_ep[0] >= env.episode_limit - 1:       # all envs terminate together (:204)
+                env.reset()
+                resets[0] += 1
+                steps_in_ep[0] = 0
 
-    def timed_block():
-        """EXACTLY a.steps steps between two fences (barrier + device sync on both sides); max over ranks"""
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
+        def timed_block():
+            """EXACTLY a.steps steps between two fences (barrier + device sync on both sides); max over ranks"""
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                one_step()
+            if dist is not None:                              # end-of-rollout RCCL gather (SURVEY 8(e)), inside the timed region
+                ret = env.episode_returns()
+                allret = gather_rollout(ret if a.backend == "nccl" else ret.cpu())
+                assert allret.shape[0] == world * B
+            fence()
+            dt = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            return dt
+
+        env.reset()
+        for _ in range(a.warmup):
             one_step()
-        if dist is not None:                                  # end-of-rollout RCCL gather (SURVEY 8(e)), inside the timed region
-            ret = env.episode_returns()
-            allret = gather_rollout(ret if a.backend == "nccl" else ret.cpu())
-            assert allret.shape[0] == world * B
-        fence()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        if inner:
+            timed_block()
+            env.close()
+            return None
+        # A block of `--steps` steps can be a few milliseconds (the driver's --steps 20 is 2.3 ms): the block is repeated, each
+        # repeat fenced and timed on its own, until the timed blocks add up to >= min_seconds (every rank runs the same number:
+        # the decision uses the max-over-ranks times).  `ms_per_step` / `value` are the MEDIAN block; min / max are reported.
+        resets[0] = 0
+        blocks = []
+        while len(blocks) < 3 or (sum(blocks) < min_seconds and len(blocks) < 2000):
+            blocks.append(timed_block())
+        resets_in_region = resets[0]
+        stats = env.stats()
+        # ---- dominant kernel (NR solve) duration, HIP events on its launch stream, separate short pass
+        env.nr_timing(True)
+        for _ in range(min(a.steps, 60)):
+            one_step()
+        torch.cuda.synchronize(dev)
+        nr_ms, nr_launches = env.nr_time_ms()
+        env.nr_timing(False)
+        nr_avg_rank_ms = nr_ms / max(nr_launches, 1)
+        nr_per_rank = [nr_avg_rank_ms]
+        if dist is not None:                                  # the dominant kernel's average duration on every rank; the roofline uses the slowest
+            t = torch.zeros(world, dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+            t[rank] = nr_avg_rank_ms
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            nr_per_rank = [float(x) for x in t.tolist()]
+        return dict(env=env, blocks=blocks, resets=resets_in_region, stats=stats, nr_per_rank=nr_per_rank, nr_launches=nr_launches)
 
-    env.reset()
-    for _ in range(a.warmup):
-        one_step()
+    B = a.envs
+    m = measure(a.case, B, a.min_seconds, inner=a.inner)
     if a.inner:
-        timed_block()
-        env.close()
         return
-    # A block of `--steps` steps can be a few milliseconds (the driver's --steps 20 is 2.5 ms): the block is repeated, each
-    # repeat fenced and timed on its own, until the timed blocks add up to >= --min-seconds (every rank runs the same number:
-    # the decision uses the max-over-ranks times).  `ms_per_step` / `value` are the MEDIAN block; min / max are reported.
-    resets[0] = 0
-    blocks = []
-    while len(blocks) < 3 or (sum(blocks) < a.min_seconds and len(blocks) < 2000):
-        blocks.append(timed_block())
-    resets_in_region = resets[0]
+    env, blocks, resets_in_region, stats = m["env"], m["blocks"], m["resets"], m["stats"]
+    nr_per_rank, nr_launches = m["nr_per_rank"], m["nr_launches"]
     blocks_sorted = sorted(blocks)
     dt = blocks_sorted[len(blocks) // 2]
-    stats = env.stats()
-
-    # ---- dominant kernel (NR solve) duration, HIP events on its launch stream, separate short pass
-    env.nr_timing(True)
-    for _ in range(min(a.steps, 60)):
-        one_step()
-    torch.cuda.synchronize(dev)
-    nr_ms, nr_launches = env.nr_time_ms()
-    env.nr_timing(False)
     kname = "k_nr_tree"
-    nr_avg_rank_ms = nr_ms / max(nr_launches, 1)
-    nr_per_rank = [nr_avg_rank_ms]
-    if dist is not None:                                      # the dominant kernel's average duration on every rank; the roofline uses the slowest
-        t = torch.zeros(world, dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
-        t[rank] = nr_avg_rank_ms
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        nr_per_rank = [float(x) for x in t.tolist()]
+    head = dict(n_bus=env.n_bus, n_agents=env.n_agents, obs_size=env.obs_size, bytes_step=algorithmic_bytes_per_env_step(env))
+    env.close()
+
+    # ---- the other shapes north_star names, in the same run and under the same clock (short: 0.2 s of timed blocks each):
+    # case33 x 4096 (BASELINE configs[1]) and the per-GPU shards of the two case322 configurations (8192 / 8, 65536 / 8)
+    shapes = []
+    if not a.no_other_shapes and a.case == "case141" and B == 4096:
+        for c2, b2 in (("case33", 4096), ("case322", 1024), ("case322", 8192)):
+            m2 = measure(c2, b2, 0.2)
+            e2 = m2["env"]
+            bl = sorted(m2["blocks"])
+            d2 = bl[len(bl) // 2]
+            by2 = algorithmic_bytes_per_env_step(e2)
+            nr2 = max(m2["nr_per_rank"]) * 1e-3
+            shapes.append({"workload": f"{c2} ({e2.n_bus}-bus, {e2.n_agents} agents), {b2} envs per GPU, step()+get_obs()",
+                           "value": world * b2 * a.steps / d2, "unit": "env-steps/s", "ms_per_step": d2 / a.steps * 1e3, "repeats": len(bl),
+                           "ms_per_step_repeats": {"min": bl[0] / a.steps * 1e3, "max": bl[-1] / a.steps * 1e3},
+                           "nr_iterations": {"mean": m2["stats"]["mean_nr_iters"], "max": m2["stats"]["max_nr_iters"]},
+                           "roofline": {"bound": "hbm", "achieved": by2 * b2 / nr2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": by2 * b2 / nr2 / 1e9 / HBM_PEAK_GBS, "kernel_avg_ms": nr2 * 1e3,
+                                        "algorithmic_bytes_per_env_step": by2, "traffic": committed_traffic(c2, b2)[0]}})
+            e2.close()
 
     if rank == 0:
         n_gpus = world
         value = n_gpus * B * a.steps / dt
-        bytes_step = algorithmic_bytes_per_env_step(env)
+        bytes_step = head["bytes_step"]
         nr_avg_s = max(nr_per_rank) * 1e-3
         achieved = bytes_step * B / nr_avg_s / 1e9
         traffic, tsrc, tdetail = None, None, None
@@ -401,7 +424,7 @@ def main():
             traffic, tsrc = committed_traffic(a.case, B)
             if tsrc:
                 tsrc = f"committed rocprofv3 PMC passes: {tsrc}"
-        flops_step = 184.0 * env.n_bus * (stats["mean_nr_iters"] + 1.0)
+        flops_step = 184.0 * head["n_bus"] * (stats["mean_nr_iters"] + 1.0)
         tfl = flops_step * B / nr_avg_s / 1e12
         out = {
             "metric": "env-steps/sec (whole node), case141 batch=4096, at 1/2/4/8 MI355X",
@@ -411,13 +434,13 @@ def main():
             "ms_per_step_repeats": {"min": blocks_sorted[0] / a.steps * 1e3, "median": dt / a.steps * 1e3,
                                     "max": blocks_sorted[-1] / a.steps * 1e3},
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{a.case} ({env.n_bus}-bus, {env.n_agents} agents), {B} parallel envs per GPU, "
+            "config": {"workload": f"{a.case} ({head['n_bus']}-bus, {head['n_agents']} agents), {B} parallel envs per GPU, "
                                    f"bowl voltage barrier, step()+get_obs(), 240-step episodes; "
                                    + (f"{resets_in_region} whole-batch reset(s) fell inside the {len(blocks)} timed block(s) "
                                       f"(their power flows are extra work, not counted as env-steps)" if resets_in_region else
                                       f"no episode boundary fell inside the {len(blocks)} timed block(s) of {a.steps} steps"),
                        "resets_in_timed_region": resets_in_region,
-                       "envs_per_gpu": B, "global_envs": n_gpus * B, "obs_size": env.obs_size,
+                       "envs_per_gpu": B, "global_envs": n_gpus * B, "obs_size": head["obs_size"],
                        "parallelism": f"env-batch sharded x{n_gpus}, no data-path collective; one all_gather of episode "
                                       f"returns ({a.backend}) at the end of the rollout, inside the timed region"},
             "nr_iterations": {"mean": stats["mean_nr_iters"], "max": stats["max_nr_iters"]},
@@ -438,10 +461,11 @@ def main():
                         "note": "f64 vector (no MFMA on the radial path: the Jacobian is eliminated without fill, there is no "
                                 "dense contraction)"},
         }
+        if shapes:
+            out["other_shapes"] = shapes
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    env.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
