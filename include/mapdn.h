@@ -268,6 +268,18 @@ int mapdn_policy_forward(const float* obs, const float* hid_in, const float* w1,
  * fit the 160 KB LDS of a CU: obs_dim up to ~2 400 columns without ids), else 0 — callers then keep their own forward. */
 int mapdn_policy_forward_fits(int32_t obs_dim, int32_t id_dim);
 
+/* LayerNorm over 64 features (+ fused ReLU when relu != 0) for the learner's training-time passes (agents/rnn_agent.py:16-21,
+ * critics/mlp_critic.py:22-27: fc1 -> LayerNorm -> ReLU), forward and backward; device pointers, fp32, contiguous [rows, 64].
+ * forward also writes the row statistics (mean, rstd [rows]) the backward needs.  backward: dx [rows, 64], dgamma, dbeta [64];
+ * `partial` is scratch of mapdn_layernorm64_backward_blocks(rows) x 128 floats (block partial sums, reduced in a fixed order:
+ * deterministic, no atomics). */
+int mapdn_layernorm64_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                              int64_t rows, float eps, int32_t relu, void* stream);
+int mapdn_layernorm64_backward_blocks(int64_t rows);
+int mapdn_layernorm64_backward(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                               const float* rstd, float* dx, float* dgamma, float* dbeta, float* partial, int64_t rows,
+                               int32_t relu, void* stream);
+
 /* counters (host, synchronises the given stream): number of envs whose last reset exhausted
  * max_tries; mean / max NR iterations of the last solve */
 int mapdn_stats(mapdn_handle* h, int64_t* reset_failures, double* mean_iters, int32_t* max_iters,

@@ -31,7 +31,7 @@ EXPORTS = (
     "mapdn_step", "mapdn_get_start_rows", "mapdn_get_returns", "mapdn_get_obs", "mapdn_get_state", "mapdn_get_results", "mapdn_get_loads",
     "mapdn_solve_only", "mapdn_get_ybus_dense", "mapdn_get_obs_index", "mapdn_get_schedule", "mapdn_get_flat_factors", "mapdn_stats", "mapdn_nr_timing",
     "mapdn_nr_time_ms", "mapdn_get_auto_reset_mask", "mapdn_dense_solve", "mapdn_step_obs", "mapdn_get_sparse_program", "mapdn_policy_forward",
-    "mapdn_policy_forward_fits",
+    "mapdn_policy_forward_fits", "mapdn_layernorm64_forward", "mapdn_layernorm64_backward", "mapdn_layernorm64_backward_blocks",
 )
 
 _pd = C.POINTER(C.c_double)
@@ -127,6 +127,9 @@ def load():
     lib.mapdn_get_sparse_program.argtypes = [vp, C.c_int32, _pi, _pi, _pi, _pi]
     lib.mapdn_policy_forward.argtypes = [vp] * 14 + [C.c_int32] * 4 + [C.c_float, vp]
     lib.mapdn_policy_forward_fits.argtypes = [C.c_int32, C.c_int32]
+    lib.mapdn_layernorm64_forward.argtypes = [vp] * 6 + [C.c_int64, C.c_float, C.c_int32, vp]
+    lib.mapdn_layernorm64_backward_blocks.argtypes = [C.c_int64]
+    lib.mapdn_layernorm64_backward.argtypes = [vp] * 10 + [C.c_int64, C.c_int32, vp]
     lib.mapdn_dense_solve.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, vp]
     lib.mapdn_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int32), vp]
     lib.mapdn_nr_timing.argtypes = [vp, C.c_int32]

@@ -163,7 +163,117 @@ k_policy_fwd(const float* __restrict__ obs, const float* __restrict__ hid_in, co
   }
 }
 
+// =====================================================================================================================
+// LayerNorm over 64 features (+ optional fused ReLU), forward and backward, for the learner's TRAINING-time passes
+// (agents/rnn_agent.py:16-21, critics/mlp_critic.py:22-27: fc1 -> LayerNorm -> ReLU).  At the reference's update intensity a batch
+// is 32 steps of every env — 10 M rows of 64 on the 322-bus feeder — and PyTorch's row-per-block LayerNorm kernels run at 0.5 TB/s
+// there (9.8 ms forward, 15 ms backward: a third of the update, profiles/e2e/r03_e2e_reference_kernel_stats.txt).  Here a row
+// is 16 lanes x float4 (four rows per wavefront), the two moments are DPP-row sums, loads and stores are 16 bytes per lane and
+// fully coalesced: both directions stream at HBM rate.  Backward: dx = rstd (a - mean(a) - xhat mean(a xhat)), a = dy gamma
+// (dy masked by the ReLU), dgamma / dbeta as per-thread column sums over a grid-stride loop, reduced per block in LDS and
+// across blocks by a second tiny launch in a fixed order (no atomics: deterministic).
+// =====================================================================================================================
+template <bool RELU>
+__global__ void __launch_bounds__(256)
+k_ln64_fwd(const f4* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, f4* __restrict__ y,
+           float* __restrict__ mean, float* __restrict__ rstd, long rows, float eps) {
+  const int l16 = threadIdx.x & 15;
+  const f4 g = ((const f4*)gamma)[l16], b = ((const f4*)beta)[l16];
+  for (long row = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; row < rows; row += ((long)gridDim.x * 256) >> 4) {
+    const f4 v = x[row * 16 + l16];
+    const float mu = row_sum16((v.x + v.y) + (v.z + v.w)) * (1.0f / 64.0f);
+    const f4 dv = v - mu;
+    const float var = row_sum16((dv.x * dv.x + dv.y * dv.y) + (dv.z * dv.z + dv.w * dv.w)) * (1.0f / 64.0f);
+    const float r = rsqrtf(var + eps);
+    f4 o = dv * r * g + b;
+    if (RELU) { o.x = fmaxf(o.x, 0.0f); o.y = fmaxf(o.y, 0.0f); o.z = fmaxf(o.z, 0.0f); o.w = fmaxf(o.w, 0.0f); }
+    y[row * 16 + l16] = o;
+    if (l16 == 0) { mean[row] = mu; rstd[row] = r; }
+  }
+}
+
+template <bool RELU>
+__global__ void __launch_bounds__(256)
+k_ln64_bwd(const f4* __restrict__ dy, const f4* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+           const float* __restrict__ mean, const float* __restrict__ rstd, f4* __restrict__ dx, float* __restrict__ partial, long rows) {
+  __shared__ f4 s_g[16][16], s_b[16][16];
+  const int l16 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const f4 g = ((const f4*)gamma)[l16], b = ((const f4*)beta)[l16];
+  f4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+  for (long row = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; row < rows; row += ((long)gridDim.x * 256) >> 4) {
+    const f4 v = x[row * 16 + l16];
+    f4 d = dy[row * 16 + l16];
+    const float mu = mean[row], r = rstd[row];
+    const f4 xh = (v - mu) * r;
+    if (RELU) {
+      const f4 pre = xh * g + b;
+      d.x = pre.x > 0.0f ? d.x : 0.0f; d.y = pre.y > 0.0f ? d.y : 0.0f; d.z = pre.z > 0.0f ? d.z : 0.0f; d.w = pre.w > 0.0f ? d.w : 0.0f;
+    }
+    const f4 a = d * g;
+    const float m1 = row_sum16((a.x + a.y) + (a.z + a.w)) * (1.0f / 64.0f);
+    const float m2 = row_sum16((a.x * xh.x + a.y * xh.y) + (a.z * xh.z + a.w * xh.w)) * (1.0f / 64.0f);
+    dx[row * 16 + l16] = (a - m1 - xh * m2) * r;
+    ag += d * xh; ab += d;
+  }
+  s_g[rg][l16] = ag; s_b[rg][l16] = ab;
+  __syncthreads();
+  if (rg == 0) {
+    f4 tg = s_g[0][l16], tb = s_b[0][l16];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) { tg += s_g[i][l16]; tb += s_b[i][l16]; }
+    ((f4*)partial)[(size_t)blockIdx.x * 32 + l16] = tg;
+    ((f4*)partial)[(size_t)blockIdx.x * 32 + 16 + l16] = tb;
+  }
+}
+
+// dgamma | dbeta [128] = sum over blocks of partial[block][128], in a fixed order: eight strided sub-sums, then those in order
+__global__ void __launch_bounds__(1024) k_ln64_reduce(const float* __restrict__ partial, int nblocks, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float s_acc[8][128];
+  const int c = threadIdx.x & 127, grp = threadIdx.x >> 7;
+  float acc = 0.0f;
+  for (int i = grp; i < nblocks; i += 8) acc += partial[(size_t)i * 128 + c];
+  s_acc[grp][c] = acc;
+  __syncthreads();
+  if (grp == 0) {
+    float t = s_acc[0][c];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += s_acc[g][c];
+    if (c < 64) dgamma[c] = t; else dbeta[c - 64] = t;
+  }
+}
+
 }  // namespace mapdn
+
+static int ln64_blocks(long rows) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const long need = (rows + 15) / 16;
+  return (int)std::max<long>(1, std::min<long>(need, (long)cus * 8));
+}
+
+extern "C" int mapdn_layernorm64_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                         int64_t rows, float eps, int32_t relu, void* stream) {
+  using namespace mapdn;
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 1) return MAPDN_E_INVALID;
+  const int nb = ln64_blocks(rows);
+  if (relu) hipLaunchKernelGGL(k_ln64_fwd<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)x, gamma, beta, (f4*)y, mean, rstd, (long)rows, eps);
+  else hipLaunchKernelGGL(k_ln64_fwd<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)x, gamma, beta, (f4*)y, mean, rstd, (long)rows, eps);
+  return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
+}
+
+extern "C" int mapdn_layernorm64_backward_blocks(int64_t rows) { return rows < 1 ? 0 : ln64_blocks(rows); }
+
+extern "C" int mapdn_layernorm64_backward(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
+                                          const float* rstd, float* dx, float* dgamma, float* dbeta, float* partial, int64_t rows,
+                                          int32_t relu, void* stream) {
+  using namespace mapdn;
+  if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || !partial || rows < 1) return MAPDN_E_INVALID;
+  const int nb = ln64_blocks(rows);
+  if (relu) hipLaunchKernelGGL(k_ln64_bwd<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)dy, (const f4*)x, gamma, beta, mean, rstd, (f4*)dx, partial, (long)rows);
+  else hipLaunchKernelGGL(k_ln64_bwd<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)dy, (const f4*)x, gamma, beta, mean, rstd, (f4*)dx, partial, (long)rows);
+  hipLaunchKernelGGL(k_ln64_reduce, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, nb, dgamma, dbeta);
+  return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
+}
 
 // launch shape of k_policy_fwd for an observation width: threads per workgroup (512 / 256), whether the one-hot id columns of
 // fc1 are staged in LDS, and the dynamic LDS — or false when no variant fits the 160 KB of a CU (very wide observations)

@@ -257,3 +257,39 @@ def test_fused_policy_forward_matches_pytorch(n_agents, obs_dim, agent_id, rows_
     # with autograd on (training-time forward) the PyTorch modules run
     monkeypatch.setenv("MAPDN_FUSED_POLICY", "1")
     assert not net._fused_policy_ok(obs, hid)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,relu", [(70001, True), (4096, False), (1 << 20, True)])
+def test_layernorm64_kernels_match_pytorch(rows, relu):
+    """mapdn_layernorm64_forward / backward (LayerNorm over 64 features + fused ReLU, the learner's training-time passes)
+    against torch.nn.functional.layer_norm + relu with autograd: outputs and all three gradients."""
+    from mapdn_amd.learner import _LayerNorm64
+    g = torch.Generator(device="cuda:0"); g.manual_seed(rows)
+    x = (torch.randn(rows, 64, device="cuda:0", generator=g) * 1.7 + 0.3).requires_grad_(True)
+    w = (torch.randn(64, device="cuda:0", generator=g) * 0.5 + 1.0).requires_grad_(True)
+    b = (torch.randn(64, device="cuda:0", generator=g) * 0.2).requires_grad_(True)
+    dy = torch.randn(rows, 64, device="cuda:0", generator=g)
+    y = _LayerNorm64.apply(x, w, b, 1e-5, relu)
+    y.backward(dy)
+    got = [y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone()]
+    x.grad = w.grad = b.grad = None
+    ref = torch.nn.functional.layer_norm(x, (64,), w, b, 1e-5)
+    if relu:
+        ref = torch.relu(ref)
+    ref.backward(dy)
+    want = [ref.detach(), x.grad, w.grad, b.grad]
+    assert torch.allclose(got[0], want[0], rtol=2e-5, atol=2e-5)
+    # dx: an element whose pre-activation is within rounding of 0 may fall on the other side of the ReLU in the two implementations
+    # (there its whole dy switches on or off); everywhere else the gradients agree
+    pre = torch.nn.functional.layer_norm(x.detach(), (64,), w.detach(), b.detach(), 1e-5)
+    rows_ok = ~(relu & (pre.abs() < 1e-5).any(dim=1))
+    assert rows_ok.float().mean().item() > 0.99
+    assert torch.allclose(got[1][rows_ok], want[1][rows_ok], rtol=1e-4, atol=1e-4)
+    scale = max(1.0, rows ** 0.5)                                   # the parameter gradients are sums over the rows
+    assert (got[2] - want[2]).abs().max().item() < 2e-5 * scale * 10 and (got[3] - want[3]).abs().max().item() < 2e-5 * scale * 10
+    # deterministic: a second backward gives the same bits (fixed-order block reduction, no atomics)
+    x.grad = w.grad = b.grad = None
+    y2 = _LayerNorm64.apply(x, w, b, 1e-5, relu)
+    y2.backward(dy)
+    assert torch.equal(w.grad, got[2]) and torch.equal(b.grad, got[3]) and torch.equal(x.grad, got[1])
