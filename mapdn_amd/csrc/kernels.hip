@@ -22,9 +22,6 @@
 #define MAPDN_NR_PF 2
 #endif
 
-// the 64-bit form of llvm.amdgcn.update.dpp (clang's __builtin_amdgcn_update_dpp is 32-bit only)
-extern "C" __device__ double __mapdn_update_dpp_f64(double, double, int, int, int, bool) __asm("llvm.amdgcn.update.dpp.f64");
-
 namespace mapdn {
 
 // =================================================================================================
@@ -360,15 +357,7 @@ __device__ __forceinline__ double rows_max(double v) {
   return fmax(__hiloint2double((int)b.x, (int)a.x), __hiloint2double((int)b.y, (int)a.y));
 }
 
-__device__ __forceinline__ double bld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
-}
-// v_mov_b64_dpp row_newbcast:N — every lane of a 16-lane row receives the value lane N of its row holds (gfx90a+: VALU rate, no LDS)
-template <int N> __device__ __forceinline__ double rowb(double v) { return __mapdn_update_dpp_f64(0.0, v, 0x150 + N, 0xf, 0xf, false); }
-
 struct Rec { u32x4 ix; d2 ykk, ykp, ypk, cks, sb; };    // per-(worker,row) constants + the env's scheduled injection
-struct RecQ { double q; d2 sb; };                       // packed: this lane's qword of the worker's StepRec (see RB in k_nr_tree)
-struct RecFQ { double q, f; d2 sb; };                   // ... and of its flat-start step
 struct RecF { u32x4 ix; d2 s, i01, i23, ap, sb; };      // flat-start form: host-factorised constants (Schedule::flat)
 struct BwdF { d2 h, g01, g23; };                        // factors of one step when they come from global memory
 
@@ -503,27 +492,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   const bool flatL = RES == 1 ? true : (RES == 2 || RES == 3) ? false : d.nr_flat_lds != 0;
   const char* recT = s_rec + voT;                  // this worker's records / flat steps in LDS
   const char* flatT = s_flat + voF;
-  // RB ("record broadcast", 16 or 32 envs per workgroup: a worker is one or two whole 16-lane DPP rows).  The 16 lanes of a
-  // worker need the SAME 80-byte record; read as five 16-byte broadcast loads that is 5 KB returned per wave and row, and with
-  // one wave per SIMD the LDS return path (~35 B/clk) is what the issue phase of a row waits for (profiles/r03_base_stamps_fine:
-  // 508 of 1 380 cycles of a full row).  Instead lane j of every 16-lane row reads qword j of its worker's record — ONE
-  // ds_read_b64 / buffer_load_dwordx2 per row, 0.5 KB per wave — and a field is taken where it is used with
-  // v_mov_b64_dpp row_newbcast:j (VALU rate, no LDS).  StepRec = qwords (flags,slots) (chs,kp) ykk ykp ypk cks; a flat-start
-  // step = the 12 doubles of Schedule::flat.
-  constexpr bool RB = false && (L % 16) == 0;      // measured (profiles/r03_*): v_mov_b64_dpp costs ~12 cycles each, more than the broadcast reads it replaces (flat row 870 -> 1050 cycles) — kept for reference, off
-  const unsigned j16 = lane & 15u;
-  const unsigned offR = (j16 < 10u ? j16 : 9u) * 8u, offF = (j16 < 12u ? j16 : 11u) * 8u;
-  auto load_q = [&](int row) -> double {
-    if (recL) return *(const double*)(recT + (unsigned)row * TB + offR);
-    return bld1(rsT, voT + offR, row_s(row, TB));
-  };
-  auto load_fq = [&](int row) -> double {
-    if (flatL) return *(const double*)(flatT + (unsigned)row * FB + offF);
-    return bld1(rsF, voF + offF, row_s(row, FB));
-  };
-  auto q_lo = [&](double q) { return (uint32_t)__double2loint(q); };
-  auto q_hi = [&](double q) { return (uint32_t)__double2hiint(q); };
-  auto q_ix = [&](double q) -> u32x4 { const double a = rowb<0>(q), b = rowb<1>(q); return u32x4{q_lo(a), q_hi(a), q_lo(b), q_hi(b)}; };
   auto load_ix = [&](int row) -> u32x4 {
     if (recL) return *(const u32x4*)(recT + (unsigned)row * TB);
     return bldu4(rsT, voT, row_s(row, TB));
@@ -552,19 +520,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     }
     o.sb = bld2(rs, voS, row_s(row, pb));
   };
-  // what the rings of the sweeps hold per prefetched row: the packed form (RB) or the expanded record
-  using RingRec = std::conditional_t<RB, RecQ, Rec>;
-  using RingRecF = std::conditional_t<RB, RecFQ, RecF>;
-  using RingIx = std::conditional_t<RB, double, u32x4>;
-  auto ring_load = [&](int row, RingRec& o) {
-    if constexpr (RB) { o.q = load_q(row); o.sb = bld2(rs, voS, row_s(row, pb)); } else load_rec(row, o);
-  };
-  auto ring_loadf = [&](int row, RingRecF& o) {
-    if constexpr (RB) { o.q = load_q(row); o.f = load_fq(row); o.sb = bld2(rs, voS, row_s(row, pb)); } else load_recf(row, o);
-  };
-  auto ring_load_ix = [&](int row) -> RingIx { if constexpr (RB) return load_q(row); else return load_ix(row); };
-  auto ring_ix = [&](const auto& o) -> u32x4 { if constexpr (RB) return q_ix(o.q); else return o.ix; };
-  auto ringix_ix = [&](const RingIx& o) -> u32x4 { if constexpr (RB) return q_ix(o); else return o; };
   auto uni = [&](unsigned x) { return __builtin_amdgcn_readfirstlane(x); };
 
   // ---------------------------------------------------------------------------------------------------------------
@@ -592,19 +547,18 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // one row ahead (LDS: V is constant during a forward sweep); unrolled by 3 so that ring indices are compile-time.
   auto fwd_sweep = [&](auto kind) {
     constexpr int K = decltype(kind)::value;
-    RingRec Tq[3]; d2 vkq[3], vpq[3];
-    ring_load(0, Tq[0]); ring_load(min(1, R - 1), Tq[1]);
-    u32x4 ixc = ring_ix(Tq[0]);                            // index words of the CURRENT row (unpacked one row ahead)
-    { const unsigned kp = ixc.w; vkq[0] = sV[(size_t)(kp & 0xffffu) * L]; vpq[0] = sV[(size_t)(kp >> 16) * L]; }
+    Rec Tq[3]; d2 vkq[3], vpq[3];
+    load_rec(0, Tq[0]); load_rec(min(1, R - 1), Tq[1]);
+    { const unsigned kp = Tq[0].ix.w; vkq[0] = sV[(size_t)(kp & 0xffffu) * L]; vpq[0] = sV[(size_t)(kp >> 16) * L]; }
     double pFp = 0.0, pFq = 0.0; bool pLive = false;       // deferred mismatch bookkeeping of the previous row
     int r = 0;
     while (r < R) {
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         if (r >= R) break;
-        const RingRec& T = Tq[u % 3];
+        const Rec& T = Tq[u % 3];
         const d2 vk = vkq[u % 3], vp = vpq[u % 3];
-        const uint32_t fl = ixc.x, slots = ixc.y, chs = ixc.z, kp = ixc.w;
+        const uint32_t fl = T.ix.x, slots = T.ix.y, chs = T.ix.z, kp = T.ix.w;
         const uint32_t flu = uni(fl);              // the wave-uniform hints, once per row on the scalar unit
         const unsigned gmax = (flu >> SU_GMAX_SHIFT) & 3u;
         // (1) gathers first: they depend on the previous row's writes and head the critical path
@@ -620,20 +574,17 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
 #pragma unroll
           for (int i = 0; i < NP; ++i) g1[i] = c1[i * L];
         }
-        {                                          // next row's operands (LDS) and the record two rows ahead
-          ixc = ring_ix(Tq[(u + 1) % 3]);
-          const unsigned kpn = ixc.w;
+        {                                          // next row's operands (LDS) and the record two rows ahead (global)
+          const unsigned kpn = Tq[(u + 1) % 3].ix.w;
           vkq[(u + 1) % 3] = sV[(size_t)(kpn & 0xffffu) * L]; vpq[(u + 1) % 3] = sV[(size_t)(kpn >> 16) * L];
-          ring_load(min(r + 2, R - 1), Tq[(u + 2) % 3]);
+          load_rec(min(r + 2, R - 1), Tq[(u + 2) % 3]);
         }
         SCHED_FENCE();
         STAMP2(200 + 10 * K);
         // (2) shadow: previous row's bookkeeping; this row's child-independent part
         //     A_kp = V_k conj(Y_kp V_p), A_pk = V_p conj(Y_pk V_k), A_kk = |V_k|^2 conj(Y_kk), A_ks = V_k conj(Y_k,slack V_slack)
         note_mismatch(pFp, pFq, pLive);
-        double gkk, bkk, gkp, bkp, gpk, bpk;
-        if constexpr (RB) { gkk = rowb<2>(T.q); bkk = rowb<3>(T.q); gkp = rowb<4>(T.q); bkp = rowb<5>(T.q); gpk = rowb<6>(T.q); bpk = rowb<7>(T.q); }
-        else { gkk = T.ykk.x; bkk = T.ykk.y; gkp = T.ykp.x; bkp = T.ykp.y; gpk = T.ypk.x; bpk = T.ypk.y; }
+        const double gkk = T.ykk.x, bkk = T.ykk.y, gkp = T.ykp.x, bkp = T.ykp.y, gpk = T.ypk.x, bpk = T.ypk.y;
         const double ek = vk.x, fk = vk.y, ep = vp.x, fp = vp.y;
         const double tr = gkp * ep - bkp * fp, ti = gkp * fp + bkp * ep;
         const double akp_r = ek * tr + fk * ti, akp_i = fk * tr - ek * ti;
@@ -642,11 +593,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const double v2 = ek * ek + fk * fk;
         const double akk_r = v2 * gkk, akk_i = -v2 * bkk;
         double aks_r = 0.0, aks_i = 0.0;           // a constant-voltage neighbour only feeds S_k
-        if (flu & SU_SLACK_ANY) {
-          double ckx, cky;
-          if constexpr (RB) { ckx = rowb<8>(T.q); cky = rowb<9>(T.q); } else { ckx = T.cks.x; cky = T.cks.y; }
-          aks_r = ek * ckx + fk * cky; aks_i = fk * ckx - ek * cky;
-        }
+        if (flu & SU_SLACK_ANY) { aks_r = ek * T.cks.x + fk * T.cks.y; aks_i = fk * T.cks.x - ek * T.cks.y; }
         const double base_r = (akk_r + aks_r) + akp_r, base_i = (akk_i + aks_i) + akp_i;
         const double m = (fl & S_CARRY_IN) ? 1.0 : 0.0;    // register carry (same worker, previous row) masked by a 0/1 factor
         SCHED_FENCE();
@@ -729,28 +676,24 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // constants of Schedule::flat; per env there is only the forward substitution of the right-hand side
   // r = F - sum of the children's t (pair 3 of the contribution slots), h = I r, t = L h.
   auto fwd_sweep_flat = [&]() {
-    RingRecF Tq[3];
-    ring_loadf(0, Tq[0]); ring_loadf(min(1, R - 1), Tq[1]);
+    RecF Tq[3];
+    load_recf(0, Tq[0]); load_recf(min(1, R - 1), Tq[1]);
     int r = 0;
     while (r < R) {
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         if (r >= R) break;
-        const RingRecF& T = Tq[u % 3];
-        const u32x4 ix = ring_ix(T);
-        const uint32_t fl = ix.x, slots = ix.y, chs = ix.z, kp = ix.w;
+        const RecF& T = Tq[u % 3];
+        const uint32_t fl = T.ix.x, slots = T.ix.y, chs = T.ix.z, kp = T.ix.w;
         const uint32_t flu = uni(fl);
         const unsigned gmax = (flu >> SU_GMAX_SHIFT) & 3u;
         d2 g0, g1;
         if (gmax >= 1u) g0 = cs[((size_t)(chs & 1023u) * 4 + 3) * L];
         if (gmax >= 2u) g1 = cs[((size_t)((chs >> 10) & 1023u) * 4 + 3) * L];
-        ring_loadf(min(r + 2, R - 1), Tq[(u + 2) % 3]);
+        load_recf(min(r + 2, R - 1), Tq[(u + 2) % 3]);
         SCHED_FENCE();
         STAMP2(230);
-        double s_r, s_i, i0, i1, i2, i3, ap_r, ap_i;
-        if constexpr (RB) { s_r = rowb<FL_SR>(T.f); s_i = rowb<FL_SI>(T.f); i0 = rowb<FL_I0>(T.f); i1 = rowb<FL_I1>(T.f); i2 = rowb<FL_I2>(T.f);
-                            i3 = rowb<FL_I3>(T.f); ap_r = rowb<FL_APR>(T.f); ap_i = rowb<FL_API>(T.f); }
-        else { s_r = T.s.x; s_i = T.s.y; i0 = T.i01.x; i1 = T.i01.y; i2 = T.i23.x; i3 = T.i23.y; ap_r = T.ap.x; ap_i = T.ap.y; }
+        const double s_r = T.s.x, s_i = T.s.y, i0 = T.i01.x, i1 = T.i01.y, i2 = T.i23.x, i3 = T.i23.y, ap_r = T.ap.x, ap_i = T.ap.y;
         const double Fp = s_r - T.sb.x, Fq = s_i - T.sb.y;           // shadow: the flat-start mismatch does not depend on children
         note_mismatch(Fp, Fq, (fl & S_LIVE) != 0);
         const double m = (fl & S_CARRY_IN) ? 1.0 : 0.0;
@@ -814,28 +757,24 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   auto bwd_xprop = [&](auto src) {
     constexpr int SRC = decltype(src)::value;
     constexpr bool gG = (SRC == 1) && !GL;         // G comes from the factor blocks in global memory
-    RingIx ixq[4]; d2 g01q[4], g23q[4]; double fqq[4];
-    auto load_g = [&](int row, const RingIx& ixr, int slot) {
+    u32x4 ixq[4]; d2 g01q[4], g23q[4];
+    auto load_g = [&](int row, const u32x4& ixr, int slot) {
       if constexpr (SRC == 0) {
-        if constexpr (RB) fqq[slot] = load_fq(row);
-        else if (flatL) { const char* p = flatT + (unsigned)row * FB; g01q[slot] = *(const d2*)(p + FL_G0 * 8); g23q[slot] = *(const d2*)(p + FL_G2 * 8); }
+        if (flatL) { const char* p = flatT + (unsigned)row * FB; g01q[slot] = *(const d2*)(p + FL_G0 * 8); g23q[slot] = *(const d2*)(p + FL_G2 * 8); }
         else { const unsigned sf = row_s(row, FB); g01q[slot] = bld2(rsF, voF + FL_G0 * 8u, sf); g23q[slot] = bld2(rsF, voF + FL_G2 * 8u, sf); }
       } else if constexpr (gG) {
-        unsigned kk;
-        if constexpr (RB) kk = q_hi(rowb<1>(ixr)) & 0xffffu; else kk = ixr.w & 0xffffu;
-        const unsigned voN = voE + kk * bb;
+        const unsigned voN = voE + (ixr.w & 0xffffu) * bb;
         g01q[slot] = bld2(rs, voN, sF_G01); g23q[slot] = bld2(rs, voN, sF_G23);
       }
     };
-    ixq[0] = ring_load_ix(R - 1); ixq[1] = ring_load_ix(max(R - 2, 0)); ixq[2] = ring_load_ix(max(R - 3, 0));
+    ixq[0] = load_ix(R - 1); ixq[1] = load_ix(max(R - 2, 0)); ixq[2] = load_ix(max(R - 3, 0));
     load_g(R - 1, ixq[0], 0); load_g(max(R - 2, 0), ixq[1], 1);
     int r = R - 1;
     while (r >= 0) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (r < 0) break;
-        uint32_t fl, kp;
-        if constexpr (RB) { fl = q_lo(rowb<0>(ixq[u % 4])); kp = q_hi(rowb<1>(ixq[u % 4])); } else { fl = ixq[u % 4].x; kp = ixq[u % 4].w; }
+        const uint32_t fl = ixq[u % 4].x, kp = ixq[u % 4].w;
         const uint32_t flu = uni(fl);
         const unsigned k = kp & 0xffffu, p = kp >> 16;
         // (1) the parent's x (its h slot, already overwritten; 0 for elimination roots), this node's h and G
@@ -845,12 +784,11 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const d2 hh = sH[(size_t)k * L];
         d2 g01, g23;
         if constexpr (SRC == 1 && GL) { g01 = sG[(size_t)(2 * k) * L]; g23 = sG[(size_t)(2 * k + 1) * L]; }
-        ixq[(u + 3) % 4] = ring_load_ix(max(r - 3, 0));
+        ixq[(u + 3) % 4] = load_ix(max(r - 3, 0));
         load_g(max(r - 2, 0), ixq[(u + 2) % 4], (u + 2) % 4);
         SCHED_FENCE();
         STAMP2(240);
-        if constexpr (SRC == 0 && RB) { const double f = fqq[u % 4]; g01 = d2{rowb<FL_G0>(f), rowb<FL_G1>(f)}; g23 = d2{rowb<FL_G2>(f), rowb<FL_G3>(f)}; }
-        else if constexpr (SRC == 0 || gG) { g01 = g01q[u % 4]; g23 = g23q[u % 4]; }
+        if constexpr (SRC == 0 || gG) { g01 = g01q[u % 4]; g23 = g23q[u % 4]; }
         // (2) x_k = h_k - G_k x_parent
         const bool cout = (fl & S_CARRY_OUT) != 0;
         const double p0 = cout ? x0 : (xr ? q.x : 0.0), p1 = cout ? x1 : (xr ? q.y : 0.0);

@@ -1,4 +1,5 @@
 #!/bin/bash
+# round-3 check on the GPU box: full GPU suite, then bench line + kernel table for the three shapes at 4096 envs
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${1:-r03_c10}
 mkdir -p $OUT
