@@ -445,6 +445,14 @@ class VoltageControl(MultiAgentEnv):
         self._act_host = torch.zeros(1, b.n_sgen, dtype=torch.float64).pin_memory()
         self._act_dev = torch.zeros(1, b.n_sgen, dtype=torch.float64, device=b.device)
         self._packed = b.fused_step and os.environ.get("MAPDN_DROPIN_PACKED", "1") != "0"
+        # zero-copy variant (history == 1): pinned host memory is mapped into the device's address space on ROCm, so the kernels
+        # read the action straight from the pinned host buffer and the solver epilogue / k_gather store reward, info, terminated
+        # and the obs straight into it — no H2D / D2H copy launches at all, one stream synchronisation per step
+        self._zero_copy = self._packed and self.history == 1 and os.environ.get("MAPDN_DROPIN_ZEROCOPY", "1") != "0"
+        if self._zero_copy:
+            po, hp = self._pk_off, self._pk_host.data_ptr()
+            self._zc = dict(reward=hp + po["reward"], info=hp + po["info"], term=hp + po["term"], obs=hp + po["obs"],
+                            act=self._act_host.data_ptr())
         self._host_obs_valid = False
         agents_obs, state = self.reset()
         self.obs_size = agents_obs[0].shape[0]                        # :87
@@ -479,9 +487,17 @@ class VoltageControl(MultiAgentEnv):
     def step(self, actions, add_noise=True):
         if self._packed:
             self._act_host.numpy()[0, :] = np.asarray(actions, dtype=np.float64).reshape(-1)
-            self._act_dev.copy_(self._act_host, non_blocking=True)
-            self._b.step(self._act_dev, add_noise=add_noise)          # enqueues only; outputs land in the packed device buffer
-            self._pk_host.copy_(self._pk_dev, non_blocking=True)
+            if self._zero_copy:
+                b, z = self._b, self._zc
+                with torch.cuda.device(b.device):
+                    _lib.check(b._lib.mapdn_step_obs(b._h, z["act"], _lib.F64, int(add_noise), z["reward"], z["term"], z["info"],
+                                                     z["obs"], _lib.F64, b._stream()), b._h)
+                b._stepped = True
+                b._obs_fresh = None                                   # (the batch object's own device-side obs buffer was not filled)
+            else:
+                self._act_dev.copy_(self._act_host, non_blocking=True)
+                self._b.step(self._act_dev, add_noise=add_noise)      # enqueues only; outputs land in the packed device buffer
+                self._pk_host.copy_(self._pk_dev, non_blocking=True)
             torch.cuda.current_stream(self._b.device).synchronize()   # the one synchronisation of the step
             po, h = self._pk_off, self._pk_np
             reward = float(h[po["reward"]:po["reward"] + 8].view(np.float64)[0])
@@ -505,7 +521,7 @@ class VoltageControl(MultiAgentEnv):
         return [o[i].copy() for i in range(o.shape[0])]
 
     def get_obs(self):
-        if self._packed and self._host_obs_valid and self._b._obs_fresh == torch.float64:   # the obs of the last step() is on the host
+        if self._packed and self._host_obs_valid:                                           # the obs of the last step() is on the host
             n, o1 = self.n_agents, self._b._obs_size1
             o = self._pk_np[self._pk_off["obs"]:].view(np.float64).reshape(n, o1)
             return [o[i].copy() for i in range(n)]
