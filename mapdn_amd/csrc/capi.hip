@@ -339,7 +339,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     h->err = "MAPDN_NR_WAVES must be 1/2/4/8 and MAPDN_NR_LANES 32/16/8"; return MAPDN_E_INVALID; }
   if (P.n + 1 > 0xffff) { h->err = "networks with more than 65534 buses are not supported (16-bit node positions in the NR step records)"; return MAPDN_E_INVALID; }
   const int Wt = W * (64 / L);
-  build_schedule(P, Wt, h->sched, nr_min_cslots(W, L), 64 / L);
+  build_schedule(P, Wt, h->sched, nr_min_cslots(W, L), 64 / L, NR_G_REG_ROWS);
   if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
   const int ncl = (int)h->sched.clist.size();
   if (ncl > 4095) { h->err = "NR schedule: more than 4095 overflow children (junctions with > 3 non-chain children)"; return MAPDN_E_INVALID; }
@@ -386,10 +386,11 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   d.nr_mm_pass = h_lds ? 1 : 0;
   if (const char* s_ = getenv("MAPDN_NR_MM_PASS")) d.nr_mm_pass = (atoi(s_) != 0 && h_lds) ? 1 : 0;
   UP(flat, h->sched.flat); d.flat_bytes = (uint32_t)(h->sched.flat.size() * sizeof(double));
-  {  // NR scratch: factor blocks (one per (worker,row) step) | Sbus (schedule order) | Vout
-    const size_t nblk = (size_t)Wt * h->sched.R;
+  {  // NR scratch: factor blocks (one per node) | 2 x Sbus (one entry per node) | Vout
+    const size_t nblk = (size_t)P.n + 2;           // Sbus by node position (+ slack, + the trash node of idle steps: stays 0)
     const size_t fb_rows = (h_lds && g_lds) ? 0 : (size_t)(P.n + 2) * NBP;   // pair rows of Bp x 16 bytes: one block per node (+ slack, trash)
-    std::vector<int32_t> sbi(h->sched.step_of_node.begin(), h->sched.step_of_node.begin() + P.n);
+    std::vector<int32_t> sbi(P.n);
+    for (int k = 0; k < P.n; ++k) sbi[k] = k;
     rc = alloc_nrbuf(fb_rows, nblk, sbi); if (rc) return rc;
   }
 #undef UP

@@ -357,6 +357,17 @@ __device__ __forceinline__ double rows_max(double v) {
   return fmax(__hiloint2double((int)b.x, (int)a.x), __hiloint2double((int)b.y, (int)a.y));
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<N, I + 1>(f); }
+}
+// ... and downwards: f(N - 1), ..., f(0)
+template <int N, class F>
+__device__ __forceinline__ void static_for_down(F&& f) {
+  if constexpr (N > 0) { f(std::integral_constant<int, N - 1>{}); static_for_down<N - 1>(f); }
+}
+
 struct Rec { u32x4 ix; d2 ykk, ykp, ypk, cks, sb; };    // per-(worker,row) constants + the env's scheduled injection
 struct RecF { u32x4 ix; d2 s, i01, i23, ap, sb; };      // flat-start form: host-factorised constants (Schedule::flat)
 struct BwdF { d2 h, g01, g23; };                        // factors of one step when they come from global memory
@@ -395,7 +406,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   const unsigned voE = e * 16u;
   const unsigned sF_H = __builtin_amdgcn_readfirstlane(NB_H * pb), sF_G01 = __builtin_amdgcn_readfirstlane(NB_G01 * pb),
                  sF_G23 = __builtin_amdgcn_readfirstlane(NB_G23 * pb);
-  const unsigned voS = d.sb_off + e * 16u + t * (unsigned)R * pb;      // scheduled injection, in schedule order: scalar row offset
+  const unsigned voS = d.sb_off + e * 16u;       // the injection Sbus, one (re, im) pair row per NODE (entry n + 1, the trash node idle steps work on, stays 0)
   // LDS map, in pair rows (L x 16 bytes: one d2 per env; a worker's 16 lanes read 256 contiguous bytes with one
   // conflict-free ds_read_b128):  V [n+2] | h [n+2] if HL | G [2(n+2)] if GL | contribution slots x 4 | x slots x 1
   //   then verdict bytes [64 W], step sizes [64 W doubles], overflow child list, net.line constants (when they fit)
@@ -482,6 +493,34 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   double fmx;                                      // largest mismatch component seen by this worker in the current sweep
   double Fprev = 0.0, Fcur = 0.0;                  // per env: ||F||inf of the two most recent accepted sweeps
   double cS0, cS1, cD0, cD1, cD2, cD3, cR0, cR1;   // register carry child -> parent (same worker, next row)
+  // G factors of the first KR rows stay in REGISTERS between a forward sweep and its backward sweep: a (worker, row) step
+  // is the same lane's in both, and with one wave per SIMD (the fat layouts) most of the register file — 512 VGPRs + AGPRs
+  // per lane — is unused.  Registers cannot be indexed by a loop counter for free (s_set_gpr_idx per dword was measured:
+  // +9 % kernel time), so those rows are PEELED: rows 0 .. KR-1 of the full forward sweep and of its backward sweep are
+  // straight-line code with the row number a compile-time constant, and the row's G is eight named 32-bit values that live
+  // in AGPRs (v_accvgpr_write / _read through the "a" constraint, so that they never compete for arch VGPRs).  The Hu
+  // schedule fills the leaf-side rows first — 94 of the 140 nodes of the 141-bus feeder sit in rows 0..5, 120 in rows
+  // 0..8 — so only the sparse root-side rows still send G through global scratch: HBM-side traffic of the launch
+  // 77 -> 30 MB (case141 x 4096), 152 -> 78 MB (case322 x 4096) at unchanged kernel time (+-1 %).  The peeled code is
+  // instruction-cache footprint (its first execution in a launch is cold), which is what limits KR.
+  constexpr int KR = (HL && !GL) ? NR_G_REG_ROWS : 0;
+  uint32_t Ga[KR > 0 ? KR : 1][8];                 // AGPR-class values: written / read only by the two helpers below
+  auto a_put = [](double v, uint32_t& lo, uint32_t& hi) {
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(__double2loint(v)));
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(__double2hiint(v)));
+  };
+  // a forward sweep that computes no G still DEFINES the registers (distinct constants, so that the statements are not merged):
+  // every path from a forward to a backward sweep then carries defined values and nothing is live around the iteration loop
+  auto a_def1 = [](uint32_t& x, auto qc) { asm("v_accvgpr_write_b32 %0, %1" : "=a"(x) : "n"(decltype(qc)::value)); };
+  auto a_define = [&]() {
+    static_for<KR * 8>([&](auto ic) { constexpr int q = decltype(ic)::value; a_def1(Ga[q / 8][q % 8], ic); });
+  };
+  auto a_get = [](uint32_t lo, uint32_t hi) -> double {
+    int l, h;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(hi));
+    return __hiloint2double(h, l);
+  };
   double x0, x1;                                   // register carry parent -> child in the backward sweep
 
   // ---- per-row constants: all addressed by (worker, row) only, so they are fetched PF rows ahead with no dependent
@@ -506,7 +545,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       o.ix = bldu4(rsT, voT, st);
       o.ykk = bld2(rsT, voT + 16u, st); o.ykp = bld2(rsT, voT + 32u, st); o.ypk = bld2(rsT, voT + 48u, st); o.cks = bld2(rsT, voT + 64u, st);
     }
-    o.sb = bld2(rs, voS, row_s(row, pb));
   };
   auto load_recf = [&](int row, RecF& o) {
     o.ix = load_ix(row);
@@ -518,8 +556,10 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       o.s = bld2(rsF, voF + FL_SR * 8u, sf); o.i01 = bld2(rsF, voF + FL_I0 * 8u, sf); o.i23 = bld2(rsF, voF + FL_I2 * 8u, sf);
       o.ap = bld2(rsF, voF + FL_APR * 8u, sf);
     }
-    o.sb = bld2(rs, voS, row_s(row, pb));
   };
+  // the env's injection at a node: addressed by node, so that the Sbus array is n pair rows, not workers x rows (its re-reads in
+  // every sweep then stay in L2 together with the G factor scratch); requested one row ahead, when the next row's node is known
+  auto load_sb = [&](uint32_t kp) -> d2 { return bld2(rs, voS + (kp & 0xffffu) * pb, 0u); };
   auto uni = [&](unsigned x) { return __builtin_amdgcn_readfirstlane(x); };
 
   // ---------------------------------------------------------------------------------------------------------------
@@ -549,13 +589,12 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     constexpr int K = decltype(kind)::value;
     Rec Tq[3]; d2 vkq[3], vpq[3];
     load_rec(0, Tq[0]); load_rec(min(1, R - 1), Tq[1]);
-    { const unsigned kp = Tq[0].ix.w; vkq[0] = sV[(size_t)(kp & 0xffffu) * L]; vpq[0] = sV[(size_t)(kp >> 16) * L]; }
+    { const unsigned kp = Tq[0].ix.w; vkq[0] = sV[(size_t)(kp & 0xffffu) * L]; vpq[0] = sV[(size_t)(kp >> 16) * L]; Tq[0].sb = load_sb(kp); }
     double pFp = 0.0, pFq = 0.0; bool pLive = false;       // deferred mismatch bookkeeping of the previous row
-    int r = 0;
-    while (r < R) {
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        if (r >= R) break;
+    // one row; u = ring position (compile-time), RS = the row number when it is a compile-time constant (peeled rows), else -1
+    auto fwd_row = [&](auto uc, auto rsc, int r) {
+      constexpr int u = decltype(uc)::value, RS = decltype(rsc)::value;
+      {
         const Rec& T = Tq[u % 3];
         const d2 vk = vkq[u % 3], vp = vpq[u % 3];
         const uint32_t fl = T.ix.x, slots = T.ix.y, chs = T.ix.z, kp = T.ix.w;
@@ -577,6 +616,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         {                                          // next row's operands (LDS) and the record two rows ahead (global)
           const unsigned kpn = Tq[(u + 1) % 3].ix.w;
           vkq[(u + 1) % 3] = sV[(size_t)(kpn & 0xffffu) * L]; vpq[(u + 1) % 3] = sV[(size_t)(kpn >> 16) * L];
+          Tq[(u + 1) % 3].sb = load_sb(kpn);
           load_rec(min(r + 2, R - 1), Tq[(u + 2) % 3]);
         }
         SCHED_FENCE();
@@ -627,6 +667,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
               };
               gather((chs >> 20) & 1023u);
               const unsigned cptr = clist_ptr(fl, slots, chs);
+#pragma unroll 1                             // rare path: keep it small, the rows' code size is instruction-cache footprint
               for (int j = 3; j < nch; ++j) gather((unsigned)s_clist[cptr + j - 3]);
             }
           }
@@ -659,6 +700,9 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
           const unsigned k = kp & 0xffffu, voN = voE + k * bb;
           if (HL) sH[(size_t)k * L] = d2{h0, h1}; else bst2(d2{h0, h1}, rs, voN, sF_H);
           if (GL) { sG[(size_t)(2 * k) * L] = d2{G0, G1}; sG[(size_t)(2 * k + 1) * L] = d2{G2, G3}; }
+          else if constexpr (RS >= 0) {
+            a_put(G0, Ga[RS][0], Ga[RS][1]); a_put(G1, Ga[RS][2], Ga[RS][3]); a_put(G2, Ga[RS][4], Ga[RS][5]); a_put(G3, Ga[RS][6], Ga[RS][7]);
+          }
           else { bst2(d2{G0, G1}, rs, voN, sF_G01); bst2(d2{G2, G3}, rs, voN, sF_G23); }
         } else {
           cS0 = apk_r; cS1 = apk_i;
@@ -667,6 +711,22 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         STAMP2(202 + 10 * K);
         if (W > 1) lds_barrier();
         STAMP(100 + K);
+      }
+    };
+    constexpr int KP = (K == 0) ? KR : 0;          // peeled rows (their G stays in registers)
+    static_for<KP>([&](auto ic) {                  // (the host pads every schedule to R >= NR_G_REG_ROWS)
+      constexpr int i = decltype(ic)::value;
+      fwd_row(std::integral_constant<int, i % 3>{}, ic, i);
+    });
+    static_assert(KP % 3 == 0, "the peeled rows must leave the record ring at position 0");
+    int r = KP;
+    while (r < R) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (r >= R) break;
+        if (u == 0) fwd_row(std::integral_constant<int, 0>{}, std::integral_constant<int, -1>{}, r);
+        else if (u == 1) fwd_row(std::integral_constant<int, 1>{}, std::integral_constant<int, -1>{}, r);
+        else fwd_row(std::integral_constant<int, 2>{}, std::integral_constant<int, -1>{}, r);
         ++r;
       }
     }
@@ -678,6 +738,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   auto fwd_sweep_flat = [&]() {
     RecF Tq[3];
     load_recf(0, Tq[0]); load_recf(min(1, R - 1), Tq[1]);
+    Tq[0].sb = load_sb(Tq[0].ix.w);
     int r = 0;
     while (r < R) {
 #pragma unroll
@@ -690,6 +751,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         d2 g0, g1;
         if (gmax >= 1u) g0 = cs[((size_t)(chs & 1023u) * 4 + 3) * L];
         if (gmax >= 2u) g1 = cs[((size_t)((chs >> 10) & 1023u) * 4 + 3) * L];
+        Tq[(u + 1) % 3].sb = load_sb(Tq[(u + 1) % 3].ix.w);
         load_recf(min(r + 2, R - 1), Tq[(u + 2) % 3]);
         SCHED_FENCE();
         STAMP2(230);
@@ -709,6 +771,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
               auto gather = [&](unsigned slot) { const d2 a = cs[((size_t)slot * 4 + 3) * L]; aR0 += a.x; aR1 += a.y; };
               gather((chs >> 20) & 1023u);
               const unsigned cptr = clist_ptr(fl, slots, chs);
+#pragma unroll 1                             // rare path: keep it small, the rows' code size is instruction-cache footprint
               for (int j = 3; j < nch; ++j) gather((unsigned)s_clist[cptr + j - 3]);
             }
           }
@@ -767,13 +830,17 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         g01q[slot] = bld2(rs, voN, sF_G01); g23q[slot] = bld2(rs, voN, sF_G23);
       }
     };
+    // rows below KP are peeled (straight-line code, G in registers: see Gs); their index words are fetched up front
+    constexpr int KP = gG ? KR : 0;
+    u32x4 ixs[KP > 0 ? KP : 1];
+    static_for<KP>([&](auto ic) { constexpr int i = decltype(ic)::value; ixs[i] = load_ix(i); });
     ixq[0] = load_ix(R - 1); ixq[1] = load_ix(max(R - 2, 0)); ixq[2] = load_ix(max(R - 3, 0));
     load_g(R - 1, ixq[0], 0); load_g(max(R - 2, 0), ixq[1], 1);
     int r = R - 1;
-    while (r >= 0) {
+    while (r >= KP) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (r < 0) break;
+        if (r < KP) break;
         const uint32_t fl = ixq[u % 4].x, kp = ixq[u % 4].w;
         const uint32_t flu = uni(fl);
         const unsigned k = kp & 0xffffu, p = kp >> 16;
@@ -784,8 +851,8 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const d2 hh = sH[(size_t)k * L];
         d2 g01, g23;
         if constexpr (SRC == 1 && GL) { g01 = sG[(size_t)(2 * k) * L]; g23 = sG[(size_t)(2 * k + 1) * L]; }
-        ixq[(u + 3) % 4] = load_ix(max(r - 3, 0));
-        load_g(max(r - 2, 0), ixq[(u + 2) % 4], (u + 2) % 4);
+        ixq[(u + 3) % 4] = load_ix(max(r - 3, KP));
+        load_g(max(r - 2, KP), ixq[(u + 2) % 4], (u + 2) % 4);
         SCHED_FENCE();
         STAMP2(240);
         if constexpr (SRC == 0 || gG) { g01 = g01q[u % 4]; g23 = g23q[u % 4]; }
@@ -802,6 +869,28 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         --r;
       }
     }
+    static_for_down<KP>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      {
+        const uint32_t fl = ixs[i].x, kp = ixs[i].w;
+        const uint32_t flu = uni(fl);
+        const unsigned k = kp & 0xffffu, p = kp >> 16;
+        d2 q;
+        const bool xr = (flu & SU_XR_ANY) != 0;
+        if (xr) q = sH[(size_t)p * L];
+        const d2 hh = sH[(size_t)k * L];
+        SCHED_FENCE();
+        const bool cout = (fl & S_CARRY_OUT) != 0;
+        const double p0 = cout ? x0 : (xr ? q.x : 0.0), p1 = cout ? x1 : (xr ? q.y : 0.0);
+        const double G0 = a_get(Ga[i][0], Ga[i][1]), G1 = a_get(Ga[i][2], Ga[i][3]), G2 = a_get(Ga[i][4], Ga[i][5]), G3 = a_get(Ga[i][6], Ga[i][7]);
+        const double y0 = hh.x - (G0 * p0 + G1 * p1);
+        const double y1 = hh.y - (G2 * p0 + G3 * p1);
+        x0 = y0; x1 = y1;
+        sH[(size_t)k * L] = d2{y0, y1};
+        if (W > 1) lds_barrier();
+        STAMP(110 + SRC);
+      }
+    });
     // (3) update of every node from its x, three nodes per pass (loads first)
     for (unsigned kb = t; kb < n; kb += 3u * Wt) {
       unsigned kk[3]; d2 xx[3], vv[3]; bool lv[3];
@@ -850,7 +939,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       auto cl = [&](int j) { return row_s(min(j, NPs - 1), TB); };
       u32x4 ixA = bldu4(rsP, voP, 0u), ixB = bldu4(rsP, voP, cl(1));
       d2 ykkN = bld2(rsP, voP + 16u, 0u), ykpN = bld2(rsP, voP + 32u, 0u), cksN = bld2(rsP, voP + 64u, 0u);
-      d2 sbN = bld2(rs, voSb + (ixA.z >> 16) * pb, 0u);
+      d2 sbN = bld2(rs, voSb + (ixA.w & 0xffffu) * pb, 0u);
       for (int j = 0; j < NPs; ++j) {
         const u32x4 ix = ixA;
         const d2 ykk = ykkN, ykp = ykpN, cks = cksN, sb = sbN;
@@ -861,7 +950,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         {
           const unsigned s1 = cl(j + 1);
           ykkN = bld2(rsP, voP + 16u, s1); ykpN = bld2(rsP, voP + 32u, s1); cksN = bld2(rsP, voP + 64u, s1);
-          sbN = bld2(rs, voSb + (ixB.z >> 16) * pb, 0u);
+          sbN = bld2(rs, voSb + (ixB.w & 0xffffu) * pb, 0u);
           ixA = ixB; ixB = bldu4(rsP, voP, cl(j + 2));
         }
         const double gkk = ykk.x, bkk = ykk.y, gkp = ykp.x, bkp = ykp.y;
@@ -877,6 +966,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         if (nch > 2) { aS0 += a2.x; aS1 += a2.y; }
         if (__any(nch > 3)) {                                            // rare: junctions with more than three children
           const int c_lo = d.mm_ptr[k];
+#pragma unroll 1
           for (int q = 3; q < nch; ++q) { const d2 a = sH[(size_t)d.mm_child[c_lo + q] * L]; aS0 += a.x; aS1 += a.y; }
         }
         const double sr = base_r + aS0, si = base_i + aS1;
@@ -958,8 +1048,8 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     allok = true; fmx = 0.0;
     cS0 = cS1 = cD0 = cD1 = cD2 = cD3 = cR0 = cR1 = 0.0;
     STAMP(10);
-    if (first) fwd_sweep_flat();
-    else if (light) { if (HL && d.nr_mm_pass) mismatch_pass(); else fwd_sweep(std::integral_constant<int, 1>{}); }
+    if (first) { fwd_sweep_flat(); a_define(); }
+    else if (light) { if (HL && d.nr_mm_pass) mismatch_pass(); else fwd_sweep(std::integral_constant<int, 1>{}); a_define(); }
     else fwd_sweep(std::integral_constant<int, 0>{});
     if constexpr (L == 16) {                     // AND of the workers' verdicts, per env: in the wave by row swaps, across
       fmx = rows_max(fmx);                       // the W waves through W LDS entries (instead of Wt)

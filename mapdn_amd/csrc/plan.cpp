@@ -395,7 +395,7 @@ void sparse_program(const Plan& P, int S, SparseProg& G) {
   }
 }
 
-void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw) {
+void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw, int min_rows) {
   const int n = P.n;
   if (Sw < 1 || W % Sw) Sw = 1;
   S.W = W; S.S = Sw; S.steps.clear(); S.clist.clear();
@@ -444,6 +444,7 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw) {
       if (p < n && --pending[p] == 0) ready.push_back(p);
     }
   }
+  while ((int)rows.size() < min_rows) rows.push_back(std::vector<int>(W, -1));   // idle rows (the kernel's peeled rows always exist)
   const int R = (int)rows.size();
   S.R = R;
   S.steps.assign((size_t)W * R, StepRec{});
@@ -567,7 +568,7 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw) {
       auto child = [&](int q) { return (uint32_t)(q < nch ? S.mm_child[c_lo + q] : n + 1); };   // absent: the trash node
       T.flags = (live ? 1u : 0u) | ((uint32_t)std::min(nch, 255) << 8);
       T.slots = child(0) | (child(1) << 16);
-      T.chs = child(2) | ((uint32_t)S.step_of_node[k] << 16);
+      T.chs = child(2);
       T.kp = (uint32_t)k | ((uint32_t)P.par[k] << 16);
       const double* c = &P.yc[(size_t)k * 8];
       T.ykk[0] = c[0]; T.ykk[1] = c[1]; T.ykp[0] = c[2]; T.ykp[1] = c[3]; T.ypk[0] = c[4]; T.ypk[1] = c[5]; T.cks[0] = c[6]; T.cks[1] = c[7];

@@ -165,6 +165,11 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& out,
 // canonical (chain child first, then ascending position) and therefore independent of W.
 // min_cslots: lower bound on the number of contribution slots (the kernel's epilogue re-uses that LDS region)
 // S: workers per wavefront (only sets the granularity of the wave-uniform SU_* hints).
-void build_schedule(const Plan& P, int W, Schedule& out, int min_cslots = 0, int S = 1);
+// leaf-side rows of the tree kernel whose G factors stay in registers (k_nr_tree peels them: a multiple of 3; 8 AGPRs each);
+// the schedules the kernel runs are padded with idle rows to at least this many (min_rows)
+#ifndef NR_G_REG_ROWS
+#define NR_G_REG_ROWS 6
+#endif
+void build_schedule(const Plan& P, int W, Schedule& out, int min_cslots = 0, int S = 1, int min_rows = 0);
 
 }  // namespace mapdn
