@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -91,7 +92,12 @@ static void choose_nr_geometry(int Bp, int n, int n_cu, int& W, int& L, int& lea
   else if (n < 200) {
     L = 16;
     if (Bp / L > n_cu) { W = 2; lean = 1; } else W = 4;
-  } else { W = 4; L = 8; }                        // 32 workers; LDS holds 8 envs of a ~320-bus feeder
+  } else {
+    // ~320-bus feeders: LDS holds voltages + h factors of 8 envs (32 workers, rows = tree radius).  A batch that would need more
+    // than one round of such workgroups takes 16 envs per workgroup instead — 16 workers, ~30 % more rows, h in global scratch,
+    // but half as many rounds: 161.6 -> 138.8 us per launch at 4096 envs (profiles/r03_geometry_case322.txt)
+    W = 4; L = (Bp / 8 > n_cu) ? 16 : 8;
+  }
 }
 
 extern "C" {
@@ -361,6 +367,9 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   if (lds_need > LDS_MAX) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
   d.nr_waves = W; d.nr_lanes = L; d.nr_h_lds = h_lds; d.nr_g_lds = g_lds; d.nr_line_lds = line_lds; d.nr_rec_lds = rec_lds; d.nr_flat_lds = flat_lds;
   h->lds_bytes = lds_need;
+  if (getenv("MAPDN_DEBUG_GEOMETRY"))
+    fprintf(stderr, "[mapdn] k_nr_tree geometry: W %d L %d lean %d rows %d cslots %d | LDS: h %d rec %d flat %d line %d G %d = %zu B\n",
+            W, L, lean, R_, h->sched.n_cslots, h_lds, rec_lds, flat_lds, line_lds, g_lds, lds_need);
   // 1e-7: with quadratic convergence the mismatch after such a step is ~|Y| dx^2 << tol, so a wrong prediction
   // (which costs one extra mismatch-only sweep for that workgroup) practically never happens
   d.nr_check_dx = 1e-7;

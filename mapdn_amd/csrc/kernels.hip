@@ -1384,12 +1384,12 @@ void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const
 // the per-row `if (recL)` / `if (flatL)` branches and the conservative s_waitcnt at their joins disappear (-6 % kernel time
 // on case141 x 4096).  Every other (W, L) — env-var overrides, tests — runs the generic RES 0 body.
 constexpr int nr_res(int w, int l, bool h_lds) {
-  return h_lds ? (((w == 1 && l == 16) || (w == 4 && l == 16) || (w == 4 && l == 8)) ? 1 : 0) : ((w == 2 && l == 16) ? 2 : 0);
+  return h_lds ? (((w == 1 && l == 16) || (w == 4 && l == 16) || (w == 4 && l == 8)) ? 1 : 0) : (((w == 2 || w == 4) && l == 16) ? 2 : 0);
 }
 // h in LDS, records and flat constants in global memory: the fat layout of nets whose schedule does not fit (case322: W = 4, L = 8)
 constexpr int nr_res_hg(int w, int l) { return (w == 4 && l == 8) ? 2 : 0; }
 // ... records resident, flat constants in global memory: what the 322-bus feeder gets by default
-constexpr int nr_res_hr(int w, int l) { return (w == 4 && l == 8) ? 3 : 0; }
+constexpr int nr_res_hr(int w, int l) { return (w == 4 && (l == 8 || l == 16)) ? 3 : 0; }
 // (W, L) instantiations of k_nr_tree
 #define NR_FOR_EACH(X) X(1, 8) X(1, 16) X(1, 32) X(2, 8) X(2, 16) X(2, 32) X(4, 8) X(4, 16) X(4, 32) X(8, 16)
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {

@@ -9,8 +9,9 @@ with NO geometry override:
     9 noisy calls that contain a forced unsolvable step (voltage_control_env.py:188-196), the episode-limit boundary and
     the per-env auto-reset that follows both (the reference loop's reset() right after `done`, models/model.py:204-262);
     reward / terminated / 11 info values / obs / bus voltages <= 1e-9, NR iteration counts of the final call exact;
-  * env g inside the big batch is bit-identical to a B = 1 handle with env_id_offset = g (a different launch geometry,
-    the same global id): results do not depend on the batch an env sits in.
+  * env g inside the big batch against a B = 1 handle with env_id_offset = g (a different launch geometry, the same global
+    id): obs and terminated bit-identical, reward / info (sums of per-worker partials) equal to the last ulp — results do not
+    depend on the batch an env sits in.
 """
 import numpy as np
 import pytest
@@ -50,7 +51,7 @@ def test_default_launch_matches_oracle_at_full_size(case, B, monkeypatch):
     for e, o in oracles.items():
         oo, _ = o.reset()
         assert np.abs(np.array(oo) - obs[e]).max() < 1e-9
-    # the same global ids as single-env handles (another geometry): bit-identical trajectories
+    # the same global ids as single-env handles (another geometry): the same trajectories
     twins = {g: VoltageControlBatch(net, prof, dict(_args(case), auto_reset=True), n_envs=1, device="cuda:0", env_id_offset=g,
                                     obs_dtype=torch.float64) for g in (watch[0], bad_env, watch[-1])}
     for g, tw in twins.items():
@@ -69,7 +70,10 @@ def test_default_launch_matches_oracle_at_full_size(case, B, monkeypatch):
         mask = env.auto_reset_mask().cpu().numpy()
         for g, tw in twins.items():
             r1, t1, i1 = tw.step(act[g:g + 1])
-            assert torch.equal(r1[0], r[g]) and torch.equal(t1[0], term[g]) and torch.equal(i1[0], info[g]), (t, g)
+            # voltages, hence obs, are bit-identical in every launch geometry; reward / info are sums over buses and lines whose
+            # per-worker partials depend on the number of workers (a single-env handle may get another geometry): last-ulp equal
+            assert torch.equal(t1[0], term[g]), (t, g)
+            assert torch.allclose(r1[0], r[g], rtol=1e-13, atol=1e-13) and torch.allclose(i1[0], info[g], rtol=1e-13, atol=1e-13), (t, g)
             assert torch.equal(tw.get_obs()[0], obs[g]), (t, g)
         acpu, rcpu, tcpu, icpu, ocpu, vcpu = act.cpu().numpy(), r.cpu().numpy(), term.cpu().numpy(), info.cpu().numpy(), obs.cpu().numpy(), vm.cpu().numpy()
         for e, o in oracles.items():
