@@ -345,7 +345,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     h->err = "MAPDN_NR_WAVES must be 1/2/4/8 and MAPDN_NR_LANES 32/16/8"; return MAPDN_E_INVALID; }
   if (P.n + 1 > 0xffff) { h->err = "networks with more than 65534 buses are not supported (16-bit node positions in the NR step records)"; return MAPDN_E_INVALID; }
   const int Wt = W * (64 / L);
-  build_schedule(P, Wt, h->sched, nr_min_cslots(W, L), 64 / L, NR_G_REG_ROWS);
+  build_schedule(P, Wt, h->sched, nr_min_cslots(W, L), 64 / L, NR_HG_REG_ROWS > NR_G_REG_ROWS ? NR_HG_REG_ROWS : NR_G_REG_ROWS);
   if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
   const int ncl = (int)h->sched.clist.size();
   if (ncl > 4095) { h->err = "NR schedule: more than 4095 overflow children (junctions with > 3 non-chain children)"; return MAPDN_E_INVALID; }

@@ -503,17 +503,22 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // 0..8 — so only the sparse root-side rows still send G through global scratch: HBM-side traffic of the launch
   // 77 -> 30 MB (case141 x 4096), 152 -> 78 MB (case322 x 4096) at unchanged kernel time (+-1 %).  The peeled code is
   // instruction-cache footprint (its first execution in a launch is cold), which is what limits KR.
-  constexpr int KR = (HL && !GL) ? NR_G_REG_ROWS : 0;
+  // When h lives in global scratch too (!HL: the lean layouts, the 322-bus feeder at 16 envs per workgroup), the peeled rows keep
+  // h AND G in registers (12 AGPRs per row) and there are NR_HG_REG_ROWS of them.
+  constexpr int KR = GL ? 0 : (HL ? NR_G_REG_ROWS : NR_HG_REG_ROWS);
+  constexpr bool RH = !HL;                         // the peeled rows' h is in registers as well
   uint32_t Ga[KR > 0 ? KR : 1][8];                 // AGPR-class values: written / read only by the two helpers below
+  uint32_t Ha[(KR > 0 && RH) ? KR : 1][4];
   auto a_put = [](double v, uint32_t& lo, uint32_t& hi) {
     asm("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(__double2loint(v)));
     asm("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(__double2hiint(v)));
   };
-  // a forward sweep that computes no G still DEFINES the registers (distinct constants, so that the statements are not merged):
+  // a forward sweep that computes no G still DEFINES the registers (a distinct number in each statement's comment, so that they are not merged):
   // every path from a forward to a backward sweep then carries defined values and nothing is live around the iteration loop
-  auto a_def1 = [](uint32_t& x, auto qc) { asm("v_accvgpr_write_b32 %0, %1" : "=a"(x) : "n"(decltype(qc)::value)); };
+  auto a_def1 = [](uint32_t& x, auto qc) { asm("v_accvgpr_write_b32 %0, 0 ; def %1" : "=a"(x) : "n"(decltype(qc)::value)); };
   auto a_define = [&]() {
     static_for<KR * 8>([&](auto ic) { constexpr int q = decltype(ic)::value; a_def1(Ga[q / 8][q % 8], ic); });
+    if constexpr (RH) static_for<KR * 4>([&](auto ic) { constexpr int q = decltype(ic)::value; a_def1(Ha[q / 4][q % 4], std::integral_constant<int, 1000 + q>{}); });
   };
   auto a_get = [](uint32_t lo, uint32_t hi) -> double {
     int l, h;
@@ -698,7 +703,9 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
           }
           SCHED_FENCE();                           // the factors leave after the contribution is on its way
           const unsigned k = kp & 0xffffu, voN = voE + k * bb;
-          if (HL) sH[(size_t)k * L] = d2{h0, h1}; else bst2(d2{h0, h1}, rs, voN, sF_H);
+          if (HL) sH[(size_t)k * L] = d2{h0, h1};
+          else if constexpr (RS >= 0) { a_put(h0, Ha[RS][0], Ha[RS][1]); a_put(h1, Ha[RS][2], Ha[RS][3]); }
+          else bst2(d2{h0, h1}, rs, voN, sF_H);
           if (GL) { sG[(size_t)(2 * k) * L] = d2{G0, G1}; sG[(size_t)(2 * k + 1) * L] = d2{G2, G3}; }
           else if constexpr (RS >= 0) {
             a_put(G0, Ga[RS][0], Ga[RS][1]); a_put(G1, Ga[RS][2], Ga[RS][3]); a_put(G2, Ga[RS][4], Ga[RS][5]); a_put(G3, Ga[RS][6], Ga[RS][7]);
@@ -994,14 +1001,18 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         else { f.g01 = bld2(rs, voN, sF_G01); f.g23 = bld2(rs, voN, sF_G23); }
       }
     };
+    // rows below KP are peeled (straight-line code, h and G in registers: see Ga / Ha); their index words are fetched up front
+    constexpr int KP = (SRC == 1 && !GL) ? KR : 0;
+    u32x4 ixs[KP > 0 ? KP : 1];
+    static_for<KP>([&](auto ic) { constexpr int i = decltype(ic)::value; ixs[i] = load_ix(i); });
     ixq[0] = load_ix(R - 1); ixq[1] = load_ix(max(R - 2, 0)); ixq[2] = load_ix(max(R - 3, 0));
     load_f(R - 1, ixq[0], fq[0]); load_f(max(R - 2, 0), ixq[1], fq[1]);
     double py0 = 0.0, py1 = 0.0; d2 pvk = sV[(size_t)(n + 1) * L]; unsigned pk = n + 1; bool pLive = false;   // deferred update of the previous row
     int r = R - 1;
-    while (r >= 0) {
+    while (r >= KP) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (r < 0) break;
+        if (r < KP) break;
         const u32x4 ix = ixq[u % 4];
         const uint32_t fl = ix.x, slots = ix.y;
         const uint32_t flu = uni(fl);
@@ -1014,8 +1025,8 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const d2 g01 = gG ? fq[u % 4].g01 : sG[(size_t)(2 * k) * L];
         const d2 g23 = gG ? fq[u % 4].g23 : sG[(size_t)(2 * k + 1) * L];
         const d2 vk = sV[(size_t)k * L];           // (only this node's own deferred update ever writes it)
-        ixq[(u + 3) % 4] = load_ix(max(r - 3, 0));
-        load_f(max(r - 2, 0), ixq[(u + 2) % 4], fq[(u + 2) % 4]);
+        ixq[(u + 3) % 4] = load_ix(max(r - 3, KP));
+        load_f(max(r - 2, KP), ixq[(u + 2) % 4], fq[(u + 2) % 4]);
         SCHED_FENCE();
         // (2) shadow: the previous row's voltage update
         apply_update(py0, py1, pvk, pk, pLive);
@@ -1033,6 +1044,31 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         --r;
       }
     }
+    static_for_down<KP>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const u32x4 ix = ixs[i];
+      const uint32_t fl = ix.x, slots = ix.y;
+      const uint32_t flu = uni(fl);
+      const unsigned k = ix.w & 0xffffu;
+      d2 q;
+      const bool xr = (flu & SU_XR_ANY) != 0;
+      if (xr) q = xs[(size_t)((slots >> 20) & 1023u) * L];
+      const d2 vk = sV[(size_t)k * L];
+      SCHED_FENCE();
+      apply_update(py0, py1, pvk, pk, pLive);
+      SCHED_FENCE();
+      const double hh0 = a_get(Ha[i][0], Ha[i][1]), hh1 = a_get(Ha[i][2], Ha[i][3]);
+      const double G0 = a_get(Ga[i][0], Ga[i][1]), G1 = a_get(Ga[i][2], Ga[i][3]), G2 = a_get(Ga[i][4], Ga[i][5]), G3 = a_get(Ga[i][6], Ga[i][7]);
+      const bool cout = (fl & S_CARRY_OUT) != 0;
+      const double p0 = cout ? x0 : (xr ? q.x : 0.0), p1 = cout ? x1 : (xr ? q.y : 0.0);
+      const double y0 = hh0 - (G0 * p0 + G1 * p1);
+      const double y1 = hh1 - (G2 * p0 + G3 * p1);
+      x0 = y0; x1 = y1;
+      if (flu & SU_XW_ANY) xs[(size_t)((slots >> 10) & 1023u) * L] = d2{y0, y1};
+      py0 = y0; py1 = y1; pvk = vk; pk = k; pLive = (fl & S_LIVE) != 0;
+      if (W > 1) lds_barrier();
+      STAMP(110 + SRC);
+    });
     apply_update(py0, py1, pvk, pk, pLive);
   };
 #undef SCHED_FENCE

@@ -170,6 +170,10 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& out,
 #ifndef NR_G_REG_ROWS
 #define NR_G_REG_ROWS 6
 #endif
+// ... and, in the layouts whose h factors are in global scratch too, rows whose h AND G stay in registers (12 AGPRs each)
+#ifndef NR_HG_REG_ROWS
+#define NR_HG_REG_ROWS 12
+#endif
 void build_schedule(const Plan& P, int W, Schedule& out, int min_cslots = 0, int S = 1, int min_rows = 0);
 
 }  // namespace mapdn
