@@ -156,7 +156,10 @@ const char* mapdn_last_error(const mapdn_handle* h);
  *   MAPDN_NR_SPARSE (0/1)                                  1: use the general sparse solver on a radial net too (cross-checks)
  *   MAPDN_NR_DENSE (0/1)                                   1: use the dense LDS-resident LU with f64 MFMA trailing updates
  *                                                          (<= 65 buses; any topology) instead
- *   MAPDN_SP_LANES (16/8/4/2)                              envs per workgroup of the sparse solver (default: scored per net) */
+ *   MAPDN_SP_LANES (16/8/4/2)                              envs per workgroup of the sparse solver (default: scored per net)
+ *   MAPDN_DEBUG_GEOMETRY (set)                             print the chosen NR geometry and LDS residency to stderr
+ * Results do not depend on these knobs: bus voltages, iteration counts and observations are bit-identical in every geometry;
+ * reward / info are sums over buses and lines formed from per-worker partials and agree to the last ulp. */
 int mapdn_create(const mapdn_netspec* net, const mapdn_env_config* cfg, int32_t n_envs,
                  int32_t device, mapdn_handle** out);
 void mapdn_destroy(mapdn_handle* h);

@@ -703,7 +703,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
           }
           SCHED_FENCE();                           // the factors leave after the contribution is on its way
           const unsigned k = kp & 0xffffu, voN = voE + k * bb;
-          if (HL) sH[(size_t)k * L] = d2{h0, h1};
+          if constexpr (HL) sH[(size_t)k * L] = d2{h0, h1};
           else if constexpr (RS >= 0) { a_put(h0, Ha[RS][0], Ha[RS][1]); a_put(h1, Ha[RS][2], Ha[RS][3]); }
           else bst2(d2{h0, h1}, rs, voN, sF_H);
           if (GL) { sG[(size_t)(2 * k) * L] = d2{G0, G1}; sG[(size_t)(2 * k + 1) * L] = d2{G2, G3}; }
