@@ -118,6 +118,11 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
   // wide k_post kernel (thread per bus x env) commits res_bus — |V|, angle(V), p_mw, q_mvar — for the
   // envs flagged in d.commit: throughput work does not belong in this 512-wave kernel
   double* gV = d.nrbuf + (size_t)d.r_vout * SB + e;
+  // this worker's first sgen q values (written by the inject kernel, cold in the cache): requested now, used after the two loops
+  constexpr int QPRE = 3;
+  double q_pre[QPRE];
+#pragma unroll
+  for (int i = 0; i < QPRE; ++i) { const unsigned j = t + (unsigned)i * Wt; q_pre[i] = (j < (unsigned)d.ns) ? d.q_new[(size_t)j * SB + e] : 0.0; }
   // the barrier type is hoisted out of the loop (one branch-free instance per type), so that the unrolled
   // iterations — sqrt and exp chains of different buses — can be interleaved by the scheduler
   auto bus_loop = [&](auto type_tag) {
@@ -150,6 +155,7 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
     mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
     bar += barrier(d.barrier_type, v);
   }
+  stamp(22);
   if (t == 0 && valid) d.commit[e] = commitf ? 1 : 0;
   // ---- res_line.pl_mw = Re(Sf + St) * sn   (out-of-service rows: fpos = tpos = slack, all-zero admittances)
   // LineFlow = {int32 fpos, tpos; double y[8]}: from LDS when staged there, else through the constant address space
@@ -172,13 +178,16 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
     }
   };
   if (d.nr_line_lds) line_loop((const double*)s_lines); else line_loop(linec);
+  stamp(23);
   // ---- sgen.q_mvar of the accepted solve; q statistics
-#pragma unroll 3
-  for (unsigned j = t; j < (unsigned)d.ns; j += Wt) {
-    const size_t o = (size_t)j * SB + e;
-    const double qn = d.q_new[o];
-    if (commitf) d.cur_q[o] = qn;
-    q_loss += fabs(qn * d.sgen_scale[j]); q_fail += fabs(qn);       // res_sgen.q_mvar (:604-606); the raw table (:189)
+  {
+    int i = 0;
+    for (unsigned j = t; j < (unsigned)d.ns; j += Wt, ++i) {
+      const size_t o = (size_t)j * SB + e;
+      const double qn = i < QPRE ? (i == 0 ? q_pre[0] : i == 1 ? q_pre[1] : q_pre[2]) : d.q_new[o];
+      if (commitf) d.cur_q[o] = qn;
+      q_loss += fabs(qn * d.sgen_scale[j]); q_fail += fabs(qn);     // res_sgen.q_mvar (:604-606); the raw table (:189)
+    }
   }
   // ---- slow path (wave-uniform, rare): an env of this wave is active but did not converge -> its
   // statistics come from the PREVIOUS committed state (voltage_control_env.py:190 restores last_powergrid)
@@ -210,6 +219,16 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
 #pragma unroll
   for (int q = 0; q < 10; ++q) sm[(size_t)(q * Wt + t) * L] = part[q];
   __syncthreads();
+  // worker q (and q + Wt, ...) forms the total of quantity q over the workers, in the fixed order 0, 1, 2, ..., and leaves it in
+  // entry 0 of its row (only this lane reads that row); worker 0 then picks up ten totals instead of summing 10 x Wt values itself
+  constexpr unsigned UNR = Wt <= 16 ? Wt : 8;     // (the general solvers have up to 128 workers)
+  for (unsigned q = t; q < 10u; q += Wt) {
+    double a = sm[(size_t)(q * Wt) * L];
+#pragma unroll UNR
+    for (unsigned ww = 1; ww < Wt; ++ww) { const double b = sm[(size_t)(q * Wt + ww) * L]; a = (q == 4u || q == 5u) ? fmax(a, b) : a + b; }
+    sm[(size_t)(q * Wt) * L] = a;
+  }
+  __syncthreads();
   if (t != 0 || !valid) return;
   if (!act) {                                     // frozen env: terminated earlier in this episode
     reward[e] = 0.0; terminated[e] = 1;
@@ -225,14 +244,8 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
     return;
   }
   double tot[10];
-  constexpr unsigned UNR = Wt <= 16 ? Wt : 8;     // (the general solvers have up to 128 workers)
 #pragma unroll
-  for (int q = 0; q < 10; ++q) {
-    double a = sm[(size_t)(q * Wt) * L];
-#pragma unroll UNR
-    for (unsigned ww = 1; ww < Wt; ++ww) { const double b = sm[(size_t)(q * Wt + ww) * L]; a = (q == 4 || q == 5) ? fmax(a, b) : a + b; }
-    tot[q] = a;
-  }
+  for (int q = 0; q < 10; ++q) tot[q] = sm[(size_t)(q * Wt) * L];
   {
     const bool ok = conv;
     const double inv_nb = 1.0 / (double)d.nb;
@@ -258,6 +271,7 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
     d.done[e] = term ? 1 : 0;
     reward[e] = rew; terminated[e] = term ? 1 : 0;
   }
+  stamp(24);
 }
 
 }  // namespace mapdn
