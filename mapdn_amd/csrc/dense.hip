@@ -226,8 +226,7 @@ k_nr_dense(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
         const double y0 = rhs[2 * tid], y1 = rhs[2 * tid + 1];
         double s, c;
         sincos(-y0, &s, &c);
-        const double sc = 1.0 - y1;
-        sV[tid] = d2{sc * (ek * c - fk * s), sc * (ek * s + fk * c)};
+        sV[tid] = nr_rotate(d2{ek, fk}, s, c, y1);
       }
       ++it;
       __syncthreads();

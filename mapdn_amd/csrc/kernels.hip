@@ -812,9 +812,25 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
 #if !(MAPDN_EXP & 1)
     if (__any(live && !(fabs(dth) <= 0.5))) sincos(dth, &s, &c);   // wave-uniform, only when a lane diverges
 #endif
-    const double sc = 1.0 - y1;
-    const double en = sc * (vk.x * c - vk.y * s), fn = sc * (vk.x * s + vk.y * c);
-    sV[(size_t)k * L] = done ? vk : d2{en, fn};     // converged envs keep their state; idle steps hit the trash node
+    sV[(size_t)k * L] = done ? vk : nr_rotate(vk, s, c, y1);   // converged envs keep their state; idle steps hit the trash node
+  };
+  // ... of three nodes at once: ONE wave-uniform check for the rare large-angle case instead of one per node, so that the three
+  // polynomial chains are a single basic block the scheduler can interleave (same expressions per node: same bits)
+  auto apply_update3 = [&](const d2 (&xx)[3], const d2 (&vv)[3], const unsigned (&kk)[3], const bool (&lv)[3]) {
+    double s[3], c[3];
+    bool big = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      dxm = fmax(dxm, lv[i] ? fmax(fabs(xx[i].x), fabs(xx[i].y)) : 0.0);
+      sincos_small(-xx[i].x, &s[i], &c[i]);
+      big = big || (lv[i] && !(fabs(xx[i].x) <= 0.5));
+    }
+    if (__any(big)) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) if (__any(lv[i] && !(fabs(xx[i].x) <= 0.5))) sincos(-xx[i].x, &s[i], &c[i]);   // as apply_update decides, node by node
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sV[(size_t)kk[i] * L] = done ? vv[i] : nr_rotate(vv[i], s[i], c[i], xx[i].y);
   };
   // ---- backward sweep, h in LDS (HL): x-propagation + parallel update.
   // Only x_k = h_k - G_k x_parent is a chain down the tree; the voltage update of a node needs nothing but its own x.  So the
@@ -907,8 +923,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         lv[i] = kx < n; kk[i] = lv[i] ? kx : n + 1u;
         xx[i] = sH[(size_t)kk[i] * L]; vv[i] = sV[(size_t)kk[i] * L];
       }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) apply_update(xx[i].x, xx[i].y, vv[i], kk[i], lv[i]);
+      apply_update3(xx, vv, kk, lv);
       STAMP(30);
     }
   };

@@ -48,6 +48,13 @@ __device__ __forceinline__ double rcp_nr(double x) {
   return fma(r, t, r);
 }
 
+// newtonpf update of one bus in rectangular form: V <- V (1 - y1) e^{j dth} with (s, c) = sincos(dth).  The fused multiply-adds are
+// spelled out, so that every kernel and code path rounds alike whatever the compiler would contract.
+__device__ __forceinline__ d2 nr_rotate(d2 v, double s, double c, double y1) {
+  const double sc = 1.0 - y1;
+  return d2{sc * fma(v.x, c, -(v.y * s)), sc * fma(v.x, s, v.y * c)};
+}
+
 // cos/sin of a Newton angle step |x| <= 0.5: Taylor to x^16 / x^17 (remainder < 2e-23)
 __device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
   const double z = x * x;

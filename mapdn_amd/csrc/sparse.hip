@@ -168,8 +168,7 @@ k_nr_sparse(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ 
         const d2 vi = sV[(size_t)i * L];
         double sn, cs;
         sincos(-y0, &sn, &cs);
-        const double sc = 1.0 - y1;
-        sV[(size_t)i * L] = d2{sc * (vi.x * cs - vi.y * sn), sc * (vi.x * sn + vi.y * cs)};
+        sV[(size_t)i * L] = nr_rotate(vi, sn, cs, y1);
       }
     }
     if (!done) ++it;
