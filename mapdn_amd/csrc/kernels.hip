@@ -953,6 +953,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         sH[(size_t)k * L] = d2{apk_r, apk_i};
       }
     }
+    STAMP(31);
     if (W > 1) lds_barrier();
     // (2) S_k, F_k, verdict.  The index words run two turns ahead, the constants and the Sbus entry (whose address needs the index
     // word) one turn ahead.
