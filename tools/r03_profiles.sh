@@ -10,7 +10,7 @@ cd /tmp
 cfg_run() {  # case envs
   local c=$1 b=$2 t=${1}_b${2}
   timeout 600 python $R/bench.py --case $c --envs $b --steps 480 --warmup 24 --no-cpu-baseline > $OUT/bench_$t.json 2> $OUT/bench_$t.err
-  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ks_$t -o ks -- python $R/bench.py --case $c --envs $b --steps 100 --warmup 10 --no-cpu-baseline --no-traffic > /dev/null 2> $OUT/ks_$t.log
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ks_$t -o ks -- python $R/bench.py --case $c --envs $b --steps 100 --warmup 10 --no-cpu-baseline --no-traffic --no-other-shapes > /dev/null 2> $OUT/ks_$t.log
   db=$(find $OUT/ks_$t -name "*.db" | head -1)
   [ -n "$db" ] && python $R/tools/prof_summary.py $db $OUT/kernel_stats_$t.txt > /dev/null
   rm -rf $OUT/ks_$t
