@@ -816,21 +816,22 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   };
   // ... of three nodes at once: ONE wave-uniform check for the rare large-angle case instead of one per node, so that the three
   // polynomial chains are a single basic block the scheduler can interleave (same expressions per node: same bits)
-  auto apply_update3 = [&](const d2 (&xx)[3], const d2 (&vv)[3], const unsigned (&kk)[3], const bool (&lv)[3]) {
-    double s[3], c[3];
+  constexpr int UPN = NR_UPDATE_GROUP;            // nodes per turn of the update pass
+  auto apply_update3 = [&](const d2 (&xx)[UPN], const d2 (&vv)[UPN], const unsigned (&kk)[UPN], const bool (&lv)[UPN]) {
+    double s[UPN], c[UPN];
     bool big = false;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < UPN; ++i) {
       dxm = fmax(dxm, lv[i] ? fmax(fabs(xx[i].x), fabs(xx[i].y)) : 0.0);
       sincos_small(-xx[i].x, &s[i], &c[i]);
       big = big || (lv[i] && !(fabs(xx[i].x) <= 0.5));
     }
     if (__any(big)) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) if (__any(lv[i] && !(fabs(xx[i].x) <= 0.5))) sincos(-xx[i].x, &s[i], &c[i]);   // as apply_update decides, node by node
+      for (int i = 0; i < UPN; ++i) if (__any(lv[i] && !(fabs(xx[i].x) <= 0.5))) sincos(-xx[i].x, &s[i], &c[i]);   // as apply_update decides, node by node
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) sV[(size_t)kk[i] * L] = done ? vv[i] : nr_rotate(vv[i], s[i], c[i], xx[i].y);
+    for (int i = 0; i < UPN; ++i) sV[(size_t)kk[i] * L] = done ? vv[i] : nr_rotate(vv[i], s[i], c[i], xx[i].y);
   };
   // ---- backward sweep, h in LDS (HL): x-propagation + parallel update.
   // Only x_k = h_k - G_k x_parent is a chain down the tree; the voltage update of a node needs nothing but its own x.  So the
@@ -915,10 +916,10 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       }
     });
     // (3) update of every node from its x, three nodes per pass (loads first)
-    for (unsigned kb = t; kb < n; kb += 3u * Wt) {
-      unsigned kk[3]; d2 xx[3], vv[3]; bool lv[3];
+    for (unsigned kb = t; kb < n; kb += (unsigned)UPN * Wt) {
+      unsigned kk[UPN]; d2 xx[UPN], vv[UPN]; bool lv[UPN];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < UPN; ++i) {
         const unsigned kx = kb + (unsigned)i * Wt;
         lv[i] = kx < n; kk[i] = lv[i] ? kx : n + 1u;
         xx[i] = sH[(size_t)kk[i] * L]; vv[i] = sV[(size_t)kk[i] * L];

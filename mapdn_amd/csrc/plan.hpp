@@ -171,6 +171,10 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& out,
 #define NR_G_REG_ROWS 6
 #endif
 // ... and, in the layouts whose h factors are in global scratch too, rows whose h AND G stay in registers (12 AGPRs each)
+// nodes per turn of k_nr_tree's update pass (their loads up front, their arithmetic one basic block)
+#ifndef NR_UPDATE_GROUP
+#define NR_UPDATE_GROUP 3
+#endif
 #ifndef NR_HG_REG_ROWS
 #define NR_HG_REG_ROWS 12
 #endif
