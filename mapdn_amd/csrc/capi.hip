@@ -345,26 +345,36 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     h->err = "MAPDN_NR_WAVES must be 1/2/4/8 and MAPDN_NR_LANES 32/16/8"; return MAPDN_E_INVALID; }
   if (P.n + 1 > 0xffff) { h->err = "networks with more than 65534 buses are not supported (16-bit node positions in the NR step records)"; return MAPDN_E_INVALID; }
   const int Wt = W * (64 / L);
-  build_schedule(P, Wt, h->sched, nr_min_cslots(W, L), 64 / L, NR_HG_REG_ROWS > NR_G_REG_ROWS ? NR_HG_REG_ROWS : NR_G_REG_ROWS);
-  if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
-  const int ncl = (int)h->sched.clist.size();
-  if (ncl > 4095) { h->err = "NR schedule: more than 4095 overflow children (junctions with > 3 non-chain children)"; return MAPDN_E_INVALID; }
   // Optional LDS residents, in order of benefit: the h factors, the step records, the flat-start constants, the net.line
   // constants of the fused res_line epilogue, then the G factors (with everything resident the solve state never leaves
   // the chip; what does not fit stays in / goes to L2-resident global memory).  In lean mode (big batches, see
   // choose_nr_geometry) only the voltages and hand-off slots are resident, so that several workgroups share a CU.
-  const int R_ = h->sched.R;
-  auto lds_for = [&](int hl, int gl, int ll, int rl, int fl) {
-    return nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, ncl, hl, gl, ll ? P.n_line : 0, rl ? R_ : 0, fl ? R_ : 0); };
+  // The kernel peels the first rows of its full sweeps (their G — and h, when h is not in LDS — stay in registers): a schedule
+  // shorter than that is rebuilt with idle rows appended; one that needs no peeled rows (G in LDS) is left alone.
   const size_t LDS_MAX = 160 * 1024;
   auto opt = [&](const char* name, int dflt) { const char* s = getenv(name); return s ? (atoi(s) ? 1 : 0) : dflt; };
-  int h_lds = opt("MAPDN_NR_H_LDS", !lean && lds_for(1, 0, 0, 0, 0) <= LDS_MAX);
-  int rec_lds = opt("MAPDN_NR_REC_LDS", !lean && lds_for(h_lds, 0, 0, 1, 0) <= LDS_MAX);
-  int flat_lds = opt("MAPDN_NR_FLAT_LDS", !lean && lds_for(h_lds, 0, 0, rec_lds, 1) <= LDS_MAX);
-  int line_lds = opt("MAPDN_NR_LINE_LDS", !lean && P.n_line > 0 && lds_for(h_lds, 0, 1, rec_lds, flat_lds) <= LDS_MAX) && P.n_line > 0;
-  int g_lds = opt("MAPDN_NR_G_LDS", !lean && h_lds && lds_for(1, 1, line_lds, rec_lds, flat_lds) <= LDS_MAX) && h_lds;
-  const size_t lds_need = lds_for(h_lds, g_lds, line_lds, rec_lds, flat_lds);
-  if (lds_need > LDS_MAX) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
+  int h_lds = 0, rec_lds = 0, flat_lds = 0, line_lds = 0, g_lds = 0, ncl = 0, R_ = 0, min_rows = 0;
+  size_t lds_need = 0;
+  for (int pass = 0; pass < 4; ++pass) {
+    build_schedule(P, Wt, h->sched, nr_min_cslots(W, L), 64 / L, min_rows);
+    if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
+    ncl = (int)h->sched.clist.size();
+    if (ncl > 4095) { h->err = "NR schedule: more than 4095 overflow children (junctions with > 3 non-chain children)"; return MAPDN_E_INVALID; }
+    R_ = h->sched.R;
+    auto lds_for = [&](int hl, int gl, int ll, int rl, int fl) {
+      return nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, ncl, hl, gl, ll ? P.n_line : 0, rl ? R_ : 0, fl ? R_ : 0); };
+    h_lds = opt("MAPDN_NR_H_LDS", !lean && lds_for(1, 0, 0, 0, 0) <= LDS_MAX);
+    rec_lds = opt("MAPDN_NR_REC_LDS", !lean && lds_for(h_lds, 0, 0, 1, 0) <= LDS_MAX);
+    flat_lds = opt("MAPDN_NR_FLAT_LDS", !lean && lds_for(h_lds, 0, 0, rec_lds, 1) <= LDS_MAX);
+    line_lds = opt("MAPDN_NR_LINE_LDS", !lean && P.n_line > 0 && lds_for(h_lds, 0, 1, rec_lds, flat_lds) <= LDS_MAX) && P.n_line > 0;
+    g_lds = opt("MAPDN_NR_G_LDS", !lean && h_lds && lds_for(1, 1, line_lds, rec_lds, flat_lds) <= LDS_MAX) && h_lds;
+    lds_need = lds_for(h_lds, g_lds, line_lds, rec_lds, flat_lds);
+    if (lds_need > LDS_MAX) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
+    const int need = g_lds ? 0 : (h_lds ? NR_G_REG_ROWS : NR_HG_REG_ROWS);
+    if (R_ >= need) { min_rows = -1; break; }
+    min_rows = need;
+  }
+  if (min_rows >= 0) { h->err = "NR schedule: could not settle the number of peeled rows"; return MAPDN_E_INVALID; }
   d.nr_waves = W; d.nr_lanes = L; d.nr_h_lds = h_lds; d.nr_g_lds = g_lds; d.nr_line_lds = line_lds; d.nr_rec_lds = rec_lds; d.nr_flat_lds = flat_lds;
   h->lds_bytes = lds_need;
   if (getenv("MAPDN_DEBUG_GEOMETRY"))
