@@ -1334,7 +1334,15 @@ k_gather(const double* __restrict__ base, const int32_t* rows_g, const double* s
   typedef const __attribute__((address_space(4))) double* c_f64;
   const c_i32 rows = (c_i32)(unsigned long long)rows_g, x_ptr = (c_i32)(unsigned long long)x_ptr_g, x_row = (c_i32)(unsigned long long)x_row_g;
   const c_f64 scales = (c_f64)(unsigned long long)scales_g;
-  const int c0 = blockIdx.x * 64, e0 = blockIdx.y * 64;
+  // XCD-aware tile order: consecutive workgroups land on consecutive XCDs (block b on XCD b % 8, observed; only speed depends
+  // on it), and a source row of 64 envs is read by every column tile whose zones contain that bus (2.4 of them on average) —
+  // so all column tiles of an env tile go to ONE XCD, whose L2 then serves the re-reads: XCD k takes env tiles k, k + 8, ...
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if ((gridDim.y & 7u) == 0u) {
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7u, slot = lin >> 3;
+    by = (slot / gridDim.x) * 8u + xcd; bx = slot % gridDim.x;
+  }
+  const int c0 = (int)bx * 64, e0 = (int)by * 64;
   const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int rw[16]; double sc[16];
 #pragma unroll
