@@ -20,6 +20,7 @@ for part in "$@"; do
 case $part in
 main) cfg_run case141 4096; cfg_run case33 4096; cfg_run case322 4096; cfg_run case322 1024; cfg_run case322 8192; cfg_run case141 8192; cfg_run case141_deep 4096;;
 case33only) cfg_run case33 4096;;
+headline) cfg_run case141 4096; cfg_run case33 4096;;
 stamps) for c in case141 case141_deep case322 case33; do MAPDN_LIB_PATH=$R/mapdn_amd/lib_stamps.so timeout 120 python $R/tools/nr_stamps.py --case $c --envs 4096 > $OUT/stamps_$c.txt 2>&1; done; grep -E "row|update|verdict|solve end" $OUT/stamps_case141.txt | tail -30;;
 full) timeout 900 python $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | cut -c1-300;;
 sq) timeout 600 rocprofv3 -i $R/tools/pmc_sq.txt --output-format csv -d $OUT/sq -o sq -- python $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-traffic > $OUT/sq.log 2>&1
