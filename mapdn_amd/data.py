@@ -256,11 +256,14 @@ def from_pandapower(net) -> NetSpec:
 # to_dict_with_coord_transform) and the rest are scalars / dicts (name, f_hz, sn_mva, version, std_types, _options ...).
 # Nets pickled as objects (pickle.dump(net)) carry `pandapower.auxiliary.pandapowerNet` (a dict subclass) holding real
 # pandas DataFrames.  Both forms are data: no pandapower CODE is needed to read them.  The unpickler below resolves only
-#   * numpy's array / dtype / scalar reconstructors and pandas' container classes (pandas.core.*, pandas._libs.*),
+#   * numpy's array / dtype / scalar reconstructors and an EXPLICIT (module, name) list of pandas' data classes and pickle
+#     reconstructors (_PANDAS_OK; a module-prefix rule would also expose the helper functions pandas modules re-export —
+#     round 3's rule did, and a gadget chain through them reached os.system),
 #   * plain builtin containers,
 #   * `pandapower.*` names, which are mapped to INERT stand-ins (a dict subclass for the net, an attribute bag for
 #     anything else, e.g. controller objects inside net.controller) — their code is never imported or run,
-# and refuses every other global (os, subprocess, builtins.eval ...): a pickle is a program, model.p is downloaded data.
+# and refuses every other global (os, subprocess, builtins.eval, functions inside pandas ...): a pickle is a program, model.p is
+# downloaded data.  (Defence in depth, not a proof: prefer netspec.npz for files of unknown origin.)
 # ------------------------------------------------------------------------------------------------
 class InertNet(dict):
     """attribute-style dict standing in for pandapower.auxiliary.pandapowerNet / ADict (tables are pandas DataFrames)"""
@@ -299,13 +302,54 @@ _MISC_OK = {("collections", "OrderedDict"), ("collections", "defaultdict"), ("co
             ("datetime", "datetime"), ("datetime", "date"), ("datetime", "timedelta"), ("datetime", "timezone"),
             ("_codecs", "encode"), ("__builtin__", "object"), ("__builtin__", "dict"), ("__builtin__", "list"), ("__builtin__", "set"),
             ("__builtin__", "tuple"), ("__builtin__", "slice"), ("__builtin__", "long"), ("__builtin__", "unicode")}
-_PANDAS_PREFIXES = ("pandas.core.frame", "pandas.core.series", "pandas.core.internals", "pandas.core.indexes", "pandas.core.index",
-                    "pandas.core.arrays", "pandas.core.dtypes", "pandas.core.generic", "pandas._libs", "pandas.indexes", "pandas.tseries")
+# pandas: an explicit (module, name) list of the DATA classes and the reconstructor functions a pickled DataFrame / Series /
+# Index references (enumerated with pickletools over frames of every column kind, protocols 2-5, plus the legacy paths of
+# pandas.compat.pickle_compat).  NOT a module-prefix rule: pandas modules re-export functions (import helpers, file
+# handles, functools.partial ...) that a hand-assembled pickle could call through REDUCE.
+_PANDAS_OK = {
+    ("pandas.core.frame", "DataFrame"), ("pandas.core.series", "Series"),
+    ("pandas.core.internals.managers", "BlockManager"), ("pandas.core.internals.managers", "SingleBlockManager"),
+    ("pandas._libs.internals", "_unpickle_block"), ("pandas._libs.arrays", "__pyx_unpickle_NDArrayBacked"),
+    ("pandas.core.indexes.base", "Index"), ("pandas.core.indexes.base", "_new_Index"),
+    ("pandas.core.indexes.range", "RangeIndex"), ("pandas.core.indexes.multi", "MultiIndex"),
+    ("pandas.core.indexes.frozen", "FrozenList"),
+    ("pandas.core.indexes.datetimes", "DatetimeIndex"), ("pandas.core.indexes.datetimes", "_new_DatetimeIndex"),
+    ("pandas.core.indexes.category", "CategoricalIndex"),
+    ("pandas.core.arrays.categorical", "Categorical"), ("pandas.core.arrays", "Categorical"),
+    ("pandas.core.dtypes.dtypes", "CategoricalDtype"), ("pandas.core.dtypes.dtypes", "DatetimeTZDtype"),
+    ("pandas.core.arrays.datetimes", "DatetimeArray"),
+    ("pandas.core.arrays.boolean", "BooleanArray"), ("pandas.core.arrays.boolean", "BooleanDtype"),
+    ("pandas.core.arrays.integer", "IntegerArray"), ("pandas.core.arrays.integer", "Int64Dtype"),
+    ("pandas.core.arrays.integer", "Int32Dtype"), ("pandas.core.arrays.integer", "UInt32Dtype"),
+    ("pandas.core.arrays.integer", "UInt64Dtype"),
+    ("pandas.core.arrays.floating", "FloatingArray"), ("pandas.core.arrays.floating", "Float64Dtype"),
+    ("pandas.core.arrays.floating", "Float32Dtype"),
+    ("pandas.core.arrays.string_", "StringArray"), ("pandas.core.arrays.string_", "StringDtype"),
+    ("pandas._libs.missing", "NA"), ("pandas._libs.tslibs.nattype", "__nat_unpickle"),
+    ("pandas._libs.tslibs.timestamps", "_unpickle_timestamp"), ("pandas._libs.tslibs.timestamps", "Timestamp"),
+}
+# module paths of older pandas versions (pandapower 2.7.0 pins pandas 1.1.3) that pickle_compat maps onto the entries above
+_PANDAS_LEGACY = {
+    ("pandas.core.indexes.numeric", "Int64Index"), ("pandas.core.indexes.numeric", "UInt64Index"),
+    ("pandas.core.indexes.numeric", "Float64Index"), ("pandas.core.internals.blocks", "new_block"),
+    ("pandas.indexes.base", "Index"), ("pandas.indexes.base", "_new_Index"), ("pandas.indexes.multi", "MultiIndex"),
+    ("pandas.indexes.numeric", "Float64Index"), ("pandas.indexes.numeric", "Int64Index"), ("pandas.indexes.range", "RangeIndex"),
+    ("pandas.core.base", "FrozenList"), ("pandas.core.categorical", "Categorical"), ("pandas.core.series", "TimeSeries"),
+    ("pandas.tseries.index", "DatetimeIndex"), ("pandas.tseries.index", "_new_DatetimeIndex"),
+    ("pandas._libs.tslib", "__nat_unpickle"), ("pandas.tslib", "__nat_unpickle"), ("pandas._libs.tslib", "Timestamp"),
+    ("pandas.tslib", "Timestamp"),
+}
+_PANDAS_FUNCS = {"_unpickle_block", "__pyx_unpickle_NDArrayBacked", "_new_Index", "_new_DatetimeIndex", "__nat_unpickle",
+                 "_unpickle_timestamp"}
 
 
 def _restricted_unpickler(f):
     import importlib
     import pickle
+
+    def refuse(module, name):
+        raise pickle.UnpicklingError(f"model.p references {module}.{name}: not a numpy / pandas / builtin data class — refused "
+                                     "(mapdn_amd.data reads pandapower pickles as data, it never imports or runs their code)")
 
     class U(pickle.Unpickler):
         def find_class(self, module, name):
@@ -318,12 +362,21 @@ def _restricted_unpickler(f):
                 if module == "copy_reg":
                     module = "copyreg"
                 return getattr(importlib.import_module(module), name)
-            if module.startswith(_PANDAS_PREFIXES) and not name.startswith("__"):
-                import pandas.compat.pickle_compat as pc          # old pandas module paths -> current classes (data classes only)
-                module, name = pc._class_locations_map.get((module, name), (module, name)) if hasattr(pc, "_class_locations_map") else (module, name)
-                return getattr(importlib.import_module(module), name)
-            raise pickle.UnpicklingError(f"model.p references {module}.{name}: not a numpy / pandas / builtin data class — refused "
-                                         "(mapdn_amd.data reads pandapower pickles as data, it never imports or runs their code)")
+            if (module, name) in _PANDAS_LEGACY:
+                import pandas.compat.pickle_compat as pc          # old pandas module paths -> current classes
+                module, name = getattr(pc, "_class_locations_map", {}).get((module, name), (module, name))
+                if (module, name) == ("pandas._libs.tslib", "Timestamp"):
+                    module = "pandas._libs.tslibs.timestamps"
+            if (module, name) not in _PANDAS_OK:
+                refuse(module, name)
+            obj = getattr(importlib.import_module(module), name)
+            # belt and braces: what the name resolves to must itself live in pandas and be a class, the NA singleton or one of
+            # the named reconstructors — never a function another module re-exports under an allowed name
+            home = getattr(obj, "__module__", None) or getattr(type(obj), "__module__", "")
+            ok = home.startswith("pandas.") and (isinstance(obj, type) or name in _PANDAS_FUNCS or name == "NA")
+            if not ok:
+                refuse(module, name)
+            return obj
     return U(f, encoding="latin1")
 
 

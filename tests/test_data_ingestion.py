@@ -329,6 +329,47 @@ def test_model_p_with_code_in_it_is_refused(tmp_path):
         read_pandapower_pickle(p)
 
 
+def test_model_p_gadgets_inside_pandas_are_refused(tmp_path):
+    """a module-prefix allow-list lets a hand-assembled pickle reach functions that pandas modules merely
+    RE-EXPORT (import helpers, file handles, functools.partial) and chain them into os.system.  The allow-list is now explicit
+    (module, name) pairs of data classes and reconstructors: every link of that chain must be refused, and a frame of every
+    column kind must still load."""
+    import pickle
+    import pandas as pd
+    from mapdn_amd.data import _restricted_unpickler, read_pandapower_pickle
+    gadgets = [
+        b"cpandas._libs.tslibs.timezones\nimport_optional_dependency\n(S'os'\ntR.",   # returns the os module
+        b"cpandas.core.indexes.extension\n_inherit_from_data\n(S'system'\nS'x'\ntR.",  # builds method(self) -> getattr(self._data, ...)
+        b"cpandas.core.frame\nget_handle\n(S'/tmp/mapdn_should_not_exist'\nS'w'\ntR.",  # truncates a file
+        b"cpandas.core.frame\nfunctools\n.",                                           # a module re-exported as an attribute
+        b"cpandas._libs.lib\nmap_infer\n.",
+        b"cpandas.core.generic\npickle\n.",
+        b"cpandas.core.series\n_coerce_method\n.",
+        b"cpandas.io.pickle\nread_pickle\n.",
+        b"cfunctools\npartial\n.",
+        b"cos\nsystem\n.",
+    ]
+    p = str(tmp_path / "model.p")
+    for g in gadgets:
+        with open(p, "wb") as f:
+            f.write(g)
+        with pytest.raises(pickle.UnpicklingError, match="refused"):
+            read_pandapower_pickle(p)
+    assert not os.path.exists("/tmp/mapdn_should_not_exist")
+    # ... while real tables of every column kind still load, in every protocol
+    df = pd.DataFrame({"a": [1.0, 2.0], "b": [1, 2], "c": [True, False], "d": ["x", None], "e": pd.Categorical(["u", "v"]),
+                       "f": pd.to_datetime(["2020-01-01", "2020-01-02"]), "g": pd.array([1, None], dtype="Int64"),
+                       "h": pd.array(["s", None], dtype="string"), "i": pd.array([True, None], dtype="boolean"),
+                       "j": pd.array([1.5, None], dtype="Float64")})
+    for obj in (df, df.set_index(["a", "b"]), df.set_index("d"), df["a"], pd.Timestamp("2020-01-01")):
+        for proto in (2, 4, 5):
+            with open(p, "wb") as f:
+                pickle.dump({"t": obj}, f, protocol=proto)
+            with open(p, "rb") as f:
+                got = _restricted_unpickler(f).load()["t"]
+            assert got.equals(obj) if hasattr(obj, "equals") else got == obj
+
+
 def test_load_scenario_opens_a_directory_with_model_p(tmp_path):
     """the reference's data directory layout: model.p + three CSVs, no netspec.npz, no pandapower"""
     from mapdn_amd.data import load_scenario, save_profiles_csv
