@@ -73,8 +73,6 @@ class BatchedOracleShard:
         from mapdn_amd.netspec import make_case
         from oracle import env_restated
         from oracle.batched_np import BatchedRunpp
-        self.er = env_restated
-        self.real_runpp = env_restated.runpp_restated
         net, prof = make_case(case)
         self.net = net
         self.envs = [env_restated.VoltageControlOracle(net, prof, _oracle_args(case), env_id=first_env_id + e) for e in range(n_envs)]
@@ -88,11 +86,8 @@ class BatchedOracleShard:
                           np.stack([e.sgen_p for e in envs]), qs)
         out = []
         for e, a, r in zip(envs, actions, res):
-            self.er.runpp_restated = lambda *x, _r=r, **k: _r          # the env's own runpp call returns its share of the batch
-            try:
-                rew, term, info = e.step(a)
-            finally:
-                self.er.runpp_restated = self.real_runpp
+            e._runpp_override = r                                       # the env's own runpp call takes its share of the batch (an
+            rew, term, info = e.step(a)                                 # explicit per-env hook: no process-wide state is patched)
             e.get_obs()
             if term:
                 e.reset()                                               # (rare) the restart's power flow: the one-env solver

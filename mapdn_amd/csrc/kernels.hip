@@ -1366,7 +1366,8 @@ k_gather(const double* __restrict__ base, const int32_t* rows_g, const double* s
   __syncthreads();
   // write phase: 16 threads x 4 consecutive columns per env row -> 16-byte (f32) / 32-byte (f64) stores
   const int q4 = (threadIdx.x & 15) * 4, er = threadIdx.x >> 4;
-  const bool vec = (C % 4) == 0;
+  // the 4-column vector store needs C % 4 == 0 AND a base pointer aligned to the vector (callers may hand in a view into a packed buffer)
+  const bool vec = (C % 4) == 0 && ((unsigned long long)out % (sizeof(T) * 4)) == 0;
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int r = er + 16 * pass, e = e0 + r, c = c0 + q4;

@@ -112,7 +112,7 @@ k_policy_fwd(const float* __restrict__ obs, const float* __restrict__ hid_in, co
     for (int nt = 0; nt < 4; ++nt) {
       const int u = 16 * nt + j;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xt[(4 * g + r) * 68 + u] = fmaxf(fmaf((acc[nt][r] - mean[r]) * rstd[r], sG[u], sB[u]), 0.0f);
+      for (int r = 0; r < 4; ++r) { const float o = fmaf((acc[nt][r] - mean[r]) * rstd[r], sG[u], sB[u]); xt[(4 * g + r) * 68 + u] = o > 0.0f ? o : (o != o ? o : 0.0f); }   // ReLU, NaN kept (as torch.relu)
     }
     // (one wavefront: its LDS writes are visible to its later reads, no barrier)
     // ---- GRUCell pre-activations: r, z over [x | h] (K = 128), i_n over x, h_n over h
@@ -186,7 +186,9 @@ k_ln64_fwd(const f4* __restrict__ x, const float* __restrict__ gamma, const floa
     const float var = row_sum16((dv.x * dv.x + dv.y * dv.y) + (dv.z * dv.z + dv.w * dv.w)) * (1.0f / 64.0f);
     const float r = rsqrtf(var + eps);
     f4 o = dv * r * g + b;
-    if (RELU) { o.x = fmaxf(o.x, 0.0f); o.y = fmaxf(o.y, 0.0f); o.z = fmaxf(o.z, 0.0f); o.w = fmaxf(o.w, 0.0f); }
+    // torch.relu propagates NaN (fmaxf would turn it into 0 and hide a diverged update)
+    if (RELU) { o.x = o.x > 0.0f ? o.x : (o.x != o.x ? o.x : 0.0f); o.y = o.y > 0.0f ? o.y : (o.y != o.y ? o.y : 0.0f);
+                o.z = o.z > 0.0f ? o.z : (o.z != o.z ? o.z : 0.0f); o.w = o.w > 0.0f ? o.w : (o.w != o.w ? o.w : 0.0f); }
     y[row * 16 + l16] = o;
     if (l16 == 0) { mean[row] = mu; rstd[row] = r; }
   }

@@ -432,11 +432,18 @@ class VoltageControl(MultiAgentEnv):
         # are views of it) mirrored by ONE pinned host buffer: a step() is one async H2D of the action, the four kernels, one
         # async D2H of the packed outputs and a single stream synchronisation; the get_obs() that follows costs nothing.
         n, o1 = b.n_agents, b._obs_size1
-        self._pk_off = dict(reward=0, info=8, term=8 + 8 * N_INFO, obs=8 + 8 * N_INFO + 8)
+        # Offsets: info 32-byte aligned, obs 64-byte aligned — k_gather's write phase stores 4 consecutive f64 columns as one
+        # 32-byte vector (kernels.hip, `V4`), which assumes the alignment torch.empty gave the old stand-alone obs tensor
+        # (torch device allocations and pinned host allocations are >= 256-byte aligned; asserted below)
+        off_info = 32
+        off_term = off_info + 8 * N_INFO
+        off_obs = (off_term + 8 + 63) // 64 * 64
+        self._pk_off = dict(reward=0, info=off_info, term=off_term, obs=off_obs)
         nbytes = self._pk_off["obs"] + 8 * n * o1
         self._pk_dev = torch.zeros(nbytes, dtype=torch.uint8, device=b.device)
         self._pk_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
         self._pk_np = self._pk_host.numpy()
+        assert self._pk_dev.data_ptr() % 64 == 0 and self._pk_host.data_ptr() % 64 == 0, "packed step buffers must be 64-byte aligned"
         po = self._pk_off
         b._reward = self._pk_dev[po["reward"]:po["reward"] + 8].view(torch.float64)
         b._info = self._pk_dev[po["info"]:po["info"] + 8 * N_INFO].view(torch.float64).view(1, N_INFO)

@@ -105,8 +105,8 @@ class _LayerNorm64(torch.autograd.Function):
         dy2 = dy.reshape(-1, 64).contiguous()
         dx = torch.empty_like(x2)
         dw, db = torch.empty_like(w), torch.empty_like(b)
-        partial = torch.empty(lib.mapdn_layernorm64_backward_blocks(rows) * 128, dtype=torch.float32, device=x2.device)
-        with torch.cuda.device(x2.device):
+        with torch.cuda.device(x2.device):                  # the block count follows the CU count of the CURRENT device: ask inside the context
+            partial = torch.empty(lib.mapdn_layernorm64_backward_blocks(rows) * 128, dtype=torch.float32, device=x2.device)
             _lib.check(lib.mapdn_layernorm64_backward(dy2.data_ptr(), x2.data_ptr(), w.data_ptr(), b.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                       dx.data_ptr(), dw.data_ptr(), db.data_ptr(), partial.data_ptr(), rows, int(ctx.relu),
                                                       torch.cuda.current_stream(x2.device).cuda_stream))
@@ -116,7 +116,7 @@ class _LayerNorm64(torch.autograd.Function):
 def layernorm_act(ln: nn.LayerNorm, act, x: torch.Tensor) -> torch.Tensor:
     """act(LayerNorm(x)): one HIP launch each way for the reference's default shape (64 features, ReLU, fp32, on the GPU), the
     PyTorch modules otherwise (MAPDN_FUSED_LN=0 forces them)."""
-    if (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 64 and act is F.relu and ln.elementwise_affine
+    if (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 64 and act is F.relu and ln.elementwise_affine and ln.bias is not None
             and ln.weight.dtype == torch.float32 and x.numel() >= 64 * 1024 and os.environ.get("MAPDN_FUSED_LN", "1") != "0"):
         return _LayerNorm64.apply(x, ln.weight, ln.bias, ln.eps, True)
     return act(ln(x))

@@ -73,6 +73,7 @@ class VoltageControlOracle:
         self.args = a
         self.net, self.prof = net, prof
         self.env_id = int(env_id)
+        self._runpp_override = None                     # see _take_action
         self.seed = int(a["seed"])
         self.draw = 0
         self.episode_limit = a["episode_limit"]
@@ -163,7 +164,11 @@ class VoltageControlOracle:
 
     def _take_action(self, actions):                                                         # :548-566
         self.sgen_q = self._clip_reactive_power(np.asarray(actions, dtype=np.float64), self.sgen_p)
-        res = runpp_restated(self.net, self.load_p, self.load_q, self.sgen_p, self.sgen_q)
+        # `_runpp_override`: a result computed outside for exactly these inputs (bench.py's batched-numpy CPU baseline solves the
+        # power flows of many envs as one vectorised Newton iteration and hands every env its share); consumed once
+        res, self._runpp_override = self._runpp_override, None
+        if res is None:
+            res = runpp_restated(self.net, self.load_p, self.load_q, self.sgen_p, self.sgen_q)
         if res.converged:
             self.res = res
             self.res_sgen_q = self.sgen_q * self.net.sgen_scaling     # res_sgen.q_mvar = q_mvar * scaling
