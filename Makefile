@@ -1,13 +1,27 @@
 # Convenience targets; the Python entry points (mapdn_amd.build, __graft_entry__.build) do the same build.
+# `make -j8 lib` compiles the translation units in parallel (k_nr_tree's instantiations are four objects from one source).
 HIPCC ?= /opt/rocm/bin/hipcc
+FLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result
 LIB   := mapdn_amd/libmapdn_hip.so
-SRC   := mapdn_amd/csrc/plan.cpp mapdn_amd/csrc/kernels.hip mapdn_amd/csrc/dense.hip mapdn_amd/csrc/sparse.hip mapdn_amd/csrc/policy.hip mapdn_amd/csrc/capi.hip
-HDR   := mapdn_amd/csrc/plan.hpp mapdn_amd/csrc/kernels.hpp mapdn_amd/csrc/nr_common.hpp include/mapdn.h
+CSRC  := mapdn_amd/csrc
+SRC   := plan.cpp kernels.hip dense.hip sparse.hip policy.hip capi.hip
+HDR   := $(CSRC)/plan.hpp $(CSRC)/kernels.hpp $(CSRC)/nr_common.hpp $(CSRC)/nr_tree.hpp $(CSRC)/nr_inst_list.hpp include/mapdn.h
+OBJ   := $(addprefix build/,$(addsuffix .o,$(basename $(SRC)))) build/nr_inst_0.o build/nr_inst_1.o build/nr_inst_2.o build/nr_inst_3.o
 
 lib: $(LIB)
 
-$(LIB): $(SRC) $(HDR)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-result -o $@.tmp $(SRC)
+build/%.o: $(CSRC)/%.hip $(HDR)
+	@mkdir -p build
+	$(HIPCC) $(FLAGS) -c $< -o $@
+build/%.o: $(CSRC)/%.cpp $(HDR)
+	@mkdir -p build
+	$(HIPCC) $(FLAGS) -c $< -o $@
+build/nr_inst_%.o: $(CSRC)/nr_inst.hip $(HDR)
+	@mkdir -p build
+	$(HIPCC) $(FLAGS) -DNR_INST_PART=$* -c $< -o $@
+
+$(LIB): $(OBJ)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@.tmp $(OBJ)
 	mv $@.tmp $@
 
 c_abi_host: examples/c_abi_host.c $(LIB)

@@ -118,6 +118,53 @@ typedef struct mapdn_env_config {
                                        random initial action; voltage_control_env.py:96-135) and reports reward 0,
                                        terminated 0, info 0 and mapdn_get_auto_reset_mask() == 1; `terminated` is
                                        therefore reported exactly once per episode                                  */
+  /* ---- launch / solver tuning.  Appended fields, every one 0 = automatic, so that zero-initialised older callers keep
+   * working and two handles in one process can differ (nothing below is process-global).  Results do not depend on the
+   * GEOMETRY fields: bus voltages, iteration counts and observations are bit-identical in every geometry; reward / info are
+   * sums over buses and lines formed from per-worker partials and agree to the last ulp.  For tools and A/B runs every
+   * field has an environment-variable override that is read once, inside mapdn_create (named per field). */
+  int32_t nr_solver;                /* 0 auto: tree kernel (k_nr_tree) for radial feeders, sparse block program (k_nr_sparse)
+                                       for meshed nets; 1: k_nr_sparse on a radial net too (cross-checks); 2: k_nr_dense, the
+                                       LDS-resident dense LU with f64 MFMA trailing updates (<= 65 buses, any topology).
+                                       env: MAPDN_NR_SPARSE=1 / MAPDN_NR_DENSE=1                                         */
+  int32_t nr_waves;                 /* k_nr_tree: waves per workgroup, 0 auto | 1 | 2 | 4              env: MAPDN_NR_WAVES */
+  int32_t nr_lanes;                 /* k_nr_tree: envs per workgroup,  0 auto | 8 | 16 | 32            env: MAPDN_NR_LANES
+                                       (a (waves, lanes) pair that is not compiled in — csrc/nr_inst_list.hpp — is refused) */
+  int32_t nr_lean;                  /* 0 auto | 1 lean: only voltages + hand-off slots in LDS, several workgroups per CU |
+                                       2 fat: whatever fits of h, step records, flat-start constants, net.line constants, G
+                                                                                                     env: MAPDN_NR_LEAN=1/0 */
+  int32_t nr_h_lds, nr_g_lds, nr_rec_lds, nr_flat_lds, nr_line_lds;
+                                    /* LDS residency of the h / G factors, the step records, the flat-start constants, the
+                                       net.line constants: 0 auto (whatever fits, in that order) | 1 resident | 2 not resident
+                                       env: MAPDN_NR_H_LDS, MAPDN_NR_G_LDS, MAPDN_NR_REC_LDS, MAPDN_NR_FLAT_LDS,
+                                       MAPDN_NR_LINE_LDS = 1/0                                                             */
+  int32_t nr_mm_pass;               /* the predicted-final mismatch evaluation: 0 auto (barrier-free pass over all nodes when h
+                                       is LDS-resident) | 1 pass | 2 mismatch-only tree sweep (same bits) env: MAPDN_NR_MM_PASS */
+  int32_t sp_lanes;                 /* k_nr_sparse: envs per workgroup, 0 auto (scored per net) | 16 | 8 | 4 | 2
+                                                                                                       env: MAPDN_SP_LANES */
+  int32_t inject_full;              /* 1: step() / reset() rebuild Sbus on every bus (k_inject) instead of on the PV buses only
+                                       (k_inject_sgen); same bits, for A/B runs and tests               env: MAPDN_INJECT_FULL */
+  double nr_check_dx;               /* Newton-step size below which the next sweep is first tried mismatch-only; 0 = 1e-7
+                                       (never changes results)                                         env: MAPDN_NR_CHECK_DX */
+  double nr_check_quad;             /* safety factor of the second predictor, ||F||^3 / ||F_prev||^2 < tol / factor; 0 = 1,
+                                       +inf disables it                                              env: MAPDN_NR_CHECK_QUAD */
+  int32_t debug_geometry;           /* 1: print the chosen NR geometry and LDS residency to stderr   env: MAPDN_DEBUG_GEOMETRY */
+  /* ---- numerical options of runpp that DO change results (pp.runpp keyword arguments the reference leaves at their
+   * defaults, voltage_control_env.py:557) */
+  double tolerance_mva;             /* runpp(tolerance_mva=...): 0 = 1e-8 (the pandapower default)                          */
+  int32_t tolerance_is_pu;          /* How the stopping rule of newtonpf is formed from tolerance_mva.  0 (default): ||F||inf <
+                                       tolerance_mva / sn_mva, F in per unit — the rule as restated in oracle/pp_restated.py from
+                                       pandapower 2.7.0 (`ppci_variables` / `_run_newton_raphson_pf`; UNPINNED: pandapower is not
+                                       installable here).  1: ||F||inf < tolerance_mva with F in per unit (no division).  The two
+                                       coincide on every net with sn_mva == 1 (all MAPDN scenarios and bench nets);
+                                       tests/test_pandapower_pin.py::test_tolerance_rule_on_sn_mva_not_one decides which one
+                                       pandapower uses wherever pandapower is installed                                    */
+  int32_t nr_init;                  /* runpp(init=...): 0 "auto"/"flat" — every solve starts at the slack set-point, what the
+                                       reference does (default; exact pandapower iterates); 1 "results" — OPT-IN warm start: a
+                                       step() solve starts from the env's last accepted voltages and falls back to the exact
+                                       flat-start solve when it has not converged after 3 iterations; voltages then agree with
+                                       the flat-start answer to the solver tolerance (<< 1e-6 p.u.), iteration counts differ.
+                                       Radial feeders only (k_nr_tree); reset() and mapdn_solve_only always start flat          */
 } mapdn_env_config;
 
 typedef struct mapdn_dims_t {
@@ -140,26 +187,8 @@ const char* mapdn_last_error(const mapdn_handle* h);
  * all blocks of a few envs in LDS (nets up to ~2400 blocks after fill: the 322-bus case with tie lines fits).
  * Nets beyond that and nets with buses not connected to the ext_grid return MAPDN_E_TOPOLOGY.
  * device == -1 builds a host-only handle (plan, dims, ybus/obs-index export; no device calls).
- * Tuning knobs read from the environment at create time (defaults are chosen per topology):
- *   MAPDN_NR_WAVES (1/2/4/8), MAPDN_NR_LANES (8/16/32)     waves and envs per NR workgroup
- *   MAPDN_NR_LEAN (0/1)                                    1: only voltages + hand-off slots in LDS (several workgroups per CU)
- *   MAPDN_NR_H_LDS, MAPDN_NR_G_LDS, MAPDN_NR_REC_LDS,      keep the h / G factors, the step records, the flat-start constants,
- *   MAPDN_NR_FLAT_LDS, MAPDN_NR_LINE_LDS (0/1)             the net.line constants in LDS (default: whatever fits, in that order)
- *   MAPDN_NR_MM_PASS (0/1, default 1 with h in LDS)        0: the predicted-final mismatch evaluation runs as a mismatch-only tree
- *                                                          sweep instead of the barrier-free pass over all nodes (same bits)
- *   MAPDN_INJECT_FULL (0/1)                                1: step() / reset() rebuild Sbus on every bus (k_inject) instead of on
- *                                                          the PV buses only (k_inject_sgen); same bits, for A/B runs and tests
- *   MAPDN_NR_CHECK_DX (default 1e-7)                       Newton-step size below which the next sweep is
- *                                                          first tried mismatch-only (never changes results)
- *   MAPDN_NR_CHECK_QUAD (default 1)                        safety factor of the second predictor, ||F||^3/||F_prev||^2 < tol / factor
- *                                                          ("inf" disables it)
- *   MAPDN_NR_SPARSE (0/1)                                  1: use the general sparse solver on a radial net too (cross-checks)
- *   MAPDN_NR_DENSE (0/1)                                   1: use the dense LDS-resident LU with f64 MFMA trailing updates
- *                                                          (<= 65 buses; any topology) instead
- *   MAPDN_SP_LANES (16/8/4/2)                              envs per workgroup of the sparse solver (default: scored per net)
- *   MAPDN_DEBUG_GEOMETRY (set)                             print the chosen NR geometry and LDS residency to stderr
- * Results do not depend on these knobs: bus voltages, iteration counts and observations are bit-identical in every geometry;
- * reward / info are sums over buses and lines formed from per-worker partials and agree to the last ulp. */
+ * Launch geometry and solver choice: automatic per topology and batch size; mapdn_env_config's tuning fields (and, for tools,
+ * their environment-variable overrides) select them explicitly.  mapdn_get_nr_geometry() reports what was chosen. */
 int mapdn_create(const mapdn_netspec* net, const mapdn_env_config* cfg, int32_t n_envs,
                  int32_t device, mapdn_handle** out);
 void mapdn_destroy(mapdn_handle* h);
@@ -234,6 +263,12 @@ int mapdn_get_obs_index(const mapdn_handle* h, int32_t* kind, int32_t* index);
  * rows [W * (*n_rows)] node position per (wave, row) or -1, parent [n] parent position per node
  * (n = n_bus-1 means the slack).  Call with rows == NULL to query *n_rows first. */
 int mapdn_get_schedule(const mapdn_handle* h, int32_t n_waves, int32_t* n_rows, int32_t* rows, int32_t* parent);
+
+/* Host-side export of the launch geometry mapdn_create settled on (also for device == -1 handles, which assume a 256-CU
+ * device): out[16] = solver (0 tree, 1 sparse, 2 dense), waves, lanes (envs per workgroup), lean, schedule rows, h_lds, g_lds,
+ * rec_lds, flat_lds, line_lds, mm_pass, dynamic LDS bytes per workgroup, workgroups, workgroups resident per CU (model),
+ * rounds of workgroups, modelled launch time in ns (the chooser's score; 0 when the geometry was forced). */
+int mapdn_get_nr_geometry(const mapdn_handle* h, int32_t* out16);
 
 /* Host-side export of the flat-start factorisation the NR kernel's first iteration uses (plan check, CPU tests):
  * factors [n][12] per elimination position = S_calc (re, im), D^-1 (4, row-major), A_pk (re, im), G (4, row-major)

@@ -32,6 +32,7 @@ EXPORTS = (
     "mapdn_solve_only", "mapdn_get_ybus_dense", "mapdn_get_obs_index", "mapdn_get_schedule", "mapdn_get_flat_factors", "mapdn_stats", "mapdn_nr_timing",
     "mapdn_nr_time_ms", "mapdn_get_auto_reset_mask", "mapdn_dense_solve", "mapdn_step_obs", "mapdn_get_sparse_program", "mapdn_policy_forward",
     "mapdn_policy_forward_fits", "mapdn_layernorm64_forward", "mapdn_layernorm64_backward", "mapdn_layernorm64_backward_blocks",
+    "mapdn_get_nr_geometry",
 )
 
 _pd = C.POINTER(C.c_double)
@@ -62,7 +63,22 @@ class CEnvConfig(C.Structure):
         ("v_lower", C.c_double), ("v_upper", C.c_double), ("episode_limit", C.c_int32),
         ("action_low", C.c_double), ("action_high", C.c_double), ("reset_action", C.c_int32),
         ("state_space", C.c_int32), ("seed", C.c_uint64), ("env_id_offset", C.c_int64), ("auto_reset", C.c_int32),
+        # launch / solver tuning (0 = automatic) and the runpp options the reference leaves at their defaults — include/mapdn.h
+        ("nr_solver", C.c_int32), ("nr_waves", C.c_int32), ("nr_lanes", C.c_int32), ("nr_lean", C.c_int32),
+        ("nr_h_lds", C.c_int32), ("nr_g_lds", C.c_int32), ("nr_rec_lds", C.c_int32), ("nr_flat_lds", C.c_int32), ("nr_line_lds", C.c_int32),
+        ("nr_mm_pass", C.c_int32), ("sp_lanes", C.c_int32), ("inject_full", C.c_int32),
+        ("nr_check_dx", C.c_double), ("nr_check_quad", C.c_double), ("debug_geometry", C.c_int32),
+        ("tolerance_mva", C.c_double), ("tolerance_is_pu", C.c_int32), ("nr_init", C.c_int32),
     ]
+
+
+# keys of the `tuning` dict of VoltageControlBatch (== the appended fields of mapdn_env_config)
+TUNING_INT = ("nr_solver", "nr_waves", "nr_lanes", "nr_lean", "nr_h_lds", "nr_g_lds", "nr_rec_lds", "nr_flat_lds", "nr_line_lds",
+              "nr_mm_pass", "sp_lanes", "inject_full", "debug_geometry", "tolerance_is_pu", "nr_init")
+TUNING_F64 = ("nr_check_dx", "nr_check_quad", "tolerance_mva")
+NR_SOLVERS = dict(auto=0, tree=0, sparse=1, dense=2)
+GEOMETRY_KEYS = ("solver", "waves", "lanes", "lean", "rows", "h_lds", "g_lds", "rec_lds", "flat_lds", "line_lds", "mm_pass",
+                 "lds_bytes", "workgroups", "resident_per_cu", "rounds", "model_ns")
 
 
 class CDims(C.Structure):
@@ -124,6 +140,7 @@ def load():
     lib.mapdn_get_obs_index.argtypes = [vp, _pi, _pi]
     lib.mapdn_get_schedule.argtypes = [vp, C.c_int32, _pi, _pi, _pi]
     lib.mapdn_get_flat_factors.argtypes = [vp, _pd, _pi]
+    lib.mapdn_get_nr_geometry.argtypes = [vp, _pi]
     lib.mapdn_get_sparse_program.argtypes = [vp, C.c_int32, _pi, _pi, _pi, _pi]
     lib.mapdn_policy_forward.argtypes = [vp] * 14 + [C.c_int32] * 4 + [C.c_float, vp]
     lib.mapdn_policy_forward_fits.argtypes = [C.c_int32, C.c_int32]
@@ -195,8 +212,19 @@ def make_cnetspec(net: NetSpec):
     return s, keep
 
 
-def make_cconfig(args: dict, env_id_offset: int = 0) -> CEnvConfig:
+def make_cconfig(args: dict, env_id_offset: int = 0, tuning: dict | None = None) -> CEnvConfig:
+    """mapdn_env_config from the reference's constructor kwargs; `tuning` fills the appended launch / solver fields
+    (include/mapdn.h: nr_waves, nr_lanes, nr_lean, nr_*_lds, nr_mm_pass, nr_solver = 'sparse' | 'dense', nr_init, tolerance_mva ...)."""
     c = CEnvConfig()
+    for k, v in (tuning or {}).items():
+        if k == "nr_solver" and isinstance(v, str):
+            v = NR_SOLVERS[v]
+        if k in TUNING_INT:
+            setattr(c, k, int(v))
+        elif k in TUNING_F64:
+            setattr(c, k, float(v))
+        else:
+            raise KeyError(f"unknown tuning key {k!r} (known: {TUNING_INT + TUNING_F64})")
     bt = args.get("voltage_barrier_type", "l1")
     if bt not in BARRIER_IDS:
         raise KeyError(bt)   # reference: Voltage_Barrier[name] KeyError (voltage_barrier_backend.py:8)
@@ -219,3 +247,10 @@ def make_cconfig(args: dict, env_id_offset: int = 0) -> CEnvConfig:
     c.env_id_offset = int(env_id_offset)
     c.auto_reset = int(bool(args.get("auto_reset", False)))
     return c
+
+
+def nr_geometry(handle) -> dict:
+    """what mapdn_create settled on for this handle (mapdn_get_nr_geometry)"""
+    out = (C.c_int32 * 16)()
+    check(load().mapdn_get_nr_geometry(handle, out), handle)
+    return dict(zip(GEOMETRY_KEYS, [int(x) for x in out]))

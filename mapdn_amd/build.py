@@ -7,9 +7,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libmapdn_hip.so")
+LIB = os.environ.get("MAPDN_BUILD_OUT") or os.path.join(HERE, "libmapdn_hip.so")   # MAPDN_BUILD_OUT: debug variants beside the product library
 SOURCES = ["plan.cpp", "kernels.hip", "dense.hip", "sparse.hip", "policy.hip", "capi.hip"]
-HEADERS = ["plan.hpp", "kernels.hpp", "nr_common.hpp", os.path.join("..", "..", "include", "mapdn.h")]
+# k_nr_tree's instantiations (nr_inst_list.hpp) are compiled as NR_PARTS objects from ONE source, in parallel
+NR_INST_SOURCE, NR_PARTS = "nr_inst.hip", 4
+HEADERS = ["plan.hpp", "kernels.hpp", "nr_common.hpp", "nr_tree.hpp", "nr_inst_list.hpp", NR_INST_SOURCE,
+           os.path.join("..", "..", "include", "mapdn.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 
 
 def _stale() -> bool:
@@ -21,18 +25,39 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc -c every translation unit (in parallel: the NR instantiations dominate), then link the shared library."""
     if not force and not _stale():
         return LIB
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    tmp = LIB + f".tmp{os.getpid()}"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-o", tmp]
-    cmd += os.environ.get("MAPDN_EXTRA_FLAGS", "").split()        # debug builds only (e.g. -DMAPDN_NR_STAMPS)
-    # .cpp host files are compiled as plain C++ by hipcc; .hip as HIP
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
-    os.replace(tmp, LIB)          # atomic: a concurrent loader never sees a half-written library
+    extra = os.environ.get("MAPDN_EXTRA_FLAGS", "").split()        # debug builds only (e.g. -DMAPDN_NR_STAMPS)
+    objdir = tempfile.mkdtemp(prefix="mapdn_build_")
+    jobs = []                                                      # (command, object)
+    for p in range(NR_PARTS):                                      # longest first
+        o = os.path.join(objdir, f"nr_inst_{p}.o")
+        jobs.append(([hipcc] + FLAGS + extra + [f"-DNR_INST_PART={p}", "-c", os.path.join(CSRC, NR_INST_SOURCE), "-o", o], o))
+    for s in SOURCES:                                              # .cpp host files are compiled as plain C++ by hipcc; .hip as HIP
+        o = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        jobs.append(([hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, s), "-o", o], o))
+
+    def run(job):
+        if verbose:
+            print(" ".join(job[0]), file=sys.stderr)
+        subprocess.run(job[0], check=True)
+        return job[1]
+    try:
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+            objs = list(ex.map(run, jobs))
+        tmp = LIB + f".tmp{os.getpid()}"
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+        if verbose:
+            print(" ".join(link), file=sys.stderr)
+        subprocess.run(link, check=True)
+        os.replace(tmp, LIB)      # atomic: a concurrent loader never sees a half-written library
+    finally:
+        shutil.rmtree(objdir, ignore_errors=True)
     return LIB
 
 

@@ -32,6 +32,9 @@ struct mapdn_handle {
   uint32_t sb_base = 0, sb_bytes = 0;   // the two Sbus buffers of nrbuf: d.sb_off / d.sb_off_alt alternate between them
   std::vector<int32_t> ld_dest_host;
   size_t lds_bytes = 0;
+  // what mapdn_create settled on (mapdn_get_nr_geometry); tree solver only: W .. mm_pass
+  struct Geo { int W = 0, L = 0, lean = 0, rows = 0, h_lds = 0, g_lds = 0, rec_lds = 0, flat_lds = 0, line_lds = 0, mm_pass = 0, ncl = 0;
+               size_t lds = 0; long wgs = 0; int resident = 0, rounds = 0; double model_ns = 0.0; } geo;
   int32_t *obs_rows = nullptr, *state_rows = nullptr, *iota_idx = nullptr, *vm_row = nullptr, *va_row = nullptr;
   int32_t *obs_xptr = nullptr, *obs_xrow = nullptr;
   double *obs_scale = nullptr, *state_scale = nullptr;
@@ -79,25 +82,141 @@ static int dupload(mapdn_handle* h, const T** p, const std::vector<T>& v) {
   return MAPDN_OK;
 }
 
-// NR launch geometry for a padded batch of Bp envs on a net with n non-slack buses (MI355X: 256 CUs x 4 SIMDs, one
-// wave per SIMD is all a 16-env workgroup can offer).  Measured on case33/141/322 (tools/r02_nr_sweep.sh,
-// profiles/r02_nr_geometry_*.txt):
-//   * a batch that gives every CU at most one workgroup is latency-bound: spread each env over 16 workers on all four
-//     SIMDs (W = 4) and keep everything the solve touches in LDS ("fat");
-//   * a bigger batch is throughput-bound: 8 workers (W = 2) and only the voltages + hand-off slots in LDS ("lean",
-//     ~55 KB), so that two or three workgroups share a CU and hide each other's latency (1.5x the env rate of fat).
-static void choose_nr_geometry(int Bp, int n, int n_cu, int& W, int& L, int& lean) {
-  lean = 0;
-  if (n < 48) { W = 1; L = 16; }                  // small feeders: 4 workers are enough
-  else if (n < 200) {
-    L = 16;
-    if (Bp / L > n_cu) { W = 2; lean = 1; } else W = 4;
-  } else {
-    // ~320-bus feeders: LDS holds voltages + h factors of 8 envs (32 workers, rows = tree radius).  A batch that would need more
-    // than one round of such workgroups takes 16 envs per workgroup instead — 16 workers, ~30 % more rows, h in global scratch,
-    // but half as many rounds: 161.6 -> 138.8 us per launch at 4096 envs (profiles/r03_geometry_case322.txt)
-    W = 4; L = (Bp / 8 > n_cu) ? 16 : 8;
+// ---- tuning knobs: a field of mapdn_env_config (0 = automatic), overridden by an environment variable when one is set (tools,
+// A/B runs).  Read once, in mapdn_create; nothing is process-global afterwards.
+static int knob_int(int cfg_value, const char* env) { const char* s = getenv(env); return s ? atoi(s) : cfg_value; }
+// tri-state residency / mode switches: cfg 0 auto | 1 on | 2 off;  env NAME=1 -> on, NAME=0 -> off
+static int knob_tri(int cfg_value, const char* env) { const char* s = getenv(env); return s ? (atoi(s) ? 1 : 2) : cfg_value; }
+static double knob_f64(double cfg_value, const char* env, double dflt) {
+  const char* s = getenv(env);
+  if (s) return atof(s);
+  return cfg_value != 0.0 ? cfg_value : dflt;
+}
+
+// ---- k_nr_tree launch geometry.
+// A workgroup = W waves serving L envs; each wave carries 64/L lane-group workers, so Wt = W*64/L workers eliminate independent
+// subtrees of every env concurrently (schedule rows R(Wt) >= the radius of the feeder).  Small batches are latency-bound: spread
+// each env over many workers and keep everything the solve touches in LDS ("fat", one workgroup per CU); batches that would need
+// several ROUNDS of such workgroups take fewer workers / less LDS per env instead so that more envs are resident ("lean", or 16
+// instead of 8 envs per workgroup on the 322-bus class).  The choice is the minimum of a launch-time model over the candidate
+// (W, L, lean) triples, each with its own schedule and LDS residency settled first:
+//     t = rounds x [ c0 + b n/Wt + row(W) R (1 + p [h not in LDS]) ] x load x share
+//   rounds = ceil(workgroups / (CUs x resident));  resident = workgroups per CU by LDS (160 KB) and registers (one wave per SIMD:
+//            every instantiation uses more than half of the register file)
+//   row(W) = 2.37 / 2.90 / 3.00 us per schedule row (all sweeps of one solve together) with 1 / 2 / 4 waves: the row barrier
+//            spans the workgroup;  c0 = 26 us, b = 0.36 us per node and worker (passes, epilogue)
+//   load   = 1 + 0.21 [h not in LDS] x min(1, workgroups / CUs): factors through L2 / HBM slow down as the chip fills
+//   share  = 1 + 0.5 x max(0, waves per SIMD - 1)
+// Least-squares fit (relative error, 25 points, residuals <= 10 %, tools/nr_geometry_fit.py) to the launch times measured for
+// case33 / case141 / case141_deep / case322 at 1024 ... 16384 envs in fat and lean layouts (profiles/r02_nr_geometry_case141.txt,
+// profiles/r03_geometry_case322.txt, profiles/r03_final_*_kernel_stats.txt); it ranks every measured pair in the measured order.
+// mapdn_env_config.nr_waves / nr_lanes / nr_lean pin a choice.
+static double nr_model_ns(int W, int L, int n, int R, int h_lds, long wgs, int resident, int n_cu) {
+  const double Wt = (double)W * (64 / L);
+  const long per_round = (long)n_cu * std::max(resident, 1);
+  const double rounds = (double)((wgs + per_round - 1) / per_round);
+  const double row = W == 1 ? 2374.0 : (W == 2 ? 2903.0 : 3001.0);
+  const double fill = (double)wgs / (double)n_cu;                           // workgroups per CU wanted
+  const double conc = std::min((double)std::max(resident, 1), std::max(1.0, fill));   // ... sharing a CU
+  const double base = 26032.0 + 363.0 * (double)n / Wt + row * (double)R * (h_lds ? 1.0 : 1.023);
+  const double load = 1.0 + (h_lds ? 0.0 : 0.21) * std::min(1.0, fill);
+  const double share = 1.0 + 0.5 * std::max(0.0, conc * W / 4.0 - 1.0);
+  return rounds * base * load * share;
+}
+
+// Settles the k_nr_tree geometry of a handle: (W, L, lean) — pinned by the config / environment or chosen by the model above —
+// then the schedule for Wt workers and the LDS residents.  Works without a device (host-only handles assume n_cu CUs).
+static int settle_tree_geometry(mapdn_handle* h, int Bp, int n_cu) {
+  const Plan& P = h->plan;
+  const mapdn_env_config& c = h->cfg;
+  const size_t LDS_MAX = 160 * 1024;
+  if (P.n + 1 > 0xffff) { h->err = "networks with more than 65534 buses are not supported (16-bit node positions in the NR step records)"; return MAPDN_E_INVALID; }
+  const int f_h = knob_tri(c.nr_h_lds, "MAPDN_NR_H_LDS"), f_g = knob_tri(c.nr_g_lds, "MAPDN_NR_G_LDS"), f_rec = knob_tri(c.nr_rec_lds, "MAPDN_NR_REC_LDS"),
+            f_flat = knob_tri(c.nr_flat_lds, "MAPDN_NR_FLAT_LDS"), f_line = knob_tri(c.nr_line_lds, "MAPDN_NR_LINE_LDS");
+  auto tri = [](int forced, bool dflt) { return forced == 1 ? 1 : (forced == 2 ? 0 : (dflt ? 1 : 0)); };
+  // Optional LDS residents, in order of benefit: the h factors, the step records, the flat-start constants, the net.line
+  // constants of the fused res_line epilogue, then the G factors (with everything resident the solve state never leaves
+  // the chip; what does not fit stays in / goes to L2-resident global memory).  In lean mode only the voltages and hand-off
+  // slots are resident, so that several workgroups share a CU.
+  // The kernel peels the first rows of its full sweeps (their G — and h, when h is not in LDS — stay in registers): a schedule
+  // shorter than that is rebuilt with idle rows appended; one that needs no peeled rows (G in LDS) is left alone.
+  auto settle = [&](int W, int L, int lean, Schedule& S, mapdn_handle::Geo& g) -> int {   // 0 ok, 1 does not fit / not compiled, <0 error
+    const int Wt = W * (64 / L);
+    int min_rows = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+      build_schedule(P, Wt, S, nr_min_cslots(W, L), 64 / L, min_rows);
+      if (S.n_cslots > 1023 || S.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
+      g.ncl = (int)S.clist.size();
+      if (g.ncl > 4095) { h->err = "NR schedule: more than 4095 overflow children (junctions with > 3 non-chain children)"; return MAPDN_E_INVALID; }
+      if ((long)S.R * Wt > 0xffff) { h->err = "NR schedule has more than 65535 steps"; return MAPDN_E_INVALID; }
+      const int R_ = S.R;
+      auto lds_for = [&](int hl, int gl, int ll, int rl, int fl) {
+        return nr_lds_bytes(W, L, P.n, S.n_cslots, S.n_xslots, g.ncl, hl, gl, ll ? P.n_line : 0, rl ? R_ : 0, fl ? R_ : 0); };
+      g.h_lds = tri(f_h, !lean && lds_for(1, 0, 0, 0, 0) <= LDS_MAX);
+      g.rec_lds = tri(f_rec, !lean && lds_for(g.h_lds, 0, 0, 1, 0) <= LDS_MAX);
+      g.flat_lds = tri(f_flat, !lean && lds_for(g.h_lds, 0, 0, g.rec_lds, 1) <= LDS_MAX);
+      g.line_lds = (tri(f_line, !lean && P.n_line > 0 && lds_for(g.h_lds, 0, 1, g.rec_lds, g.flat_lds) <= LDS_MAX) && P.n_line > 0) ? 1 : 0;
+      g.g_lds = (tri(f_g, !lean && g.h_lds && lds_for(1, 1, g.line_lds, g.rec_lds, g.flat_lds) <= LDS_MAX) && g.h_lds) ? 1 : 0;
+      g.lds = lds_for(g.h_lds, g.g_lds, g.line_lds, g.rec_lds, g.flat_lds);
+      if (g.lds > LDS_MAX) return 1;
+      const int need = g.g_lds ? 0 : (g.h_lds ? NR_G_REG_ROWS : NR_HG_REG_ROWS);
+      if (R_ >= need) { min_rows = -1; break; }
+      min_rows = need;
+    }
+    if (min_rows >= 0) { h->err = "NR schedule: could not settle the number of peeled rows"; return MAPDN_E_INVALID; }
+    const int compiled = nr_geometry_compiled(W, L, g.h_lds, g.g_lds, g.rec_lds, g.flat_lds);
+    if (!compiled) return 1;
+    g.W = W; g.L = L; g.lean = lean; g.rows = S.R;
+    g.wgs = Bp / L;
+    // workgroups resident per CU: LDS, and the register file — every k_nr_tree instantiation keeps factors of its peeled rows in
+    // AGPRs and uses 284 ... 452 of a SIMD's 512 registers per lane: one wave per SIMD, i.e. 4 / W workgroups per CU
+    g.resident = (int)std::max<size_t>(1, std::min<size_t>(LDS_MAX / std::max<size_t>(g.lds, 1), (size_t)std::max(4 / W, 1)));
+    const long per_round = (long)n_cu * g.resident;
+    g.rounds = (int)((g.wgs + per_round - 1) / per_round);
+    g.model_ns = nr_model_ns(W, L, P.n, S.R, g.h_lds, g.wgs, g.resident, n_cu) * (compiled == 2 ? 1.0 : 1.05);   // generic body: the
+                                                                   // per-row residency branches cost ~6 %
+    return 0;
+  };
+  int W = knob_int(c.nr_waves, "MAPDN_NR_WAVES"), L = knob_int(c.nr_lanes, "MAPDN_NR_LANES");
+  const int lean_k = knob_tri(c.nr_lean, "MAPDN_NR_LEAN");          // 0 auto, 1 lean, 2 fat
+  if ((W != 0 && W != 1 && W != 2 && W != 4 && W != 8) || (L != 0 && L != 8 && L != 16 && L != 32)) {
+    h->err = "nr_waves (MAPDN_NR_WAVES) must be 1/2/4/8 and nr_lanes (MAPDN_NR_LANES) 8/16/32 (0 = automatic)"; return MAPDN_E_INVALID; }
+  mapdn_handle::Geo best; Schedule bestS; bool have = false;
+  const bool forced = W != 0 && L != 0 && lean_k != 0;
+  // automatic candidates: the pairs the model was fitted on; the other compiled pairs (nr_inst_list.hpp) only when pinned
+  static const int cand[][2] = {{1, 16}, {2, 16}, {4, 16}, {4, 8}};
+  for (const auto& wl : cand) {
+    if ((W && wl[0] != W) || (L && wl[1] != L)) continue;
+    for (int lean = 0; lean < 2; ++lean) {
+      if ((lean_k == 1 && !lean) || (lean_k == 2 && lean)) continue;
+      mapdn_handle::Geo g; Schedule S;
+      const int r = settle(wl[0], wl[1], lean, S, g);
+      if (r < 0) return r;
+      if (r > 0) continue;
+      if (!have || g.model_ns < best.model_ns) { best = g; bestS = std::move(S); have = true; }
+    }
   }
+  if (!have && W && L) {          // a pinned pair outside the candidate list (e.g. tests): no model, just settle it
+    mapdn_handle::Geo g; Schedule S;
+    const int r = settle(W, L, lean_k == 1 ? 1 : 0, S, g);
+    if (r < 0) return r;
+    if (r == 0) { best = g; bestS = std::move(S); have = true; }
+    else if (g.lds > LDS_MAX) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (nr_lanes / MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
+  }
+  if (!have) {
+    h->err = (W || L) ? "this (nr_waves, nr_lanes) combination is not compiled in or does not fit the 160 KB LDS of a CU (csrc/nr_inst_list.hpp)"
+                      : "no compiled k_nr_tree geometry fits this network into the 160 KB LDS of a CU";
+    return MAPDN_E_INVALID; }
+  if (forced) best.model_ns = 0.0;
+  const int mm = knob_tri(c.nr_mm_pass, "MAPDN_NR_MM_PASS");
+  best.mm_pass = (best.h_lds && mm != 2) ? 1 : 0;    // the pass needs the h array in LDS
+  h->geo = best; h->sched = std::move(bestS); h->lds_bytes = best.lds;
+  if (knob_int(c.debug_geometry, "MAPDN_DEBUG_GEOMETRY"))
+    fprintf(stderr, "[mapdn] k_nr_tree geometry: W %d L %d lean %d rows %d cslots %d | LDS: h %d rec %d flat %d line %d G %d = %zu B | "
+                    "%ld workgroups, %d per CU, %d round(s), model %.1f us\n",
+            best.W, best.L, best.lean, best.rows, h->sched.n_cslots, best.h_lds, best.rec_lds, best.flat_lds, best.line_lds, best.g_lds,
+            best.lds, best.wgs, best.resident, best.rounds, best.model_ns * 1e-3);
+  return MAPDN_OK;
 }
 
 extern "C" {
@@ -111,6 +230,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   if (!cfg->use_line_weight && !cfg->use_q_weight) {   // voltage_control_env.py:616-617
     h->err = "NotImplementedError: Please at least give one weight, either q_weight or line_weight."; return MAPDN_E_INVALID; }
   if (cfg->episode_limit < 2) { h->err = "episode_limit must be >= 2"; return MAPDN_E_INVALID; }
+  if (cfg->nr_init != 0 && cfg->nr_init != 1) { h->err = "nr_init must be 0 (flat start) or 1 (warm start from the last accepted voltages)"; return MAPDN_E_INVALID; }
   int rc = build_plan(*net, *cfg, h->plan, h->err);
   if (rc) return rc;
   {
@@ -119,11 +239,14 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     // blocks of L envs in LDS); MAPDN_NR_DENSE=1 selects the dense LDS-resident LU with f64 MFMA (<= 65 buses),
     // MAPDN_NR_SPARSE=1 the sparse kernel on a radial net (cross-checks).
     const Plan& P0 = h->plan;
-    const char* fs = getenv("MAPDN_NR_SPARSE"); const char* fd = getenv("MAPDN_NR_DENSE");
-    const bool want_dense = fd && atoi(fd);
-    const bool want_sparse = !want_dense && ((fs && atoi(fs)) || !P0.radial);
+    int pick = cfg->nr_solver;
+    if (const char* fs = getenv("MAPDN_NR_SPARSE")) if (atoi(fs)) pick = 1;
+    if (const char* fd = getenv("MAPDN_NR_DENSE")) if (atoi(fd)) pick = 2;
+    if (pick < 0 || pick > 2) { h->err = "nr_solver must be 0 (auto), 1 (sparse) or 2 (dense)"; return MAPDN_E_INVALID; }
+    const bool want_dense = pick == 2;
+    const bool want_sparse = !want_dense && (pick == 1 || !P0.radial);
     if (want_dense) {
-      if (2 * P0.n > 128) { h->err = "MAPDN_NR_DENSE: the dense general-topology solver handles at most 65 buses"; return MAPDN_E_TOPOLOGY; }
+      if (2 * P0.n > 128) { h->err = "nr_solver = dense (MAPDN_NR_DENSE): the dense general-topology solver handles at most 65 buses"; return MAPDN_E_TOPOLOGY; }
       h->solver = 2;
     } else if (want_sparse) {
       SparseProg g0;
@@ -141,7 +264,11 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   h->device = device;
   std::memset(&h->d, 0, sizeof(h->d));
   h->d.B = B;
-  if (device == -1) { h->host_only = true; return MAPDN_OK; }   // plan only (CPU tests): no device work
+  if (device == -1) {                                            // plan only (CPU tests): no device work
+    h->host_only = true;
+    if (h->solver == 0) return settle_tree_geometry(h, (B + 63) / 64 * 64, 256);   // (an MI355X has 256 CUs)
+    return MAPDN_OK;
+  }
   int ndev = 0;
   HIPCHK(h, hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) { h->err = "device index out of range"; return MAPDN_E_HIP; }
@@ -178,7 +305,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     UP(sgb_pos, sgb); UP(sgb_of_pos, sgb_of); UP(lb_pos, lb); UP(mlo_pos, mlo);
     h->ld_dest_host.assign(std::max(P.nl, 1), 2);             // filled once the Sbus order (sb_index) is known, see alloc_nrbuf
     rc = dalloc(h, &d.bus_ld, (size_t)2 * d.n_sgb * d.Bp); if (rc) return rc;
-    if (const char* s_ = getenv("MAPDN_INJECT_FULL")) h->inject_full = atoi(s_) != 0;
+    h->inject_full = knob_int(cfg->inject_full, "MAPDN_INJECT_FULL") != 0;
   }
   {
     std::vector<LineFlow> padded(P.lines);               // read 16 bytes at a time by the NR kernel's LDS staging
@@ -309,13 +436,14 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
         if (score > best) { best = score; h->sp_lanes = l; }
       }
     }
-    if (const char* s_ = getenv("MAPDN_SP_LANES")) {   // experiments: envs per workgroup (16 / 8 / 4 / 2)
-      const int l = atoi(s_);
+    {                                                  // pinned envs per workgroup (16 / 8 / 4 / 2)
+      const int l = knob_int(cfg->sp_lanes, "MAPDN_SP_LANES");
       if (l == 16 || l == 8 || l == 4 || l == 2) h->sp_lanes = l;
+      else if (l != 0) { h->err = "sp_lanes (MAPDN_SP_LANES) must be 16, 8, 4 or 2 (0 = automatic)"; return MAPDN_E_INVALID; }
     }
     sparse_program(P, 64 / h->sp_lanes, h->sprog);
     const SparseProg& G = h->sprog;
-    if (nr_sparse_lds_bytes(P.n, G.n_blocks, h->sp_lanes) > 160 * 1024) { h->err = "MAPDN_SP_LANES: does not fit in LDS"; return MAPDN_E_INVALID; }
+    if (nr_sparse_lds_bytes(P.n, G.n_blocks, h->sp_lanes) > 160 * 1024) { h->err = "sp_lanes (MAPDN_SP_LANES): does not fit in LDS"; return MAPDN_E_INVALID; }
     d.sparse = 1; d.sp_lanes = h->sp_lanes; d.sp_blocks = G.n_blocks; d.sp_fill = (int32_t)G.fill_slots.size();
     d.sp_phases = G.n_phases; d.sp_rows_per_sub = G.rows_per_sub; d.sp_max_nnz = G.max_nnz;
     UP(sp_ops, G.ops); d.sp_ops_bytes = (uint32_t)(G.ops.size() * sizeof(SpOp));
@@ -328,82 +456,34 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     h->lds_bytes = nr_sparse_lds_bytes(P.n, G.n_blocks, h->sp_lanes);
     return MAPDN_OK;
   }
-  // ---- NR launch geometry: a workgroup = W waves serving L envs; each wave carries 64/L lane-group
-  // workers, so Wt = W*64/L workers eliminate independent subtrees of every env concurrently.
-  // Small batches get few envs per workgroup (many workgroups, all lanes busy with intra-env
-  // parallelism); big batches get L = 64 (pure env parallelism).  Override: MAPDN_NR_WAVES / MAPDN_NR_LANES.
-  int W, L, lean;
+  // ---- NR launch geometry (settle_tree_geometry above)
   {
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, device));
-    choose_nr_geometry(d.Bp, P.n, prop.multiProcessorCount, W, L, lean);
+    rc = settle_tree_geometry(h, d.Bp, prop.multiProcessorCount); if (rc) return rc;
   }
-  if (const char* s = getenv("MAPDN_NR_LEAN")) lean = atoi(s) ? 1 : 0;
-  if (const char* s = getenv("MAPDN_NR_WAVES")) W = atoi(s);
-  if (const char* s = getenv("MAPDN_NR_LANES")) L = atoi(s);
-  if (!(W == 1 || W == 2 || W == 4 || W == 8) || !(L == 32 || L == 16 || L == 8)) {
-    h->err = "MAPDN_NR_WAVES must be 1/2/4/8 and MAPDN_NR_LANES 32/16/8"; return MAPDN_E_INVALID; }
-  if (P.n + 1 > 0xffff) { h->err = "networks with more than 65534 buses are not supported (16-bit node positions in the NR step records)"; return MAPDN_E_INVALID; }
-  const int Wt = W * (64 / L);
-  // Optional LDS residents, in order of benefit: the h factors, the step records, the flat-start constants, the net.line
-  // constants of the fused res_line epilogue, then the G factors (with everything resident the solve state never leaves
-  // the chip; what does not fit stays in / goes to L2-resident global memory).  In lean mode (big batches, see
-  // choose_nr_geometry) only the voltages and hand-off slots are resident, so that several workgroups share a CU.
-  // The kernel peels the first rows of its full sweeps (their G — and h, when h is not in LDS — stay in registers): a schedule
-  // shorter than that is rebuilt with idle rows appended; one that needs no peeled rows (G in LDS) is left alone.
-  const size_t LDS_MAX = 160 * 1024;
-  auto opt = [&](const char* name, int dflt) { const char* s = getenv(name); return s ? (atoi(s) ? 1 : 0) : dflt; };
-  int h_lds = 0, rec_lds = 0, flat_lds = 0, line_lds = 0, g_lds = 0, ncl = 0, R_ = 0, min_rows = 0;
-  size_t lds_need = 0;
-  for (int pass = 0; pass < 4; ++pass) {
-    build_schedule(P, Wt, h->sched, nr_min_cslots(W, L), 64 / L, min_rows);
-    if (h->sched.n_cslots > 1023 || h->sched.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
-    ncl = (int)h->sched.clist.size();
-    if (ncl > 4095) { h->err = "NR schedule: more than 4095 overflow children (junctions with > 3 non-chain children)"; return MAPDN_E_INVALID; }
-    R_ = h->sched.R;
-    auto lds_for = [&](int hl, int gl, int ll, int rl, int fl) {
-      return nr_lds_bytes(W, L, P.n, h->sched.n_cslots, h->sched.n_xslots, ncl, hl, gl, ll ? P.n_line : 0, rl ? R_ : 0, fl ? R_ : 0); };
-    h_lds = opt("MAPDN_NR_H_LDS", !lean && lds_for(1, 0, 0, 0, 0) <= LDS_MAX);
-    rec_lds = opt("MAPDN_NR_REC_LDS", !lean && lds_for(h_lds, 0, 0, 1, 0) <= LDS_MAX);
-    flat_lds = opt("MAPDN_NR_FLAT_LDS", !lean && lds_for(h_lds, 0, 0, rec_lds, 1) <= LDS_MAX);
-    line_lds = opt("MAPDN_NR_LINE_LDS", !lean && P.n_line > 0 && lds_for(h_lds, 0, 1, rec_lds, flat_lds) <= LDS_MAX) && P.n_line > 0;
-    g_lds = opt("MAPDN_NR_G_LDS", !lean && h_lds && lds_for(1, 1, line_lds, rec_lds, flat_lds) <= LDS_MAX) && h_lds;
-    lds_need = lds_for(h_lds, g_lds, line_lds, rec_lds, flat_lds);
-    if (lds_need > LDS_MAX) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
-    const int need = g_lds ? 0 : (h_lds ? NR_G_REG_ROWS : NR_HG_REG_ROWS);
-    if (R_ >= need) { min_rows = -1; break; }
-    min_rows = need;
-  }
-  if (min_rows >= 0) { h->err = "NR schedule: could not settle the number of peeled rows"; return MAPDN_E_INVALID; }
-  d.nr_waves = W; d.nr_lanes = L; d.nr_h_lds = h_lds; d.nr_g_lds = g_lds; d.nr_line_lds = line_lds; d.nr_rec_lds = rec_lds; d.nr_flat_lds = flat_lds;
-  h->lds_bytes = lds_need;
-  if (getenv("MAPDN_DEBUG_GEOMETRY"))
-    fprintf(stderr, "[mapdn] k_nr_tree geometry: W %d L %d lean %d rows %d cslots %d | LDS: h %d rec %d flat %d line %d G %d = %zu B\n",
-            W, L, lean, R_, h->sched.n_cslots, h_lds, rec_lds, flat_lds, line_lds, g_lds, lds_need);
+  const mapdn_handle::Geo& G_ = h->geo;
+  const int ncl = G_.ncl, h_lds = G_.h_lds, g_lds = G_.g_lds;
+  d.nr_waves = G_.W; d.nr_lanes = G_.L; d.nr_h_lds = G_.h_lds; d.nr_g_lds = G_.g_lds; d.nr_line_lds = G_.line_lds; d.nr_rec_lds = G_.rec_lds; d.nr_flat_lds = G_.flat_lds;
   // 1e-7: with quadratic convergence the mismatch after such a step is ~|Y| dx^2 << tol, so a wrong prediction
   // (which costs one extra mismatch-only sweep for that workgroup) practically never happens
-  d.nr_check_dx = 1e-7;
-  if (const char* s = getenv("MAPDN_NR_CHECK_DX")) d.nr_check_dx = atof(s);
+  d.nr_check_dx = knob_f64(cfg->nr_check_dx, "MAPDN_NR_CHECK_DX", 1e-7);
   // quadratic extrapolation of the mismatch norm, no safety margin: in 4096-env samples of all three cases it
   // predicts the last sweep of 95-100 % of the workgroups and never a non-final one (tools/predictor_study.py)
-  d.nr_check_quad = 1.0;
-  if (const char* s = getenv("MAPDN_NR_CHECK_QUAD")) d.nr_check_quad = atof(s);
+  d.nr_check_quad = knob_f64(cfg->nr_check_quad, "MAPDN_NR_CHECK_QUAD", 1.0);
   d.nr_rows = h->sched.R; d.nr_cslots = h->sched.n_cslots; d.nr_xslots = h->sched.n_xslots; d.nr_nclist = ncl;
   {
     // the attribute is per kernel function, not per handle: always raise it to the full 160 KB so that
     // handles with different LDS needs can share an instantiation
-    const int lr = nr_set_lds_limit(W, L, h_lds, g_lds, LDS_MAX);
-    if (lr == -2) { h->err = "this (MAPDN_NR_WAVES, MAPDN_NR_LANES) combination is not compiled in"; return MAPDN_E_INVALID; }
-    if (lr != 0) { h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return MAPDN_E_HIP; }
+    const int lr = nr_set_lds_limit(G_.W, G_.L, G_.h_lds, G_.g_lds, G_.rec_lds, G_.flat_lds, 160 * 1024);
+    if (lr == -2) { h->err = "this (nr_waves, nr_lanes) combination is not compiled in (csrc/nr_inst_list.hpp)"; return MAPDN_E_INVALID; }
+    if (lr != 0) { (void)hipGetLastError(); h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return MAPDN_E_HIP; }
   }
   UP(sched, h->sched.steps); d.sched_bytes = (uint32_t)(h->sched.steps.size() * sizeof(StepRec));
   UP(clist, h->sched.clist);
   UP(mm_ptr, h->sched.mm_ptr); UP(mm_child, h->sched.mm_child);
   UP(mm_recs, h->sched.mm_recs); d.mm_recs_bytes = (uint32_t)(h->sched.mm_recs.size() * sizeof(StepRec)); d.mm_np = h->sched.mm_np;
-  if (h->sched.R * Wt > 0xffff) { h->err = "NR schedule has more than 65535 steps"; return MAPDN_E_INVALID; }
-  // the predicted-final mismatch evaluation as a barrier-free pass over all nodes instead of a tree sweep (needs the h array in LDS)
-  d.nr_mm_pass = h_lds ? 1 : 0;
-  if (const char* s_ = getenv("MAPDN_NR_MM_PASS")) d.nr_mm_pass = (atoi(s_) != 0 && h_lds) ? 1 : 0;
+  d.nr_mm_pass = G_.mm_pass;   // the predicted-final mismatch evaluation as a barrier-free pass over all nodes instead of a tree sweep
   UP(flat, h->sched.flat); d.flat_bytes = (uint32_t)(h->sched.flat.size() * sizeof(double));
   {  // NR scratch: factor blocks (one per node) | 2 x Sbus (one entry per node) | Vout
     const size_t nblk = (size_t)P.n + 2;           // Sbus by node position (+ slack, + the trash node of idle steps: stays 0)
@@ -697,6 +777,16 @@ int mapdn_get_obs_index(const mapdn_handle* h, int32_t* kind, int32_t* index) {
   if (!h || !kind || !index) return MAPDN_E_INVALID;
   std::memcpy(kind, h->plan.obs_kind.data(), h->plan.obs_kind.size() * sizeof(int32_t));
   std::memcpy(index, h->plan.obs_idx.data(), h->plan.obs_idx.size() * sizeof(int32_t));
+  return MAPDN_OK;
+}
+
+int mapdn_get_nr_geometry(const mapdn_handle* h, int32_t* out) {
+  if (!h || !out) return MAPDN_E_INVALID;
+  const mapdn_handle::Geo& g = h->geo;
+  const int32_t v[16] = {h->solver, g.W, g.L, g.lean, g.rows, g.h_lds, g.g_lds, g.rec_lds, g.flat_lds, g.line_lds, g.mm_pass,
+                         (int32_t)h->lds_bytes, (int32_t)g.wgs, g.resident, g.rounds, (int32_t)std::min(g.model_ns, 2.0e9)};
+  std::memcpy(out, v, sizeof(v));
+  if (h->solver == 1) out[2] = h->sp_lanes;
   return MAPDN_OK;
 }
 

@@ -91,7 +91,8 @@ void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const
 // step()/reset() form of the injection: PV buses only (the rest of Sbus is kept up to date by k_advance)
 void launch_inject_sgen(const Dev& d, int mode, const void* actions, int dtype, int add_noise, hipStream_t st);
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
-int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, size_t bytes);   // -2: (waves, lanes) not instantiated
+int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds, size_t bytes);   // -2: geometry not instantiated
+int nr_geometry_compiled(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds);
 // dynamic LDS of k_nr_tree (W waves, L envs per workgroup => Wt = W*64/L workers), in pair rows of L x 16 bytes:
 // node voltages (n+2: nodes, slack, trash), h (n+2) and G (2(n+2)) when resident, contribution slots (4 rows each),
 // x slots (1 row each); then verdict bytes, step-size partials (64*W doubles), overflow child list (padded to

@@ -68,7 +68,10 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
 
   P.nb = nb; P.n = nb - 1; P.nl = net.n_load; P.ns = net.n_sgen; P.n_line = net.n_line;
   P.root_bus = net.ext_grid_bus; P.vroot = net.ext_grid_vm_pu; P.sn_mva = net.sn_mva;
-  P.tol = 1e-8 / net.sn_mva;   // runpp tolerance_mva=1e-8 on a per-unit mismatch
+  // runpp(tolerance_mva = 1e-8) on a per-unit mismatch: ||F||inf < tolerance_mva / sn_mva as restated from pandapower 2.7.0 (UNPINNED,
+  // see mapdn_env_config.tolerance_is_pu: 1 takes tolerance_mva as the per-unit bound without the division)
+  if (cfg.tolerance_mva < 0.0) { err = "tolerance_mva must be > 0 (0 = the runpp default 1e-8)"; return MAPDN_E_INVALID; }
+  P.tol = (cfg.tolerance_mva > 0.0 ? cfg.tolerance_mva : 1e-8) / (cfg.tolerance_is_pu ? 1.0 : net.sn_mva);
 
   // ---- Ybus (dense on the host; nb <= a few hundred) -------------------------------------------
   P.ybus.assign((size_t)nb * nb, cplx(0, 0));

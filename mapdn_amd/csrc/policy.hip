@@ -115,48 +115,50 @@ k_policy_fwd(const float* __restrict__ obs, const float* __restrict__ hid_in, co
       for (int r = 0; r < 4; ++r) { const float o = fmaf((acc[nt][r] - mean[r]) * rstd[r], sG[u], sB[u]); xt[(4 * g + r) * 68 + u] = o > 0.0f ? o : (o != o ? o : 0.0f); }   // ReLU, NaN kept (as torch.relu)
     }
     // (one wavefront: its LDS writes are visible to its later reads, no barrier)
-    // ---- GRUCell pre-activations: r, z over [x | h] (K = 128), i_n over x, h_n over h
-    f4 aR[4], aZ[4], aIN[4], aHN[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { aR[nt] = f4{0, 0, 0, 0}; aZ[nt] = f4{0, 0, 0, 0}; aIN[nt] = f4{0, 0, 0, 0}; aHN[nt] = f4{0, 0, 0, 0}; }
+    // ---- GRUCell pre-activations: r, z over [x | h] (K = 128), i_n over x, h_n over h — one 16-unit output tile at a time, so that
+    // four accumulator tiles are live instead of sixteen (with 512 threads a wave has 256 registers: the sixteen-tile form spilled
+    // 24 of them to scratch); the activations of the tile's 16 rows (A operands) are loaded once
+    f4 ax[4], ah[4];
     const float* hrow = hid_in + (size_t)arow * PH;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const f4 ax = *(const f4*)(xt + j * 68 + 16 * c + 4 * g);
-      const f4 ah = *(const f4*)(hrow + 16 * c + 4 * g);
+    for (int c = 0; c < 4; ++c) { ax[c] = *(const f4*)(xt + j * 68 + 16 * c + 4 * g); ah[c] = *(const f4*)(hrow + 16 * c + 4 * g); }
+    float outp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < 4; ++nt) {
+      f4 aR = f4{0, 0, 0, 0}, aZ = f4{0, 0, 0, 0}, aIN = f4{0, 0, 0, 0}, aHN = f4{0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
         const f4 wir = sWih[(size_t)(nt * 4 + c) * 64 + lane], whr = sWhh[(size_t)(nt * 4 + c) * 64 + lane];
         const f4 wiz = sWih[(size_t)((4 + nt) * 4 + c) * 64 + lane], whz = sWhh[(size_t)((4 + nt) * 4 + c) * 64 + lane];
         const f4 win = sWih[(size_t)((8 + nt) * 4 + c) * 64 + lane], whn = sWhh[(size_t)((8 + nt) * 4 + c) * 64 + lane];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          aR[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[q], wir[q], aR[nt], 0, 0, 0);
-          aZ[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[q], wiz[q], aZ[nt], 0, 0, 0);
-          aIN[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[q], win[q], aIN[nt], 0, 0, 0);
-          aR[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[q], whr[q], aR[nt], 0, 0, 0);
-          aZ[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[q], whz[q], aZ[nt], 0, 0, 0);
-          aHN[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[q], whn[q], aHN[nt], 0, 0, 0);
+          aR = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[c][q], wir[q], aR, 0, 0, 0);
+          aZ = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[c][q], wiz[q], aZ, 0, 0, 0);
+          aIN = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[c][q], win[q], aIN, 0, 0, 0);
+          aR = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[c][q], whr[q], aR, 0, 0, 0);
+          aZ = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[c][q], whz[q], aZ, 0, 0, 0);
+          aHN = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[c][q], whn[q], aHN, 0, 0, 0);
         }
       }
-    }
-    // ---- gates (torch.nn.GRUCell), new hidden state, fc2
-    float outp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      // ---- gates (torch.nn.GRUCell), new hidden state, this tile's share of fc2; C layout: reg r <-> row 4 g + r, column j
+      const int u = 16 * nt + j;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + 4 * g + r;
-      const int rc = min(row, rows - 1);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int u = 16 * nt + j;
-        const float rg = sigmoidf_(aR[nt][r] + sBih[u] + sBhh[u]);
-        const float zg = sigmoidf_(aZ[nt][r] + sBih[PH + u] + sBhh[PH + u]);
-        const float nn = tanhf(fmaf(rg, aHN[nt][r] + sBhh[2 * PH + u], aIN[nt][r] + sBih[2 * PH + u]));
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + 4 * g + r;
+        const int rc = min(row, rows - 1);
+        const float rg = sigmoidf_(aR[r] + sBih[u] + sBhh[u]);
+        const float zg = sigmoidf_(aZ[r] + sBih[PH + u] + sBhh[PH + u]);
+        const float nn = tanhf(fmaf(rg, aHN[r] + sBhh[2 * PH + u], aIN[r] + sBih[2 * PH + u]));
         const float hu = hid_in[(size_t)rc * PH + u];
         const float hnew = fmaf(zg, hu - nn, nn);                 // (1 - z) n + z h
         if (row < rows) hid_out[(size_t)row * PH + u] = hnew;
         outp[r] = fmaf(sW2[u], hnew, outp[r]);
       }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r;
       const float tot = row_sum16(outp[r]);
       if (j == 0 && row < rows) means[row] = tot + bias2;
     }

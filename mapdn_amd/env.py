@@ -69,7 +69,7 @@ class VoltageControlBatch:
 
     def __init__(self, net: NetSpec, profiles: Profiles, args=None, n_envs: int = 1, device=None,
                  env_id_offset: int = 0, max_reset_tries: int = 3, copy: bool = False,
-                 obs_dtype=torch.float32):
+                 obs_dtype=torch.float32, tuning: dict | None = None):
         a = dict(DEFAULT_ARGS)
         a.update(_as_dict(args or {}))
         if a["mode"] != "distributed":
@@ -93,7 +93,7 @@ class VoltageControlBatch:
         self.action_space = ActionSpace(low=-a["action_scale"] + a["action_bias"], high=a["action_scale"] + a["action_bias"])
         self._lib = _lib.load()
         cnet, self._keep = _lib.make_cnetspec(net)
-        ccfg = _lib.make_cconfig(a, env_id_offset)
+        ccfg = _lib.make_cconfig(a, env_id_offset, tuning)     # tuning: per-handle launch / solver fields of mapdn_env_config
         h = _lib.C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.check(self._lib.mapdn_create(_lib.C.byref(cnet), _lib.C.byref(ccfg), self.n_envs, dev_index, _lib.C.byref(h)))
@@ -351,6 +351,10 @@ class VoltageControlBatch:
         idx = np.zeros(n, np.int32)
         _lib.check(self._lib.mapdn_get_obs_index(self._h, _lib._p(kind, _lib._pi), _lib._p(idx, _lib._pi)), self._h)
         return kind.reshape(self.n_agents, -1), idx.reshape(self.n_agents, -1)
+
+    def geometry(self):
+        """the NR launch geometry mapdn_create settled on (solver, waves, envs per workgroup, LDS residency, rows, model time)"""
+        return _lib.nr_geometry(self._h)
 
     def stats(self):
         rf, mi, mx = _lib.C.c_int64(), _lib.C.c_double(), _lib.C.c_int32()

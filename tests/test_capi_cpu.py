@@ -248,3 +248,93 @@ def test_header_is_plain_c_and_usable_from_a_c_host(lib, tmp_path):
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "n_bus 5" in out and "radial 1" in out and "n_agents 2" in out
     assert "mapdn_reset on a host-only handle -> -4" in out
+
+
+def _geometry(lib, net, B, tuning=None):
+    cn, keep = _lib.make_cnetspec(net)
+    cc = _lib.make_cconfig(ARGS, 0, tuning)
+    h = C.c_void_p()
+    rc = lib.mapdn_create(C.byref(cn), C.byref(cc), B, -1, C.byref(h))
+    if rc:
+        return rc, lib.mapdn_last_error(None).decode()
+    g = _lib.nr_geometry(h)
+    lib.mapdn_destroy(h)
+    return 0, g
+
+
+@pytest.mark.parametrize("case,B,want", [
+    # the measured-best launch of every BASELINE size (profiles/r02_nr_geometry_case141.txt, profiles/r03_geometry_case322.txt):
+    # (waves, envs per workgroup, lean, h in LDS)
+    ("case33", 4096, (1, 16, 0, 1)), ("case141", 1, (4, 16, 0, 1)), ("case141", 4096, (4, 16, 0, 1)), ("case141", 8192, (2, 16, 1, 0)),
+    ("case141_deep", 4096, (4, 16, 0, 1)), ("case322", 1024, (4, 8, 0, 1)), ("case322", 4096, (4, 16, 0, 0)), ("case322", 8192, (4, 16, 0, 0)),
+])
+def test_nr_geometry_model_reproduces_the_measured_defaults(lib, case, B, want):
+    """The chooser is a launch-time model over the compiled (waves, lanes, lean) candidates (capi.hip::nr_model_ns, fitted by
+    tools/nr_geometry_fit.py), no longer two thresholds on n: at the shapes that were swept on hardware it must pick what
+    the sweeps found fastest — for host-only handles too (they assume the MI355X's 256 CUs)."""
+    net, _ = make_case(case)
+    rc, g = _geometry(lib, net, B)
+    assert rc == 0, g
+    assert (g["waves"], g["lanes"], g["lean"], g["h_lds"]) == want, g
+    assert g["solver"] == 0 and g["lds_bytes"] <= 160 * 1024 and g["model_ns"] > 0
+    assert g["workgroups"] == (B + 63) // 64 * 64 // g["lanes"]
+
+
+def test_nr_geometry_for_feeders_nobody_tuned(lib):
+    """a 69-bus feeder (Baran & Wu) and a ~200-bus random feeder get a geometry from the same model, without environment
+    variables: more than one worker per env, everything the solve touches in LDS at a small batch, a layout with more envs per
+    CU once the batch needs several rounds of workgroups; pinned fields are honoured; an uncompiled pair is refused loudly"""
+    from tests.golden.literature_cases import bw69
+    from mapdn_amd.netspec import _radial_case
+    net69 = bw69()[0]
+    rc, g = _geometry(lib, net69, 4096)
+    assert rc == 0, g
+    assert g["waves"] * 64 // g["lanes"] >= 4 and g["h_lds"] == 1 and g["rounds"] == 1, g
+    net200, _ = _radial_case("rand200", 201, 120, 20, 10, 21, 12.47, 10.0, 10.0, 5, 0.05)
+    rc, small = _geometry(lib, net200, 1024)
+    assert rc == 0 and small["h_lds"] == 1 and small["rounds"] == 1 and small["waves"] == 4, small
+    rc, big = _geometry(lib, net200, 16384)
+    assert rc == 0 and big["workgroups"] / big["resident_per_cu"] <= small["workgroups"] * 16 / small["resident_per_cu"], big
+    assert big["rounds"] * big["lanes"] * big["resident_per_cu"] * 256 >= 16384
+    # the model's estimate grows with the batch once the chip is full and is not below the one-round time
+    assert big["model_ns"] > small["model_ns"]
+    rc, g = _geometry(lib, net200, 1024, dict(nr_waves=2, nr_lanes=16, nr_lean=1))
+    assert rc == 0 and (g["waves"], g["lanes"], g["lean"], g["h_lds"], g["model_ns"]) == (2, 16, 1, 0, 0), g
+    rc, g = _geometry(lib, net200, 1024, dict(nr_h_lds=2))
+    assert rc == 0 and g["h_lds"] == 0 and g["mm_pass"] == 0, g
+    rc, msg = _geometry(lib, net200, 1024, dict(nr_waves=8, nr_lanes=16, nr_lean=1))
+    assert rc == -1 and "not compiled in" in msg
+    rc, msg = _geometry(lib, net200, 1024, dict(nr_waves=3))
+    assert rc == -1 and "nr_waves" in msg
+
+
+def test_env_config_layout_matches_the_header(lib, tmp_path):
+    """ctypes mirror of mapdn_env_config == the C struct (size and the offset of every appended tuning field)"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    fields = [f[0] for f in _lib.CEnvConfig._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mapdn.h"\nint main(void) {\n'
+                   '  printf("%zu\\n", sizeof(mapdn_env_config));\n'
+                   + "".join(f'  printf("{f} %zu\\n", offsetof(mapdn_env_config, {f}));\n' for f in fields)
+                   + "  return 0;\n}\n")
+    exe = str(tmp_path / "layout")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
+    assert int(out[0]) == C.sizeof(_lib.CEnvConfig)
+    for line in out[1:]:
+        if line:
+            name, off = line.split()
+            assert getattr(_lib.CEnvConfig, name).offset == int(off), name
+
+
+def test_tolerance_options(lib):
+    """mapdn_env_config.tolerance_mva / tolerance_is_pu: the stopping rule is tolerance_mva / sn_mva per unit by default (the rule
+    as restated from pandapower, unpinned) or tolerance_mva itself; visible through the plan on a net with sn_mva != 1"""
+    net, _ = make_case("case141")                       # sn_mva = 10
+    assert net.sn_mva == 10.0
+    for tuning, ok in ((None, True), (dict(tolerance_is_pu=1), True), (dict(tolerance_mva=1e-6), True), (dict(tolerance_mva=-1.0), False)):
+        rc, g = _geometry(lib, net, 64, tuning)
+        assert (rc == 0) == ok, g

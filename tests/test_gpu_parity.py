@@ -23,9 +23,9 @@ def args_for(case, **kw):
     return a
 
 
-def make(case, B, **kw):
+def make(case, B, tuning=None, **kw):
     net, prof = make_case(case)
-    env = VoltageControlBatch(net, prof, args_for(case, **kw), n_envs=B, device="cuda:0", obs_dtype=torch.float64)
+    env = VoltageControlBatch(net, prof, args_for(case, **kw), n_envs=B, device="cuda:0", obs_dtype=torch.float64, tuning=tuning)
     return net, prof, env
 
 
@@ -665,8 +665,8 @@ def test_end_to_end_ddpg_training_on_device(tmp_path):
         env.close()
 
 
-@pytest.mark.parametrize("check_dx", ["1e30", "0"])
-def test_convergence_prediction_is_only_a_shortcut(check_dx, monkeypatch):
+@pytest.mark.parametrize("check_dx", [1e30, 1e-300])
+def test_convergence_prediction_is_only_a_shortcut(check_dx):
     """The NR kernel runs a forward sweep mismatch-only when it predicts convergence and redoes it in full
     when the prediction was wrong.  Forcing the prediction to 'always' (every sweep after the first is tried
     mismatch-only and redone) and to 'never' must give the same iterations and bit-identical voltages."""
@@ -681,9 +681,9 @@ def test_convergence_prediction_is_only_a_shortcut(check_dx, monkeypatch):
     ref_env = VoltageControlBatch(net, prof, args_for(case), n_envs=B, device="cuda:0")
     vm0, va0, it0, cv0 = [x.cpu().numpy() for x in ref_env.solve(pl, ql, pv, qs)]
     ref_env.close()
-    monkeypatch.setenv("MAPDN_NR_CHECK_DX", check_dx)
-    monkeypatch.setenv("MAPDN_NR_CHECK_QUAD", "1e-300" if check_dx == "1e30" else "inf")   # always / never for the second predictor too
-    env = VoltageControlBatch(net, prof, args_for(case), n_envs=B, device="cuda:0")
+    # always / never, for the second predictor too (mapdn_env_config.nr_check_dx / nr_check_quad; 0 would mean "default")
+    tuning = dict(nr_check_dx=check_dx, nr_check_quad=1e-300 if check_dx == 1e30 else float("inf"))
+    env = VoltageControlBatch(net, prof, args_for(case), n_envs=B, device="cuda:0", tuning=tuning)
     vm, va, it, cv = [x.cpu().numpy() for x in env.solve(pl, ql, pv, qs)]
     env.close()
     assert np.array_equal(it, it0) and np.array_equal(cv, cv0) and not cv[7] and it[7] == 10
@@ -861,15 +861,15 @@ def test_fused_step_obs_equals_step_then_get_obs(case, obs_dtype):
 
 
 @pytest.mark.parametrize("case,geoms", [
-    ("case141", [("4", "16", None), ("2", "16", "1"), ("2", "16", "0"), ("1", "8", "1"), ("4", "8", None), ("8", "16", "1"), ("1", "32", "1"), ("2", "32", "1")]),
-    ("case33", [("1", "16", None), ("2", "16", None), ("1", "8", None), ("4", "32", None)]),
-    ("case322", [("4", "8", None), ("2", "8", "1"), ("4", "16", "1")]),
+    ("case141", [(4, 16, 0), (2, 16, 1), (2, 16, 2), (1, 8, 1), (4, 8, 0), (1, 32, 1), (2, 8, 2), (1, 16, 2), (4, 16, 1)]),
+    ("case33", [(1, 16, 0), (2, 16, 0), (1, 8, 0), (4, 16, 0), (2, 8, 1)]),
+    ("case322", [(4, 8, 0), (2, 8, 1), (4, 16, 1), (4, 16, 2), (2, 16, 1)]),
 ])
-def test_every_nr_launch_geometry_gives_the_same_bits(case, geoms, monkeypatch):
-    """MAPDN_NR_WAVES / MAPDN_NR_LANES / MAPDN_NR_LEAN overrides: every (waves, envs per workgroup, LDS residency) variant
-    of k_nr_tree — the specialised default instantiations, the generic ones, both per-env reduction paths (row swaps at 16
-    envs per workgroup, LDS elsewhere) — sums the children in the same canonical order, so voltages, angles and iteration
-    counts are bit-identical"""
+def test_every_nr_launch_geometry_gives_the_same_bits(case, geoms):
+    """mapdn_env_config.nr_waves / nr_lanes / nr_lean (0 auto, 1 lean, 2 fat): every (waves, envs per workgroup, LDS residency)
+    variant of k_nr_tree — the specialised default instantiations, the generic ones, both per-env reduction paths (row swaps at
+    16 envs per workgroup, LDS elsewhere) — sums the children in the same canonical order, so voltages, angles and iteration
+    counts are bit-identical.  The handles differ per `tuning`, not per process: the reference handle stays alive throughout."""
     B = 200
     net, prof = make_case(case)
     rng = np.random.default_rng(11)
@@ -877,40 +877,64 @@ def test_every_nr_launch_geometry_gives_the_same_bits(case, geoms, monkeypatch):
     pv = prof.pv[rows]
     qs = rng.uniform(-SCALE[case], SCALE[case], (B, net.n_sgen)) * np.sqrt(prof.s_max() ** 2 - pv ** 2)
     ins = (prof.load_p[rows], prof.load_q[rows], pv, qs)
-    ref = None
+    ref, ref_env, seen = None, None, set()
     for w, l, lean in geoms:
-        monkeypatch.setenv("MAPDN_NR_WAVES", w); monkeypatch.setenv("MAPDN_NR_LANES", l)
-        if lean is None:
-            monkeypatch.delenv("MAPDN_NR_LEAN", raising=False)
-        else:
-            monkeypatch.setenv("MAPDN_NR_LEAN", lean)
         try:
-            env = VoltageControlBatch(net, prof, args_for(case), n_envs=B, device="cuda:0")
+            env = VoltageControlBatch(net, prof, args_for(case), n_envs=B, device="cuda:0", tuning=dict(nr_waves=w, nr_lanes=l, nr_lean=lean))
         except Exception as exc:                              # a geometry whose LDS need exceeds a CU is refused, not wrong
             assert "LDS" in str(exc), exc
             continue
+        g = env.geometry()
+        assert (g["waves"], g["lanes"]) == (w, l) and (lean == 0 or g["lean"] == (lean == 1))
+        seen.add((g["waves"], g["lanes"], g["h_lds"], g["g_lds"], g["rec_lds"], g["flat_lds"]))
         out = [t.cpu().numpy() for t in env.solve(*ins)]
-        env.close()
         assert out[3].all()
         if ref is None:
-            ref = out
+            ref, ref_env = out, env                           # two live handles with different geometries from here on
         else:
             assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1]) and np.array_equal(out[2], ref[2]), (w, l, lean)
-    assert ref is not None
+            again = [t.cpu().numpy() for t in ref_env.solve(*ins)]      # ... and the first handle is unaffected by the others
+            assert all(np.array_equal(a, b) for a, b in zip(again, ref))
+            env.close()
+    ref_env.close()
+    assert len(seen) >= 3
+
+
+def test_two_handles_with_different_tuning_in_one_process(monkeypatch):
+    """the launch knobs are fields of mapdn_env_config, not process-global getenv reads.  Two handles on the same
+    net with different geometry, injection kernel and mismatch-evaluation form step side by side — interleaved calls — and
+    stay bit-identical; an environment variable still overrides the field (tools), read once at mapdn_create."""
+    case, B = "case141", 96
+    net, prof, a = make(case, B, tuning=dict(nr_waves=4, nr_lanes=16), episode_limit=6, auto_reset=True)
+    _, _, b = make(case, B, tuning=dict(nr_waves=2, nr_lanes=16, nr_lean=1, inject_full=1, nr_mm_pass=2), episode_limit=6, auto_reset=True)
+    ga, gb = a.geometry(), b.geometry()
+    assert (ga["waves"], ga["lean"], ga["h_lds"], ga["mm_pass"]) == (4, 0, 1, 1) and (gb["waves"], gb["lean"], gb["h_lds"], gb["mm_pass"]) == (2, 1, 0, 0)
+    oa, _ = a.reset(); ob, _ = b.reset()
+    assert torch.equal(oa, ob)
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(5)
+    for t in range(9):
+        act = (torch.rand(B, net.n_sgen, device="cuda:0", generator=gen, dtype=torch.float64) * 2 - 1) * SCALE[case]
+        ra, ta, ia = a.step(act); rb, tb, ib = b.step(act)
+        assert torch.equal(ta, tb) and torch.equal(a.get_obs(), b.get_obs())
+        assert torch.allclose(ra, rb, rtol=0, atol=1e-12) and torch.allclose(ia, ib, rtol=0, atol=1e-12)
+    a.close(); b.close()
+    monkeypatch.setenv("MAPDN_NR_WAVES", "2"); monkeypatch.setenv("MAPDN_NR_LANES", "16"); monkeypatch.setenv("MAPDN_NR_LEAN", "0")
+    _, _, c = make(case, B, tuning=dict(nr_waves=4, nr_lanes=16))
+    gc = c.geometry()
+    assert (gc["waves"], gc["lanes"], gc["lean"]) == (2, 16, 0)
+    c.close()
 
 
 @pytest.mark.parametrize("case", ["case33", "case141", "case322"])
-def test_pv_bus_injection_equals_all_bus_injection(case, monkeypatch):
+def test_pv_bus_injection_equals_all_bus_injection(case):
     """step() / reset() inject through k_inject_sgen — PV buses only, k_advance keeps the Sbus entries of all other buses and
-    the load part of the PV buses current — while MAPDN_INJECT_FULL=1 keeps the all-bus k_inject of round 2.  Same expressions,
+    the load part of the PV buses current — while mapdn_env_config.inject_full = 1 keeps the all-bus k_inject of round 2.  Same expressions,
     same order: bit-identical over noisy episodes with an unsolvable step, per-env auto-reset boundaries (an auto-resetting env
     refreshes all its loads inside k_inject_sgen) and a mapdn_solve_only call in between (which leaves Sbus stale)."""
     B, limit = 70, 5
     kw = dict(episode_limit=limit, auto_reset=True)
     net, prof, fast = make(case, B, **kw)
-    monkeypatch.setenv("MAPDN_INJECT_FULL", "1")
-    _, _, full = make(case, B, **kw)
-    monkeypatch.delenv("MAPDN_INJECT_FULL")
+    _, _, full = make(case, B, tuning=dict(inject_full=1), **kw)
     of, _ = fast.reset(); ou, _ = full.reset()
     assert torch.equal(of, ou)
     gen = torch.Generator(device="cuda:0"); gen.manual_seed(23)
@@ -940,9 +964,9 @@ def test_pv_bus_injection_equals_all_bus_injection(case, monkeypatch):
 
 
 @pytest.mark.parametrize("case", ["case33", "case141", "case322"])
-def test_mismatch_pass_equals_mismatch_sweep(case, monkeypatch):
+def test_mismatch_pass_equals_mismatch_sweep(case):
     """The predicted-final mismatch evaluation runs as a barrier-free pass over all nodes (k_nr_tree::mismatch_pass, the default
-    when the h array is LDS-resident) instead of a mismatch-only tree sweep (MAPDN_NR_MM_PASS=0): same expressions summed in the
+    when the h array is LDS-resident) instead of a mismatch-only tree sweep (nr_mm_pass = 2): same expressions summed in the
     same canonical order, so iterations, flags and voltages are bit-identical — also with the predictor forced to 'always',
     where every verdict after the first comes from the pass and a wrong prediction redoes the sweep in full."""
     B = 96
@@ -954,13 +978,12 @@ def test_mismatch_pass_equals_mismatch_sweep(case, monkeypatch):
     qs = act * np.sqrt(prof.s_max() ** 2 - pv ** 2)
     pl[11] *= 30.0                                   # one env that never converges
     out = {}
-    for tag, mm, always in (("sweep", "0", False), ("pass", "1", False), ("sweep_always", "0", True), ("pass_always", "1", True)):
-        monkeypatch.setenv("MAPDN_NR_MM_PASS", mm)
+    for tag, mm, always in (("sweep", 2, False), ("pass", 1, False), ("sweep_always", 2, True), ("pass_always", 1, True)):
+        tuning = dict(nr_mm_pass=mm)                       # mapdn_env_config.nr_mm_pass: 1 pass, 2 tree sweep
         if always:
-            monkeypatch.setenv("MAPDN_NR_CHECK_DX", "1e30"); monkeypatch.setenv("MAPDN_NR_CHECK_QUAD", "1e-300")
-        else:
-            monkeypatch.delenv("MAPDN_NR_CHECK_DX", raising=False); monkeypatch.delenv("MAPDN_NR_CHECK_QUAD", raising=False)
-        env = VoltageControlBatch(net, prof, args_for(case), n_envs=B, device="cuda:0")
+            tuning.update(nr_check_dx=1e30, nr_check_quad=1e-300)
+        env = VoltageControlBatch(net, prof, args_for(case), n_envs=B, device="cuda:0", tuning=tuning)
+        assert env.geometry()["mm_pass"] == (1 if mm == 1 else 0)
         out[tag] = [x.cpu().numpy() for x in env.solve(pl, ql, pv, qs)]
         env.close()
     vm0, va0, it0, cv0 = out["sweep"]

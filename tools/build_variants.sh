@@ -2,8 +2,6 @@
 # debug: build timing-experiment variants of the library side by side (mapdn_amd/lib_x<N>.so), selected with MAPDN_LIB_PATH
 cd "$(dirname "$0")/.."
 for x in "$@"; do
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result -DMAPDN_NR_STAMPS -DMAPDN_EXP=$x \
-      -o mapdn_amd/lib_x$x.so mapdn_amd/csrc/plan.cpp mapdn_amd/csrc/kernels.hip mapdn_amd/csrc/dense.hip mapdn_amd/csrc/sparse.hip mapdn_amd/csrc/policy.hip mapdn_amd/csrc/capi.hip 2>&1 | grep -E "error" ) &
+  MAPDN_BUILD_OUT=$PWD/mapdn_amd/lib_x$x.so MAPDN_EXTRA_FLAGS="-DMAPDN_NR_STAMPS -DMAPDN_EXP=$x" python -m mapdn_amd.build --force
 done
-wait
 ls -la mapdn_amd/lib_x*.so
