@@ -165,6 +165,14 @@ typedef struct mapdn_env_config {
                                        flat-start solve when it has not converged after 3 iterations; voltages then agree with
                                        the flat-start answer to the solver tolerance (<< 1e-6 p.u.), iteration counts differ.
                                        Radial feeders only (k_nr_tree); reset() and mapdn_solve_only always start flat          */
+  /* ---- composition of the step() launches (same results; A/B switches) */
+  int32_t fuse_inject;              /* step(): 0 auto — the PV-bus injection (_clip_reactive_power, Sbus of the buses with sgens)
+                                       runs inside the prologue of k_nr_tree when the handle uses the tree solver and has no
+                                       auto_reset (one launch less per step); 1 same, refused (MAPDN_E_INVALID) when impossible;
+                                       2 always its own launch (k_inject_sgen)                        env: MAPDN_FUSE_INJECT=1/0 */
+  int32_t overlap_advance;          /* step(): 1 — the profile rows of the advance (next row of the tables + noise, independent of
+                                       the solve) run on an internal side stream beside the solver launch, fork / join by events;
+                                       0 (default) everything on the caller's stream.              env: MAPDN_OVERLAP_ADVANCE=1/0 */
 } mapdn_env_config;
 
 typedef struct mapdn_dims_t {

@@ -29,6 +29,9 @@ struct mapdn_handle {
   bool sbus_stale = true;         // Sbus / bus_ld do not reflect cur_pl / cur_ql (fresh handle, after mapdn_solve_only): the next
                                   // injection runs the all-bus kernel; MAPDN_INJECT_FULL=1 keeps it that way (A/B, tests)
   bool inject_full = false;
+  bool fuse_inject = false;       // step(): the PV-bus injection runs in the prologue of k_nr_tree instead of as k_inject_sgen (tree solver, no auto_reset)
+  bool overlap = false;           // step(): the profile rows of k_advance run on a side stream beside the solver launch (experiment)
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint32_t sb_base = 0, sb_bytes = 0;   // the two Sbus buffers of nrbuf: d.sb_off / d.sb_off_alt alternate between them
   std::vector<int32_t> ld_dest_host;
   size_t lds_bytes = 0;
@@ -302,6 +305,19 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     d.n_sgb = (int32_t)sgb.size(); d.n_lb = (int32_t)lb.size(); d.n_mlo = (int32_t)mlo.size();
     if (lb.empty()) lb.push_back(0);
     if (mlo.empty()) mlo.push_back(0);
+    {   // per (PV bus | load-only bus with several loads) row of the injection: what the fused prologue of k_nr_tree needs in one 16-byte load
+      std::vector<int32_t> rec;
+      auto put = [&](int k, bool pv) {
+        const int nsg = pv ? P.sgen_ptr[k + 1] - P.sgen_ptr[k] : 0, nld = P.load_ptr[k + 1] - P.load_ptr[k];
+        rec.push_back(k < P.n ? k : -1);            // Sbus is stored by node position (sb_index[k] == k, see alloc_nrbuf below)
+        rec.push_back(k);
+        rec.push_back(pv ? P.sgen_idx[P.sgen_ptr[k]] : -1);
+        rec.push_back((nsg << 8) | std::min(nld, 2));
+      };
+      for (int i = 0; i < d.n_sgb; ++i) put(sgb[i], true);
+      for (int i = 0; i < d.n_mlo; ++i) put(mlo[i], false);
+      UP(sgb_rec, rec);
+    }
     UP(sgb_pos, sgb); UP(sgb_of_pos, sgb_of); UP(lb_pos, lb); UP(mlo_pos, mlo);
     h->ld_dest_host.assign(std::max(P.nl, 1), 2);             // filled once the Sbus order (sb_index) is known, see alloc_nrbuf
     rc = dalloc(h, &d.bus_ld, (size_t)2 * d.n_sgb * d.Bp); if (rc) return rc;
@@ -493,6 +509,18 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     rc = alloc_nrbuf(fb_rows, nblk, sbi); if (rc) return rc;
   }
 #undef UP
+  {   // composition of the step() launches
+    const int fi = knob_tri(cfg->fuse_inject, "MAPDN_FUSE_INJECT");
+    const bool can = !d.auto_reset && !h->inject_full;
+    if (fi == 1 && !can) { h->err = "fuse_inject = 1 needs a handle without auto_reset and without inject_full"; return MAPDN_E_INVALID; }
+    h->fuse_inject = can && fi != 2;
+    h->overlap = knob_int(cfg->overlap_advance, "MAPDN_OVERLAP_ADVANCE") != 0;
+    if (h->overlap) {
+      HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+  }
   return MAPDN_OK;
 }
 
@@ -510,6 +538,9 @@ void mapdn_destroy(mapdn_handle* h) {
   if (!h) return;
   for (void* p : h->allocs) (void)hipFree(p);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
 }
 
@@ -572,8 +603,9 @@ int mapdn_set_profiles(mapdn_handle* h, const double* pv, const double* load_p, 
   return MAPDN_OK;
 }
 
-static void nr_launch(mapdn_handle* h, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
-  if (!h->timing) { launch_nr(h->d, mode, reward, term, info, st); return; }
+static void nr_launch(mapdn_handle* h, int mode, double* reward, uint8_t* term, double* info, hipStream_t st,
+                      const void* fused_actions = nullptr, int fused_dtype = 0) {
+  if (!h->timing) { launch_nr(h->d, mode, reward, term, info, st, fused_actions, fused_dtype); return; }
   if (h->ev_used + 2 > h->ev.size()) {
     if (h->ev.size() >= 2 * 8192) {   // pool full: drain
       double ms; int64_t n; mapdn_nr_time_ms(h, &ms, &n); h->acc_ms = ms; h->acc_launches = n;
@@ -586,7 +618,7 @@ static void nr_launch(mapdn_handle* h, int mode, double* reward, uint8_t* term, 
   hipEvent_t a = h->ev[h->ev_used], b = h->ev[h->ev_used + 1];
   h->ev_used += 2;
   (void)hipEventRecord(a, st);
-  launch_nr(h->d, mode, reward, term, info, st);
+  launch_nr(h->d, mode, reward, term, info, st, fused_actions, fused_dtype);
   (void)hipEventRecord(b, st);
 }
 
@@ -597,6 +629,31 @@ static void inject_launch(mapdn_handle* h, int mode, const void* actions, int dt
     launch_inject(d, mode, actions, dtype, d.cur_pl, d.cur_ql, d.cur_pv, nullptr, add_noise, st);
     h->sbus_stale = false;
   } else launch_inject_sgen(d, mode, actions, dtype, add_noise, st);
+}
+
+// The launches of one step(): injection (its own launch, or the prologue of k_nr_tree: fuse_inject) -> solve + reward ->
+// profile advance (-> the Sbus buffer of the next solve) + res_bus commit.  With `overlap` the profile rows, which do not
+// depend on the solve, run on the side stream beside the solver launch.
+static int step_launches(mapdn_handle* h, const void* actions, int32_t actions_dtype, int32_t add_noise, double* reward,
+                         uint8_t* terminated, double* info, hipStream_t st) {
+  const Dev& d = h->d;
+  const bool fused = h->fuse_inject && h->solver == 0 && !h->sbus_stale;
+  if (!fused) inject_launch(h, MODE_STEP, actions, actions_dtype, add_noise, st);
+  if (h->overlap && !fused) {
+    // fork after the injection (it queues the row / draw the advance uses), join before the commit rows
+    HIPCHK(h, hipEventRecord(h->ev_fork, st));
+    HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    launch_advance(d, add_noise, 1, 0, d.sb_off_alt, h->side);
+    HIPCHK(h, hipEventRecord(h->ev_join, h->side));
+    nr_launch(h, MODE_STEP, reward, terminated, info, st);
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+    launch_advance(d, 0, 0, 1, d.sb_off_alt, st);
+  } else {
+    nr_launch(h, MODE_STEP, reward, terminated, info, st, fused ? actions : nullptr, actions_dtype);
+    launch_advance(d, add_noise, 1, 1, d.sb_off_alt, st);   // next profile row (-> the Sbus buffer of the next solve) + res_bus commit
+  }
+  std::swap(h->d.sb_off, h->d.sb_off_alt);
+  return MAPDN_OK;
 }
 
 int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, int32_t max_tries, void* stream) {
@@ -629,12 +686,8 @@ int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int3
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   const Dev& d = h->d;
-  inject_launch(h, MODE_STEP, actions, actions_dtype, add_noise, st);
-  // (Running the profile advance on a side stream beside the NR kernel was measured: the fork/join events
-  // cost more than the ~6 us they hide, 29.5 M vs 31.5 M env-steps/s, so the step stays on one stream.)
-  nr_launch(h, MODE_STEP, reward, terminated, info, st);
-  launch_advance(d, add_noise, 1, 1, d.sb_off_alt, st);   // next profile row (-> the Sbus buffer of the next solve) + res_bus commit
-  std::swap(h->d.sb_off, h->d.sb_off_alt);
+  { const int rc = step_launches(h, actions, actions_dtype, add_noise, reward, terminated, info, st); if (rc) return rc; }
+  (void)d;
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
 }
@@ -651,10 +704,7 @@ int mapdn_step_obs(mapdn_handle* h, const void* actions, int32_t actions_dtype, 
   hipStream_t st = (hipStream_t)stream;
   const Dev& d = h->d;
   const int C = h->plan.n_agents * h->plan.obs_size;
-  inject_launch(h, MODE_STEP, actions, actions_dtype, add_noise, st);
-  nr_launch(h, MODE_STEP, reward, terminated, info, st);
-  launch_advance(d, add_noise, 1, 1, d.sb_off_alt, st);   // next profile row (-> the Sbus buffer of the next solve) + res_bus commit
-  std::swap(h->d.sb_off, h->d.sb_off_alt);
+  { const int rc = step_launches(h, actions, actions_dtype, add_noise, reward, terminated, info, st); if (rc) return rc; }
   launch_gather(d, d.gbuf, h->obs_rows, h->obs_scale, 1.0, h->obs_xptr, h->obs_xrow, obs, obs_dtype, C, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;

@@ -550,7 +550,7 @@ extern "C" int mapdn_debug_stamps(unsigned long long* out, int n) {   // the sta
 }
 namespace mapdn {
 #endif
-void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
+void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st, const void* fused_actions, int fused_dtype) {
   if (d.dense) { launch_nr_dense(d, mode, reward, term, info, st); return; }
   if (d.sparse) { launch_nr_sparse(d, mode, reward, term, info, st); return; }
   const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.n, d.nr_cslots, d.nr_xslots, d.nr_nclist, d.nr_h_lds, d.nr_g_lds,
@@ -563,6 +563,7 @@ void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* in
     for (int p = 0; p < NR_INST_PARTS; ++p) if (I >= tabs[p] && I < tabs[p] + cnt[p]) g_last_part = p; }
 #endif
   Dev dd = d;
+  dd.fi_actions = (mode == MODE_STEP) ? fused_actions : nullptr; dd.fi_dtype = fused_dtype;
   void* args[] = {(void*)&dd, (void*)&mode, (void*)&reward, (void*)&term, (void*)&info};
   (void)hipLaunchKernel(I->fn, dim3(d.Bp / d.nr_lanes), dim3(64 * d.nr_waves), args, lds, st);
 }

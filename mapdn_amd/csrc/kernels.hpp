@@ -84,13 +84,20 @@ struct Dev {
   const SpOp* sp_ops; uint32_t sp_ops_bytes; const SpNz* sp_nz; uint32_t sp_nz_bytes; const int32_t* sp_fill_slots;
   int32_t dense, dn_N, dn_lda;
   const int32_t *gy_ptr, *gy_col; const double* gy_val;
+  // ---- PV-bus injection fused into the k_nr_tree prologue (step(), handles without auto_reset): per launch, set by launch_nr.
+  // sgb_rec [n_sgb + n_mlo][4] = Sbus entry of the bus (-1: slack bus, q only) | elimination position | first sgen on the bus (-1:
+  // a load-only bus with several loads) | (number of sgens << 8) | min(number of loads, 2)
+  const int32_t* sgb_rec;
+  const void* fi_actions; int32_t fi_dtype;      // actions [B, ns] of MAPDN_F32 / MAPDN_F64; nullptr: the injection ran as its own launch
 };
 
 void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const double* pl, const double* ql,
                    const double* pv, const double* q, int add_noise, hipStream_t st);
 // step()/reset() form of the injection: PV buses only (the rest of Sbus is kept up to date by k_advance)
 void launch_inject_sgen(const Dev& d, int mode, const void* actions, int dtype, int add_noise, hipStream_t st);
-void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
+// fused_actions != nullptr (MODE_STEP only): k_nr_tree's prologue performs the PV-bus injection itself (no k_inject_sgen launch)
+void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st,
+               const void* fused_actions = nullptr, int fused_dtype = 0);
 int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds, size_t bytes);   // -2: geometry not instantiated
 int nr_geometry_compiled(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds);
 // dynamic LDS of k_nr_tree (W waves, L envs per workgroup => Wt = W*64/L workers), in pair rows of L x 16 bytes:

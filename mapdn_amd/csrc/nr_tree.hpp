@@ -159,6 +159,55 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   const unsigned sF_H = __builtin_amdgcn_readfirstlane(NB_H * pb), sF_G01 = __builtin_amdgcn_readfirstlane(NB_G01 * pb),
                  sF_G23 = __builtin_amdgcn_readfirstlane(NB_G23 * pb);
   const unsigned voS = d.sb_off + e * 16u;       // the injection Sbus, one (re, im) pair row per NODE (entry n + 1, the trash node idle steps work on, stays 0)
+  // ---- fused PV-bus injection (step() of a handle without auto_reset; otherwise k_inject_sgen ran as a launch of its own).
+  // _clip_reactive_power (voltage_control_env.py:568-572): q = a sqrt(s_max^2 - p^2) of the sgens of every PV bus of this workgroup's
+  // envs, Sbus = -((loads) - (sgens)) / sn with the load part k_advance left in bus_ld — the expressions of k_inject_sgen for an env
+  // that is not restarting, in the same order (bit-identical: test_fused_injection_equals_the_injection_launch) — and the step
+  // bookkeeping its first row does.  One item per (PV bus, env), env fastest; a launch of its own cost 6.8 us for 90 k such
+  // items (launch + a chain of dependent loads); here the chain runs once per workgroup beside the LDS initialisation.  The
+  // Sbus entries are read back by this workgroup only, after the barrier that ends the prologue.
+#ifndef MAPDN_NO_FUSE_PROLOGUE      // (A/B builds only: the kernel without the prologue, to separate its register-allocation side effects)
+  if (d.fi_actions) {
+    const int nrow = d.n_sgb + d.n_mlo;
+    const size_t S_ = (size_t)d.Bp;
+    for (unsigned i = threadIdx.x; i < (unsigned)nrow * L; i += 64u * W) {
+      const unsigned jb = i / L;
+      const unsigned e2 = blockIdx.x * L + (i % L);
+      if (e2 >= (unsigned)d.B) continue;
+      const int4 rec = ((const int4*)d.sgb_rec)[jb];
+      const bool act2 = d.done[e2] == 0;
+      if (jb == 0) {
+        d.active[e2] = act2 ? 1 : 0; d.resetting[e2] = 0;
+        d.adv_row[e2] = act2 ? d.start_row[e2] + d.steps[e2] : -1; d.adv_draw[e2] = d.draw[e2];
+      }
+      if (!act2) continue;                         // frozen: q_new, Sbus stay as they are
+      const int sbi = rec.x, k = rec.y, j0 = rec.z, nsg = rec.w >> 8, nld = rec.w & 255;
+      double2* const sbp = (double2*)((char*)d.nrbuf + d.sb_off) + e2;
+      double P, Q;
+      if (nld > 1) {                               // several loads on the bus: the sum of the stored values, in CSR order
+        P = 0.0; Q = 0.0;
+        for (int q = d.load_ptr[k]; q < d.load_ptr[k + 1]; ++q) {
+          const int li = d.load_idx[q];
+          P += d.cur_pl[(size_t)li * S_ + e2] * d.load_scale[li]; Q += d.cur_ql[(size_t)li * S_ + e2] * d.load_scale[li];
+        }
+      } else if (j0 >= 0) { const double2 v = ((const double2*)d.bus_ld)[(size_t)jb * S_ + e2]; P = v.x; Q = v.y; }
+      else { P = 0.0; Q = 0.0; }
+      for (int q = 0; q < nsg; ++q) {
+        const int j = q == 0 ? j0 : d.sgen_idx[d.sgen_ptr[k] + q];
+        const size_t o = (size_t)j * S_ + e2;
+        const double p = d.cur_pv[o];
+        const double sm = d.smax[j];
+        const double lim = sqrt(sm * sm - p * p);
+        const double a = d.fi_dtype == MAPDN_F32 ? (double)((const float*)d.fi_actions)[(size_t)e2 * d.ns + j]
+                                                 : ((const double*)d.fi_actions)[(size_t)e2 * d.ns + j];
+        const double qv = lim * a;
+        d.q_new[o] = qv;
+        P -= p * d.sgen_scale[j]; Q -= qv * d.sgen_scale[j];
+      }
+      if (sbi >= 0) sbp[(size_t)sbi * S_] = make_double2(-P / d.sn, -Q / d.sn);
+    }
+  }
+#endif
   // LDS map, in pair rows (L x 16 bytes: one d2 per env; a worker's 16 lanes read 256 contiguous bytes with one
   // conflict-free ds_read_b128):  V [n+2] | h [n+2] if HL | G [2(n+2)] if GL | contribution slots x 4 | x slots x 1
   //   then verdict bytes [64 W], step sizes [64 W doubles], overflow child list, net.line constants (when they fit)
@@ -229,7 +278,8 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   unsigned ns = 0;
 #endif
   STAMP(1);
-  const bool act = d.active[e] != 0;              // this env takes part in the solve (same for all its workers)
+  // this env takes part in the solve (same for all its workers); with the fused injection the flag is formed as the prologue formed it
+  const bool act = d.fi_actions ? (e < (unsigned)d.B && d.done[e] == 0) : (d.active[e] != 0);
   // step() bookkeeping inputs, fetched now so that their latency is not paid at the very end
   const int bk_steps = d.steps[e];
   const uint32_t bk_draw = d.draw[e];

@@ -963,6 +963,51 @@ def test_pv_bus_injection_equals_all_bus_injection(case):
     fast.close(); full.close()
 
 
+@pytest.mark.parametrize("case,B,geom", [("case33", 70, None), ("case141", 70, None), ("case322", 70, None), ("case141", 200, (2, 16, 1)),
+                                         ("case322", 130, (4, 16, 2)), ("case141", 1, None)])
+@pytest.mark.parametrize("adt", [torch.float64, torch.float32])
+def test_fused_injection_equals_the_injection_launch(case, B, geom, adt):
+    """step() of a handle without auto_reset performs the PV-bus injection (_clip_reactive_power + the Sbus entries of the buses
+    with sgens + the step bookkeeping) in the PROLOGUE of k_nr_tree (mapdn_env_config.fuse_inject, default) instead of as a launch
+    of its own (fuse_inject = 2: k_inject_sgen).  Same expressions in the same order: rewards, flags, info, observations, state
+    and the result tables are bit-identical over noisy episodes with an unsolvable step, frozen envs after it, a whole-batch
+    reset() and a mapdn_solve_only call in between (after which one all-bus injection runs as a launch in both)."""
+    t0 = dict(nr_waves=geom[0], nr_lanes=geom[1], nr_lean=geom[2]) if geom else {}
+    net, prof, fused = make(case, B, tuning=dict(fuse_inject=1, **t0), episode_limit=7)
+    _, _, plain = make(case, B, tuning=dict(fuse_inject=2, **t0), episode_limit=7)
+    of, _ = fused.reset(); ou, _ = plain.reset()
+    assert torch.equal(of, ou)
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(29)
+    rng = np.random.default_rng(4)
+    for t in range(13):
+        act = ((torch.rand(B, net.n_sgen, device="cuda:0", generator=gen, dtype=torch.float64) * 2 - 1) * SCALE[case]).to(adt)
+        if t == 2:
+            act[B // 2] = 60.0                        # unsolvable: that env terminates and stays frozen until the reset below
+        if t == 4:                                    # a solve on explicit inputs in between: Sbus no longer reflects cur_pl / cur_ql
+            rows = rng.integers(0, prof.n_rows, B)
+            qs = rng.uniform(-0.3, 0.3, (B, net.n_sgen)) * prof.pv[rows]
+            a = fused.solve(prof.load_p[rows], prof.load_q[rows], prof.pv[rows], qs)
+            b = plain.solve(prof.load_p[rows], prof.load_q[rows], prof.pv[rows], qs)
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
+        if t == 7:                                    # every env hit the episode limit at call 6
+            of, sf = fused.reset(); ou, su = plain.reset()
+            assert torch.equal(of, ou) and torch.equal(sf, su)
+        ra, ta, ia = fused.step(act); rb, tb, ib = plain.step(act)
+        assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(ia, ib), t
+        if t == 2:
+            assert bool(ta[B // 2]) and ia[B // 2, 10] == 1.0
+        assert torch.equal(fused.get_obs(), plain.get_obs()) and torch.equal(fused.get_state(), plain.get_state()), t
+        fa, fb = fused.results(), plain.results()
+        assert all(torch.equal(fa[k], fb[k]) for k in fa), t
+        la, lb = fused.loads(), plain.loads()
+        assert torch.equal(la[0], lb[0]) and torch.equal(la[1], lb[1])
+    fused.close(); plain.close()
+    # a handle with auto_reset keeps the injection launch (its restarting envs refresh all their loads there); asking for the
+    # fused form on it is refused
+    with pytest.raises(Exception, match="auto_reset"):
+        make(case, B, tuning=dict(fuse_inject=1), auto_reset=True)
+
+
 @pytest.mark.parametrize("case", ["case33", "case141", "case322"])
 def test_mismatch_pass_equals_mismatch_sweep(case):
     """The predicted-final mismatch evaluation runs as a barrier-free pass over all nodes (k_nr_tree::mismatch_pass, the default
