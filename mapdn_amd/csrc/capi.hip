@@ -313,6 +313,9 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
         rec.push_back(k);
         rec.push_back(pv ? P.sgen_idx[P.sgen_ptr[k]] : -1);
         rec.push_back((nsg << 8) | std::min(nld, 2));
+        rec.push_back(nld > 0 ? P.load_idx[P.load_ptr[k]] : -1);        // the first two loads of the bus (CSR order)
+        rec.push_back(nld > 1 ? P.load_idx[P.load_ptr[k] + 1] : -1);
+        rec.push_back(0); rec.push_back(0);
       };
       for (int i = 0; i < d.n_sgb; ++i) put(sgb[i], true);
       for (int i = 0; i < d.n_mlo; ++i) put(mlo[i], false);

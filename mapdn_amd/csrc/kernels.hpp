@@ -85,8 +85,8 @@ struct Dev {
   int32_t dense, dn_N, dn_lda;
   const int32_t *gy_ptr, *gy_col; const double* gy_val;
   // ---- PV-bus injection fused into the k_nr_tree prologue (step(), handles without auto_reset): per launch, set by launch_nr.
-  // sgb_rec [n_sgb + n_mlo][4] = Sbus entry of the bus (-1: slack bus, q only) | elimination position | first sgen on the bus (-1:
-  // a load-only bus with several loads) | (number of sgens << 8) | min(number of loads, 2)
+  // sgb_rec [n_sgb + n_mlo][8] = Sbus entry of the bus (-1: slack bus, q only) | elimination position | first sgen on the bus (-1:
+  // a load-only bus with several loads) | (number of sgens << 8) | min(number of loads, 2) || first load | second load | 0 | 0
   const int32_t* sgb_rec;
   const void* fi_actions; int32_t fi_dtype;      // actions [B, ns] of MAPDN_F32 / MAPDN_F64; nullptr: the injection ran as its own launch
 };

@@ -168,43 +168,106 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // Sbus entries are read back by this workgroup only, after the barrier that ends the prologue.
 #ifndef MAPDN_NO_FUSE_PROLOGUE      // (A/B builds only: the kernel without the prologue, to separate its register-allocation side effects)
   if (d.fi_actions) {
-    const int nrow = d.n_sgb + d.n_mlo;
+    // Items are taken IT at a time per thread with ALL loads of a level issued before any is used (record + flags, then the
+    // values): the chain is paid once per batch, not once per item.  Loads are unconditional with clamped indices, only the
+    // stores are predicated.  (A first version with one item per loop turn cost 3.5 us on the 141-bus feeder: two turns of a
+    // three-deep chain of ~2 k-cycle HBM round trips — the operands were written by the previous launches.)
+    constexpr unsigned IT = 3, NT = 64u * W;
+    const unsigned nitems = (unsigned)(d.n_sgb + d.n_mlo) * L;
     const size_t S_ = (size_t)d.Bp;
-    for (unsigned i = threadIdx.x; i < (unsigned)nrow * L; i += 64u * W) {
-      const unsigned jb = i / L;
-      const unsigned e2 = blockIdx.x * L + (i % L);
-      if (e2 >= (unsigned)d.B) continue;
-      const int4 rec = ((const int4*)d.sgb_rec)[jb];
-      const bool act2 = d.done[e2] == 0;
-      if (jb == 0) {
-        d.active[e2] = act2 ? 1 : 0; d.resetting[e2] = 0;
-        d.adv_row[e2] = act2 ? d.start_row[e2] + d.steps[e2] : -1; d.adv_draw[e2] = d.draw[e2];
+    const unsigned Bm1 = (unsigned)d.B - 1u;
+    const bool a32 = d.fi_dtype == MAPDN_F32;
+    for (unsigned base = threadIdx.x; base < nitems; base += IT * NT) {
+      int4 rec[IT]; int2 rl[IT]; unsigned jb[IT], e2[IT]; bool ok[IT]; uint8_t dn[IT];
+#pragma unroll
+      for (unsigned it = 0; it < IT; ++it) {
+        const unsigned i = base + it * NT;
+        ok[it] = i < nitems;
+        const unsigned ii = ok[it] ? i : 0u;
+        jb[it] = ii / L;
+        const unsigned ee = blockIdx.x * L + (ii % L);
+        ok[it] = ok[it] && ee < (unsigned)d.B;
+        e2[it] = min(ee, Bm1);
+        rec[it] = ((const int4*)d.sgb_rec)[2 * jb[it]];
+        rl[it] = ((const int2*)d.sgb_rec)[4 * jb[it] + 2];
+        dn[it] = d.done[e2[it]];
       }
-      if (!act2) continue;                         // frozen: q_new, Sbus stay as they are
-      const int sbi = rec.x, k = rec.y, j0 = rec.z, nsg = rec.w >> 8, nld = rec.w & 255;
-      double2* const sbp = (double2*)((char*)d.nrbuf + d.sb_off) + e2;
-      double P, Q;
-      if (nld > 1) {                               // several loads on the bus: the sum of the stored values, in CSR order
-        P = 0.0; Q = 0.0;
-        for (int q = d.load_ptr[k]; q < d.load_ptr[k + 1]; ++q) {
-          const int li = d.load_idx[q];
-          P += d.cur_pl[(size_t)li * S_ + e2] * d.load_scale[li]; Q += d.cur_ql[(size_t)li * S_ + e2] * d.load_scale[li];
+      double2 blv[IT]; double pv0[IT], sm0[IT], sc0[IT], a0[IT];
+      int bk_st[IT]; int64_t bk_row[IT]; uint32_t bk_dr[IT];
+#pragma unroll
+      for (unsigned it = 0; it < IT; ++it) {
+        const int j0c = max(rec[it].z, 0);
+        blv[it] = ((const double2*)d.bus_ld)[(size_t)min(jb[it], (unsigned)d.n_sgb - 1u) * S_ + e2[it]];
+        pv0[it] = d.cur_pv[(size_t)j0c * S_ + e2[it]];
+        sm0[it] = d.smax[j0c]; sc0[it] = d.sgen_scale[j0c];
+        const size_t ai = (size_t)e2[it] * d.ns + j0c;
+        a0[it] = a32 ? (double)((const float*)d.fi_actions)[ai] : ((const double*)d.fi_actions)[ai];
+        bk_st[it] = 0; bk_row[it] = 0; bk_dr[it] = 0;
+        if (jb[it] == 0) { bk_st[it] = d.steps[e2[it]]; bk_row[it] = d.start_row[e2[it]]; bk_dr[it] = d.draw[e2[it]]; }
+      }
+      // buses with several loads (none on the 33- / 141-bus feeders, 37 on the 322-bus one): the stored values of their first
+      // two loads, requested with the rest (wave-uniform branch)
+      double lp0[IT], lq0[IT], ls0[IT], lp1[IT], lq1[IT], ls1[IT];
+      bool multi = false;
+#pragma unroll
+      for (unsigned it = 0; it < IT; ++it) multi = multi || (ok[it] && (rec[it].w & 255) > 1);
+      if (__any(multi)) {
+#pragma unroll
+        for (unsigned it = 0; it < IT; ++it) {
+          const int l0 = max(rl[it].x, 0), l1 = max(rl[it].y, 0);
+          lp0[it] = d.cur_pl[(size_t)l0 * S_ + e2[it]]; lq0[it] = d.cur_ql[(size_t)l0 * S_ + e2[it]]; ls0[it] = d.load_scale[l0];
+          lp1[it] = d.cur_pl[(size_t)l1 * S_ + e2[it]]; lq1[it] = d.cur_ql[(size_t)l1 * S_ + e2[it]]; ls1[it] = d.load_scale[l1];
         }
-      } else if (j0 >= 0) { const double2 v = ((const double2*)d.bus_ld)[(size_t)jb * S_ + e2]; P = v.x; Q = v.y; }
-      else { P = 0.0; Q = 0.0; }
-      for (int q = 0; q < nsg; ++q) {
-        const int j = q == 0 ? j0 : d.sgen_idx[d.sgen_ptr[k] + q];
-        const size_t o = (size_t)j * S_ + e2;
-        const double p = d.cur_pv[o];
-        const double sm = d.smax[j];
-        const double lim = sqrt(sm * sm - p * p);
-        const double a = d.fi_dtype == MAPDN_F32 ? (double)((const float*)d.fi_actions)[(size_t)e2 * d.ns + j]
-                                                 : ((const double*)d.fi_actions)[(size_t)e2 * d.ns + j];
-        const double qv = lim * a;
-        d.q_new[o] = qv;
-        P -= p * d.sgen_scale[j]; Q -= qv * d.sgen_scale[j];
+      } else {
+#pragma unroll
+        for (unsigned it = 0; it < IT; ++it) { lp0[it] = lq0[it] = ls0[it] = lp1[it] = lq1[it] = ls1[it] = 0.0; }
       }
-      if (sbi >= 0) sbp[(size_t)sbi * S_] = make_double2(-P / d.sn, -Q / d.sn);
+#pragma unroll
+      for (unsigned it = 0; it < IT; ++it) {
+        if (!ok[it]) continue;
+        const unsigned ee = e2[it];
+        const bool act2 = dn[it] == 0;
+        if (jb[it] == 0) {
+          d.active[ee] = act2 ? 1 : 0; d.resetting[ee] = 0;
+          d.adv_row[ee] = act2 ? bk_row[it] + bk_st[it] : -1; d.adv_draw[ee] = bk_dr[it];
+        }
+        if (!act2) continue;                       // frozen: q_new, Sbus stay as they are
+        const int sbi = rec[it].x, k = rec[it].y, j0 = rec[it].z, nsg = rec[it].w >> 8, nld = rec[it].w & 255;
+        double P, Q;
+        if (nld > 1) {                             // several loads on the bus: the sum of the stored values, in CSR order
+          P = 0.0; Q = 0.0;
+          P += lp0[it] * ls0[it]; Q += lq0[it] * ls0[it];
+          P += lp1[it] * ls1[it]; Q += lq1[it] * ls1[it];
+#pragma unroll 1
+          for (int q = d.load_ptr[k] + 2; q < d.load_ptr[k + 1]; ++q) {     // a third, fourth ... load (rare)
+            const int li = d.load_idx[q];
+            P += d.cur_pl[(size_t)li * S_ + ee] * d.load_scale[li]; Q += d.cur_ql[(size_t)li * S_ + ee] * d.load_scale[li];
+          }
+        } else if (j0 >= 0) { P = blv[it].x; Q = blv[it].y; }
+        else { P = 0.0; Q = 0.0; }
+        if (nsg > 0) {
+          {
+            const double p = pv0[it], sm = sm0[it];
+            const double lim = sqrt(sm * sm - p * p);
+            const double qv = lim * a0[it];
+            d.q_new[(size_t)j0 * S_ + ee] = qv;
+            P -= p * sc0[it]; Q -= qv * sc0[it];
+          }
+#pragma unroll 1
+          for (int q = 1; q < nsg; ++q) {          // further sgens on the same bus (rare)
+            const int j = d.sgen_idx[d.sgen_ptr[k] + q];
+            const size_t o = (size_t)j * S_ + ee;
+            const double p = d.cur_pv[o];
+            const double sm = d.smax[j];
+            const double lim = sqrt(sm * sm - p * p);
+            const size_t ai = (size_t)ee * d.ns + j;
+            const double qv = lim * (a32 ? (double)((const float*)d.fi_actions)[ai] : ((const double*)d.fi_actions)[ai]);
+            d.q_new[o] = qv;
+            P -= p * d.sgen_scale[j]; Q -= qv * d.sgen_scale[j];
+          }
+        }
+        if (sbi >= 0) ((double2*)((char*)d.nrbuf + d.sb_off))[(size_t)sbi * S_ + ee] = make_double2(-P / d.sn, -Q / d.sn);
+      }
     }
   }
 #endif
