@@ -65,12 +65,22 @@ class BatchedRunpp:
         B, nb = pl.shape[0], net.n_bus
         pd_, qd = self._demand(pl, ql, pv, qs)
         sbus = -(pd_ + 1j * qd) / net.sn_mva                                   # [B, nb]
-        V = np.full((B, nb), net.ext_grid_vm_pu, dtype=np.complex128)          # init="auto": flat start at the slack set-point
+        V, conv, it = self.newton(sbus)
+        return self._results(V, conv, it, pd_, qd, sbus)
+
+    def newton(self, sbus, V0=None, max_iter=MAX_ITER):
+        """The Newton iteration alone: sbus [B, nb] complex -> (V [B, nb], converged [B], iterations [B]).  V0 = None is runpp's
+        init="auto" (flat start at the slack set-point); a [B, nb] array is init="results" (tools/warm_start_study.py)."""
+        net = self.net
+        B, nb = sbus.shape
+        V = (np.full((B, nb), net.ext_grid_vm_pu, dtype=np.complex128) if V0 is None     # init="auto": flat start at the slack set-point
+             else np.array(V0, dtype=np.complex128))
         nonslack = np.array([k for k in range(nb) if k != self.slack])
         it = np.zeros(B, np.int64)
         conv = np.zeros(B, bool)
         active = np.ones(B, bool)
         par = self.parent
+        MAX_ITER = max_iter                                                    # (shadows the module constant inside the loop below)
         for sweep in range(MAX_ITER + 1):
             S = V * np.conj((self.ybus @ V.T).T)                               # [B, nb]
             F = S - sbus
@@ -117,7 +127,12 @@ class BatchedRunpp:
             Vn = vm * np.exp(1j * va)
             V = np.where(active[:, None], Vn, V)
             it = it + active
+        return V, conv, it
+
+    def _results(self, V, conv, it, pd_, qd, sbus):
         # ---- pfsoln + result tables (pp_restated.runpp_restated, batched)
+        net = self.net
+        B = V.shape[0]
         vm = np.abs(V); va_deg = np.angle(V) * 180.0 / np.pi
         s_inj = V * np.conj((self.ybus @ V.T).T) * net.sn_mva
         p_bus, q_bus = pd_.copy(), qd.copy()
