@@ -218,7 +218,7 @@ def measure_traffic(case, envs):
 
 
 def committed_traffic(case, envs):
-    for tag in ("r03_final", "r02_final", "r02_base", "r01"):
+    for tag in ("r04_final", "r03_final", "r02_final", "r02_base", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_traffic_{case}_b{envs}.json")
         if os.path.exists(path):
             return json.load(open(path))["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
@@ -257,8 +257,13 @@ def main():
                                                         "exercise the N>1 path on a box with fewer GPUs than ranks")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the timed --steps block until the blocks add up to this")
+    ap.add_argument("--repeats", type=int, default=0, help="exactly this many timed blocks (0: repeat until --min-seconds)")
     ap.add_argument("--inner", action="store_true", help="(internal) short un-instrumented loop for the PMC sub-runs")
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the short case33 / case322 measurements appended to the default line")
+    ap.add_argument("--env-id-offset", type=int, default=0, help="global id of this run's first env (a 1-rank run that covers the ids "
+                                                                   "of rank r of an N-rank run: r x envs); ranks add rank x envs")
+    ap.add_argument("--dump-returns", default=None, help="rank 0 writes the gathered per-env episode returns of the LAST timed block "
+                                                         "to this .npy file (pre-flight checks of the N > 1 path)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -270,8 +275,12 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.inner:
-        cpu = cpu_baseline(a.case, a.cpu_seconds)             # before any GPU work: the workers are forked
+    if rank == 0 and not a.no_cpu_baseline and not a.inner:
+        # before any GPU work: the workers are forked.  (N > 1: the other ranks wait for rank 0 at the rendezvous meanwhile; the
+        # sample is halved and the line says that the host was shared with their start-up.)
+        cpu = cpu_baseline(a.case, a.cpu_seconds if world == 1 else 0.5 * a.cpu_seconds)
+        if world > 1:
+            cpu["note"] = f"measured on rank 0 of {world} while the other ranks were starting up on the same host"
 
     import numpy as np  # noqa: F401
     import torch
@@ -301,15 +310,18 @@ def main():
         """The timed loop on one (case, envs per GPU): returns the block times (max over ranks), the env and its NR timing."""
         net, prof = make_case(case)
         args = dict(episode_limit=240, action_scale=SCALE[case], action_bias=0.0, voltage_barrier_type="bowl", seed=0)
-        env = VoltageControlBatch(net, prof, args, n_envs=B, device=dev, env_id_offset=rank * B)   # weak scaling
+        id0 = a.env_id_offset + rank * B                     # weak scaling: rank r owns the global env ids [id0, id0 + B)
+        env = VoltageControlBatch(net, prof, args, n_envs=B, device=dev, env_id_offset=id0)
         gen = torch.Generator(device=dev)
-        gen.manual_seed(1234 + rank)
+        gen.manual_seed(1234 + id0 // B)                     # actions keyed by the block of global ids, not by the rank: a 1-rank run
+                                                             # with --env-id-offset r x B replays rank r of an N-rank run exactly
         scale = SCALE[case]
         # fresh random actions for every step, drawn on the device BEFORE the timed region so that the
         # (excluded) policy costs nothing inside it; a ring of `n_act` distinct action tensors
         n_act = min(a.steps + a.warmup + 60, 256)
         acts = torch.empty(n_act, B, env.n_sgen, dtype=torch.float32, device=dev).uniform_(-scale, scale, generator=gen)
         steps_in_ep, step_no, resets = [0], [0], [0]
+        last_returns = [None]
 
         def one_step():
             act = acts[step_no[0] % n_act]
@@ -332,6 +344,9 @@ def main():
                 ret = env.episode_returns()
                 allret = gather_rollout(ret if a.backend == "nccl" else ret.cpu())
                 assert allret.shape[0] == world * B
+                last_returns[0] = allret
+            elif a.dump_returns:
+                last_returns[0] = env.episode_returns()
             fence()
             dt = time.perf_counter() - t0
             if dist is not None:
@@ -352,7 +367,7 @@ def main():
         # the decision uses the max-over-ranks times).  `ms_per_step` / `value` are the MEDIAN block; min / max are reported.
         resets[0] = 0
         blocks = []
-        while len(blocks) < 3 or (sum(blocks) < min_seconds and len(blocks) < 2000):
+        while (len(blocks) < a.repeats) if a.repeats > 0 else (len(blocks) < 3 or (sum(blocks) < min_seconds and len(blocks) < 2000)):
             blocks.append(timed_block())
         resets_in_region = resets[0]
         stats = env.stats()
@@ -370,7 +385,8 @@ def main():
             t[rank] = nr_avg_rank_ms
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             nr_per_rank = [float(x) for x in t.tolist()]
-        return dict(env=env, blocks=blocks, resets=resets_in_region, stats=stats, nr_per_rank=nr_per_rank, nr_launches=nr_launches)
+        return dict(env=env, blocks=blocks, resets=resets_in_region, stats=stats, nr_per_rank=nr_per_rank, nr_launches=nr_launches,
+                    returns=last_returns[0])
 
     B = a.envs
     m = measure(a.case, B, a.min_seconds, inner=a.inner)
@@ -378,6 +394,8 @@ def main():
         return
     env, blocks, resets_in_region, stats = m["env"], m["blocks"], m["resets"], m["stats"]
     nr_per_rank, nr_launches = m["nr_per_rank"], m["nr_launches"]
+    if a.dump_returns and rank == 0 and m["returns"] is not None:
+        np.save(a.dump_returns, m["returns"].detach().cpu().numpy())
     blocks_sorted = sorted(blocks)
     dt = blocks_sorted[len(blocks) // 2]
     kname = "k_nr_tree"
@@ -388,20 +406,23 @@ def main():
     # case33 x 4096 (BASELINE configs[1]) and the per-GPU shards of the two case322 configurations (8192 / 8, 65536 / 8)
     shapes = []
     if not a.no_other_shapes and a.case == "case141" and B == 4096:
-        for c2, b2 in (("case33", 4096), ("case322", 1024), ("case322", 8192)):
+        for c2, b2 in (("case33", 4096), ("case322", 1024), ("case322", 8192), ("case141_deep", 4096)):
             m2 = measure(c2, b2, 0.2)
             e2 = m2["env"]
             bl = sorted(m2["blocks"])
             d2 = bl[len(bl) // 2]
             by2 = algorithmic_bytes_per_env_step(e2)
             nr2 = max(m2["nr_per_rank"]) * 1e-3
-            shapes.append({"workload": f"{c2} ({e2.n_bus}-bus, {e2.n_agents} agents), {b2} envs per GPU, step()+get_obs()",
+            tr2, trsrc2 = committed_traffic(c2, b2)
+            shapes.append({"workload": f"{c2} ({e2.n_bus}-bus, {e2.n_agents} agents), {b2} envs per GPU, step()+get_obs()"
+                                       + (" — a depth stress (45-bus trunk, radius 25), not one of the reference's scenarios" if c2 == "case141_deep" else ""),
                            "value": world * b2 * a.steps / d2, "unit": "env-steps/s", "ms_per_step": d2 / a.steps * 1e3, "repeats": len(bl),
                            "ms_per_step_repeats": {"min": bl[0] / a.steps * 1e3, "max": bl[-1] / a.steps * 1e3},
                            "nr_iterations": {"mean": m2["stats"]["mean_nr_iters"], "max": m2["stats"]["max_nr_iters"]},
                            "roofline": {"bound": "hbm", "achieved": by2 * b2 / nr2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": by2 * b2 / nr2 / 1e9 / HBM_PEAK_GBS, "kernel_avg_ms": nr2 * 1e3,
-                                        "algorithmic_bytes_per_env_step": by2, "traffic": committed_traffic(c2, b2)[0]}})
+                                        "algorithmic_bytes_per_env_step": by2, "traffic": tr2,
+                                        "traffic_source": (f"committed rocprofv3 PMC passes: {trsrc2}" if trsrc2 else None)}})
             e2.close()
 
     if rank == 0:

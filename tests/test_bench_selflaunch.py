@@ -44,7 +44,7 @@ def test_bench_gpus2_without_a_launcher():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--envs", "64",
-                        "--steps", "4", "--warmup", "2", "--no-traffic"], capture_output=True, text=True, timeout=600, env=env)
+                        "--steps", "4", "--warmup", "2", "--no-traffic", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -52,6 +52,44 @@ def test_bench_gpus2_without_a_launcher():
     assert j["n_gpus"] == 2 and j["config"]["global_envs"] == 128 and j["config"]["envs_per_gpu"] == 64
     assert j["steps"] == 4 and j["warmup"] == 2 and j["value"] > 0 and "cpu_baseline" not in j
     assert abs(j["value"] - 128 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_gpus8_preflight_on_one_gpu(tmp_path):
+    """Pre-flight of the driver's first real SCALE run: `python bench.py --gpus 8` exactly as the driver calls
+    it — eight ranks, here all on cuda:0 with gloo standing in for RCCL (the nccl path differs in the backend string and in
+    the device the gathered tensor lives on) — at the headline shard size, 4096 envs per rank.  One JSON line that describes the
+    whole job, the NR kernel's time on every rank, the CPU baseline from rank 0; and rank r's episode returns are bit-identical to
+    a ONE-rank run that covers the same global env ids (--env-id-offset r x 4096): results do not depend on the number of
+    GPUs."""
+    import numpy as np
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    dump8 = str(tmp_path / "ret8.npy")
+    common = ["--envs", "4096", "--steps", "6", "--warmup", "2", "--repeats", "3", "--no-traffic", "--no-other-shapes"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--cpu-seconds", "2",
+                        "--dump-returns", dump8] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["global_envs"] == 8 * 4096 and j["config"]["envs_per_gpu"] == 4096 and j["scaling"] == "weak"
+    assert j["metric"].startswith("env-steps/sec (whole node), case141 batch=4096")
+    per_rank = j["roofline"]["kernel_avg_ms_per_rank"]
+    assert len(per_rank) == 8 and all(t > 0 for t in per_rank) and abs(j["roofline"]["kernel_avg_ms"] - max(per_rank)) < 1e-12
+    assert abs(j["value"] - 8 * 4096 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0 and "rank 0 of 8" in j["cpu_baseline"]["note"]
+    ret8 = np.load(dump8)
+    assert ret8.shape == (8 * 4096,) and np.isfinite(ret8).all()
+    for rank in (0, 5):
+        dump1 = str(tmp_path / f"ret1_{rank}.npy")
+        r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--env-id-offset", str(rank * 4096), "--no-cpu-baseline",
+                             "--dump-returns", dump1] + common, capture_output=True, text=True, timeout=600, env=env)
+        assert r1.returncode == 0, r1.stderr[-3000:]
+        j1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
+        assert j1["repeats"] == j["repeats"] == 3 and j1["config"]["global_envs"] == 4096
+        assert np.array_equal(np.load(dump1), ret8[rank * 4096:(rank + 1) * 4096]), rank      # same ids -> same keyed noise, start rows, actions
 
 
 @pytest.mark.gpu
