@@ -189,12 +189,17 @@ def _cached_ybus(net):
     return hit[1], hit[2], hit[3], hit[4]
 
 
-def runpp_restated(net, p_load, q_load, p_sgen, q_sgen, raise_on_fail=False, cache=True):
+def runpp_restated(net, p_load, q_load, p_sgen, q_sgen, raise_on_fail=False, cache=True, tolerance_mva=TOLERANCE_MVA,
+                   tolerance_is_pu=False):
     """``pp.runpp(net)`` for a net whose load/sgen columns hold the given MW / MVAr values.
 
     Returns res_bus (vm_pu, va_degree, p_mw, q_mvar sorted by bus index), res_line.pl_mw,
     converged flag and iteration count.  Ybus is cached per NetSpec object (pandapower rebuilds it
     on every call; the values are identical because the topology never changes inside MAPDN).
+
+    Stopping rule: ||F||inf < tolerance_mva / sn_mva with F in per unit — as recalled from pandapower 2.7.0 (UNPINNED: pandapower is
+    not installable here; tests/test_pandapower_pin.py::test_tolerance_rule_on_sn_mva_not_one decides it wherever pandapower is).
+    `tolerance_is_pu=True` is the other reading (||F||inf < tolerance_mva, no division) — mapdn_env_config.tolerance_is_pu.
     """
     if cache:
         ybus, yf, yt, br = _cached_ybus(net)
@@ -210,7 +215,7 @@ def runpp_restated(net, p_load, q_load, p_sgen, q_sgen, raise_on_fail=False, cac
     sbus = make_sbus(net, pd_, qd)
     # init="auto" -> flat start at mean vm set-point of voltage-controlled elements (one ext_grid)
     v0 = np.full(nb, net.ext_grid_vm_pu, dtype=np.complex128)
-    tol = TOLERANCE_MVA / net.sn_mva
+    tol = tolerance_mva / (1.0 if tolerance_is_pu else net.sn_mva)
     v, converged, it = newtonpf(ybus, sbus, v0, ref, pv, pq, tol)
     if not converged and raise_on_fail:
         raise LoadflowNotConverged(f"Power Flow nr did not converge after {MAX_ITER} iterations!")

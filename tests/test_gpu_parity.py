@@ -1038,3 +1038,29 @@ def test_mismatch_pass_equals_mismatch_sweep(case):
         vm, va, it, cv = out[tag]
         assert np.array_equal(it, it0) and np.array_equal(cv, cv0), tag
         assert np.array_equal(vm[ok], vm0[ok]) and np.array_equal(va[ok], va0[ok]), tag
+
+
+@pytest.mark.parametrize("tuning", [dict(), dict(tolerance_is_pu=1), dict(tolerance_mva=1e-3), dict(tolerance_mva=1e-3, tolerance_is_pu=1)])
+def test_tolerance_options_follow_the_oracle_on_a_net_with_sn_mva_100(tuning):
+    """mapdn_env_config.tolerance_mva / tolerance_is_pu (the two readings of how pandapower forms newtonpf's stopping rule from
+    runpp's tolerance_mva; they coincide on sn_mva = 1 nets): iteration counts and voltages follow oracle.runpp_restated with the
+    same options on a 141-bus net rescaled to sn_mva = 100, where the readings stop at different iterations"""
+    B = 64
+    net, prof = make_case("case141")
+    net.sn_mva = 100.0
+    rng = np.random.default_rng(3)
+    rows = rng.integers(0, prof.n_rows, B)
+    pv = prof.pv[rows]
+    qs = rng.uniform(-0.6, 0.6, (B, net.n_sgen)) * np.sqrt(prof.s_max() ** 2 - pv ** 2)
+    env = VoltageControlBatch(net, prof, args_for("case141"), n_envs=B, device="cuda:0", tuning=tuning)
+    vm, va, it, cv = [x.cpu().numpy() for x in env.solve(prof.load_p[rows], prof.load_q[rows], pv, qs)]
+    env.close()
+    assert cv.all()
+    its = set()
+    for e in range(0, B, 4):
+        r = runpp_restated(net, prof.load_p[rows[e]], prof.load_q[rows[e]], pv[e], qs[e], cache=False,
+                           tolerance_mva=tuning.get("tolerance_mva", 1e-8), tolerance_is_pu=bool(tuning.get("tolerance_is_pu", 0)))
+        assert r.iterations == it[e], (e, r.iterations, it[e])
+        assert np.abs(vm[e] - r.vm_pu).max() < (1e-9 if "tolerance_mva" not in tuning else 1e-6)
+        its.add(int(it[e]))
+    assert its

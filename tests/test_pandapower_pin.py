@@ -84,3 +84,32 @@ def test_transformer_net_matches_real_pandapower():
     assert np.abs(rb.p_mw.to_numpy() - r.p_mw).max() < 1e-8 and np.abs(rb.q_mvar.to_numpy() - r.q_mvar).max() < 1e-8
     assert np.abs(n.res_line.sort_index().pl_mw.to_numpy() - r.pl_mw).max() < 1e-8
     assert int(n._ppc["iterations"]) == r.iterations
+
+
+def test_tolerance_rule_on_sn_mva_not_one():
+    """THE assertion that decides mapdn_env_config.tolerance_is_pu (missing item 1): how pandapower 2.7.0 turns
+    runpp's tolerance_mva into the stopping rule of newtonpf.  On a net with sn_mva = 100 the two readings — ||F||inf <
+    tolerance_mva / sn_mva (the restatement's default) or ||F||inf < tolerance_mva — stop at different iterations for a suitably
+    coarse tolerance, while the converged voltages agree; the iteration count pandapower reports picks the reading.  If the
+    SECOND assertion below is the one that holds, set tolerance_is_pu = 1 (oracle: runpp_restated(..., tolerance_is_pu=True);
+    library: mapdn_env_config.tolerance_is_pu / tuning=dict(tolerance_is_pu=1)) — a one-line change on either side."""
+    net, prof = make_case("case141")
+    net.sn_mva = 100.0
+    row = 1234
+    pv = prof.pv[row]
+    q = 0.3 * np.sqrt(prof.s_max() ** 2 - pv ** 2)
+    decided = None
+    for tol in (1e-3, 1e-4, 1e-5, 1e-6, 1e-8):
+        n = to_pandapower(net, prof.load_p[row], prof.load_q[row], pv, q)
+        pp.runpp(n, tolerance_mva=tol)
+        it_pp = int(n._ppc["iterations"])
+        a = runpp_restated(net, prof.load_p[row], prof.load_q[row], pv, q, tolerance_mva=tol, tolerance_is_pu=False).iterations
+        b = runpp_restated(net, prof.load_p[row], prof.load_q[row], pv, q, tolerance_mva=tol, tolerance_is_pu=True).iterations
+        if a != b:
+            assert it_pp in (a, b), (tol, it_pp, a, b)
+            verdict = "divide" if it_pp == a else "as_is"
+            assert decided in (None, verdict), "pandapower's iteration counts fit neither reading consistently"
+            decided = verdict
+    assert decided is not None, "no tolerance in the sweep separates the two readings on this net"
+    assert decided == "divide", ("pandapower uses ||F||inf < tolerance_mva WITHOUT dividing by sn_mva: set tolerance_is_pu = 1 "
+                                 "(mapdn_env_config / oracle.runpp_restated) — see this test's docstring")
