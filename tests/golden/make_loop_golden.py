@@ -97,7 +97,8 @@ def run(case):
     save_profiles_csv(quantized_profiles(prof), d, float_format=f"%.{DIGITS}g")
     env_args = yaml.safe_load(open(f"{REF}/args/env_args/var_voltage_control.yaml"))["env_args"]     # the reference's own defaults
     env_args.update(data_path=d, action_scale=cfg["action_scale"], action_bias=0.0, mode="distributed", voltage_barrier_type="bowl",
-                    episode_limit=240, seed=0)
+                    episode_limit=240, seed=0,
+                    reset_action=False)      # (manual_reset would otherwise start from a random action drawn from numpy's global stream)
     np.random.seed(0)
     th.manual_seed(0)
     env = VoltageControl(env_args)
