@@ -16,6 +16,7 @@ MT19937 stream, which the product replaces by keyed Philox streams, so only the 
 Run from the repo root in a container that has /root/reference:
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_loop_golden.py
 """
+import copy
 import json
 import os
 import sys
@@ -61,8 +62,10 @@ class Recorder:
 
         def call(*args, **kwargs):
             ret = attr(*args, **kwargs)
+            # values are snapshotted AT CALL TIME: the reference's `_calc_reward(self, info={})` (voltage_control_env.py:574) returns the
+            # same dict object from every step() and mutates it in place, so a reference kept until later shows the LAST step's values
             self._log.append(dict(m=name, args=[summarize(a) for a in args], kwargs={k: summarize(v) for k, v in kwargs.items()},
-                                  ret=summarize(ret), _args=args, _kwargs=kwargs, _ret=ret))
+                                  ret=summarize(ret), _args=copy.deepcopy(args), _kwargs=copy.deepcopy(kwargs), _ret=copy.deepcopy(ret)))
             return ret
         return call
 

@@ -60,6 +60,34 @@ def test_fixture_covers_the_loops_env_surface(case):
                                                "total_line_loss", "q_loss", "destroy"))
 
 
+@pytest.mark.parametrize("case", ["case33", "case141"])
+def test_oracle_env_reproduces_the_recorded_tester_episode(case):
+    """(CPU) the deterministic part of the recording — PGTester.run: manual_reset, step(add_noise=False), get_obs, the getters —
+    replayed on oracle/env_restated.py: the checker the GPU tests lean on agrees with the reference's own loop run to 1e-12"""
+    from oracle.env_restated import VoltageControlOracle
+    meta, vals = _fixture(case)
+    net, prof = make_case(case)
+    env = VoltageControlOracle(net, quantized_profiles(prof), dict(meta["env_args"]), env_id=0, do_reset=False)
+    worst, n_steps = 0.0, 0
+    for i, c in enumerate(meta["calls"]):
+        if i < meta["phases"]["evaluation"]:
+            continue
+        if c["m"] == "manual_reset":
+            obs, state = env.manual_reset(*[int(vals[f"{i}/a{j}"]) for j in range(3)])
+            worst = max(worst, float(np.abs(state - vals[f"{i}/r/1"]).max()), max(float(np.abs(np.array(obs[k]) - vals[f"{i}/r/0/{k}"]).max()) for k in range(len(obs))))
+        elif c["m"] == "step":
+            r, t, info = env.step(np.asarray(vals[f"{i}/a0"], dtype=np.float32), add_noise=False)
+            assert t == bool(vals[f"{i}/r/1"])
+            worst = max(worst, abs(r - float(vals[f"{i}/r/0"])), float(np.abs(np.array([info[k] for k in sorted(info)]) - vals[f"{i}/r/2/dict"]).max()))
+            n_steps += 1
+        elif c["m"] == "get_obs":
+            o = env.get_obs()
+            worst = max(worst, max(float(np.abs(np.array(o[k]) - vals[f"{i}/r/{k}"]).max()) for k in range(len(o))))
+        elif c["m"] == "_get_res_bus_v":
+            worst = max(worst, float(np.abs(env.res.vm_pu - vals[f"{i}/r"]).max()))
+    assert n_steps == meta["max_steps"] and worst < 1e-12, worst
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["case33", "case141"])
 def test_drop_in_serves_the_reference_loops_call_sequence(case, tmp_path):
