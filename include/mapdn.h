@@ -159,12 +159,18 @@ typedef struct mapdn_env_config {
                                        coincide on every net with sn_mva == 1 (all MAPDN scenarios and bench nets);
                                        tests/test_pandapower_pin.py::test_tolerance_rule_on_sn_mva_not_one decides which one
                                        pandapower uses wherever pandapower is installed                                    */
-  int32_t nr_init;                  /* runpp(init=...): 0 "auto"/"flat" — every solve starts at the slack set-point, what the
-                                       reference does (default; exact pandapower iterates); 1 "results" — OPT-IN warm start: a
-                                       step() solve starts from the env's last accepted voltages and falls back to the exact
-                                       flat-start solve when it has not converged after 3 iterations; voltages then agree with
-                                       the flat-start answer to the solver tolerance (<< 1e-6 p.u.), iteration counts differ.
-                                       Radial feeders only (k_nr_tree); reset() and mapdn_solve_only always start flat          */
+  int32_t nr_init;                  /* runpp(init=...): 0 "auto" / "flat" — every solve starts at the slack set-point, what the
+                                       reference does (exact pandapower iterates).  1 ("results": start a step() solve from the
+                                       env's last accepted voltages, fall back to the flat start after 3 iterations) is RESERVED
+                                       and refused (MAPDN_E_INVALID): the study that was to gate it (tools/warm_start_study.py,
+                                       profiles/r04_warm_start_study_*.json: 3.6 M solves on the oracle, 15 % of them stressed
+                                       to and beyond voltage collapse) found it SAFE — never "converged" where the flat start
+                                       reports LoadflowNotConverged, never another root, |dV| < 1e-9 — but USELESS for this
+                                       kernel: under i.i.d. actions (bench.py's workload) the previous voltages are no closer in
+                                       Newton iterations than the flat start (mean 4.12 -> 4.23 iterations on the 141-bus feeder,
+                                       4.56 -> 6.34 on the 33-bus one, with the fallback), and under a smooth policy only 43 % /
+                                       79 % of the envs (141 / 322 buses) save an iteration, while a workgroup's 16 envs finish
+                                       together: P(all 16 save one) ~ 0.  Not built.                                           */
   /* ---- composition of the step() launches (same results; A/B switches) */
   int32_t fuse_inject;              /* step(): 0 auto — the PV-bus injection (_clip_reactive_power, Sbus of the buses with sgens)
                                        runs inside the prologue of k_nr_tree when the handle uses the tree solver and has no

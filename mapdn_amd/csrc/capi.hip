@@ -233,7 +233,10 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   if (!cfg->use_line_weight && !cfg->use_q_weight) {   // voltage_control_env.py:616-617
     h->err = "NotImplementedError: Please at least give one weight, either q_weight or line_weight."; return MAPDN_E_INVALID; }
   if (cfg->episode_limit < 2) { h->err = "episode_limit must be >= 2"; return MAPDN_E_INVALID; }
-  if (cfg->nr_init != 0 && cfg->nr_init != 1) { h->err = "nr_init must be 0 (flat start) or 1 (warm start from the last accepted voltages)"; return MAPDN_E_INVALID; }
+  if (cfg->nr_init != 0) {   // reserved: see include/mapdn.h (the gating study found the warm start safe but without effect on the launch time)
+    h->err = "nr_init != 0 (warm start, runpp init=\"results\") is not built: tools/warm_start_study.py / profiles/r04_warm_start_study_*.json "
+             "show no iteration saved per 16-env workgroup; every solve starts flat like the reference's";
+    return MAPDN_E_INVALID; }
   int rc = build_plan(*net, *cfg, h->plan, h->err);
   if (rc) return rc;
   {
