@@ -649,13 +649,14 @@ static int step_launches(mapdn_handle* h, const void* actions, int32_t actions_d
     // fork after the injection (it queues the row / draw the advance uses), join before the commit rows
     HIPCHK(h, hipEventRecord(h->ev_fork, st));
     HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    launch_advance(d, add_noise, d.sb_off_alt, h->side);
+    launch_advance(d, add_noise, 1, 0, d.sb_off_alt, h->side);
     HIPCHK(h, hipEventRecord(h->ev_join, h->side));
     nr_launch(h, MODE_STEP, reward, terminated, info, st);
     HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+    launch_advance(d, 0, 0, 1, d.sb_off_alt, st);
   } else {
     nr_launch(h, MODE_STEP, reward, terminated, info, st, fused ? actions : nullptr, actions_dtype);
-    launch_advance(d, add_noise, d.sb_off_alt, st);   // next profile row (-> the Sbus buffer of the next solve)
+    launch_advance(d, add_noise, 1, 1, d.sb_off_alt, st);   // next profile row (-> the Sbus buffer of the next solve) + res_bus commit
   }
   std::swap(h->d.sb_off, h->d.sb_off_alt);
   return MAPDN_OK;
@@ -671,9 +672,10 @@ int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, i
   const Dev& d = h->d;
   for (int t = 0; t < max_tries; ++t) {
     launch_reset_begin(d, start_rows, t == 0, st);
-    launch_advance(d, add_noise, d.sb_off, st);   // the advance precedes the solve here: it fills the buffer the solve reads
+    launch_advance(d, add_noise, 1, 0, d.sb_off, st);   // the advance precedes the solve here: it fills the buffer the solve reads
     inject_launch(h, MODE_RESET, nullptr, MAPDN_F64, add_noise, st);
-    nr_launch(h, MODE_RESET, nullptr, nullptr, nullptr, st);   // (its epilogue commits res_bus of the envs that found a solvable start)
+    nr_launch(h, MODE_RESET, nullptr, nullptr, nullptr, st);
+    launch_advance(d, 0, 0, 1, d.sb_off, st);    // res_bus commit of the envs that found a solvable start
   }
   HIPCHK(h, hipGetLastError());
   h->was_reset = true;

@@ -288,26 +288,56 @@ __global__ void __launch_bounds__(256) k_reset_begin(Dev d, const int64_t* __res
 }
 
 // =================================================================================================
-// K9b  advance — _set_demand_and_pv (voltage_control_env.py:491-513): next row of the three profile tables + std/100 * |N(0,1)|
-//      noise (:498,503,508).  (Round 4: the res_bus commit that shared this launch in rounds 2-3 now lives in the solver's epilogue,
-//      nr_common.hpp.)
+// K9b  advance (+ K6 bus commit) — _set_demand_and_pv (voltage_control_env.py:491-513): next row of the three
+//      profile tables + std/100 * |N(0,1)| noise (:498,503,508), and the commit of res_bus for the solve that just finished.
 //      rows [0, npv): thread = (Philox block of the PV table, env): one Philox4x32-10 call + one Box-Muller pair serves two
 //                     adjacent PV columns;
 //      load rows:     thread = (pair of loads, env): their P and Q values (one Philox block of each of the two load streams);
 //                     a load that is alone on its bus IS that bus's load sum, so the thread also stores what the next
-//                     injection / solve needs — the finished Sbus entry of a bus without sgens, the load part (bus_ld) of
+//                     k_inject_sgen / solve needs — the finished Sbus entry of a bus without sgens, the load part (bus_ld) of
 //                     a PV bus — as one 16-byte (P, Q) store;
-//                     (the load sum of a bus with SEVERAL loads is formed by the next injection from the stored values).
-//      Sbus is DOUBLE-BUFFERED: the solve of this step used d.sb_off, the load rows write the buffer of the next solve
-//      (`sb_write_off`: the other one in step(), the same one in reset(), where the advance comes before the solve); the host flips
-//      the buffers after every step.
+//                     (the load sum of a bus with SEVERAL loads is formed by the next k_inject_sgen from the stored values);
+//      then nb rows:  thread = (bus position, env): the K6 commit.
+//      Sbus is DOUBLE-BUFFERED: the commit reads the buffer the solve used (d.sb_off) while the load rows of the same launch
+//      write the buffer of the next solve (`sb_write_off`: the other one in step(), the same one in reset(), where the
+//      advance comes before the solve); the host flips the buffers after every step.
 // =================================================================================================
-__global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, uint32_t sb_write_off) {
+__global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.B) return;
-  const int npv = (d.ns + 1) >> 1;
+  const int npv = (d.ns + 1) >> 1, npl = (d.nl + 1) >> 1;
+  const int npairs = do_profiles ? npv + npl : 0;
+  const int nmb = 0;
   const size_t S = (size_t)d.Bp;
   double2* const sbw = (double2*)((char*)d.nrbuf + sb_write_off) + e;
+  if ((int)blockIdx.y >= npairs + nmb) {
+    // ---- K6 commit of res_bus (pandapower pfsoln/_extract_results) for envs whose solve was accepted:
+    // vm_pu = |V|, va = angle(V), p_mw/q_mvar = bus demand (-Sbus*sn) + shunt*|V|^2, slack = -(V conj(I))*sn
+    if (!d.commit[e]) return;
+    const int k = (int)blockIdx.y - npairs - nmb;  // elimination position, n == slack
+    const size_t o = (size_t)d.bus_of_pos[k] * S + e;
+    double v, P, Q;
+    if (k < d.n) {
+      const double* vo = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * k) * S + e;
+      const double2 sb = ((const double2*)((const char*)d.nrbuf + d.sb_off))[(size_t)d.sb_index[k] * S + e];
+      const double ek = vo[(size_t)VO_E * S], fk = vo[(size_t)VO_F * S];
+      v = sqrt(ek * ek + fk * fk);
+      d.va[o] = atan2(fk, ek);
+      P = -sb.x * d.sn; Q = -sb.y * d.sn;
+    } else {
+      v = d.vroot; d.va[o] = 0.0;
+      double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;     // I = Y_rr V_r + sum_neighbours Y_rk V_k
+      for (int j = 0; j < d.n_root_children; ++j) {
+        const double* cb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * d.root_children[j]) * S + e;
+        const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ec = cb[(size_t)VO_E * S], fc = cb[(size_t)VO_F * S];
+        ir += g * ec - b * fc; ii += g * fc + b * ec;
+      }
+      P = -(d.vroot * ir) * d.sn; Q = (d.vroot * ii) * d.sn;
+    }
+    d.vm[o] = v;
+    d.res_p[o] = P + d.shunt_p[k] * v * v; d.res_q[o] = Q + d.shunt_q[k] * v * v;
+    return;
+  }
   const int64_t row = d.adv_row[e];
   if (row < 0 || row >= d.T) return;               // never read outside the table
   const uint32_t draw = d.adv_draw[e];
@@ -552,10 +582,12 @@ int nr_geometry_compiled(int waves, int lanes, int h_lds, int g_lds, int rec_lds
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st) {
   hipLaunchKernelGGL(k_reset_begin, dim3((d.B + 255) / 256), dim3(256), 0, st, d, start_rows, first_try);
 }
-// next profile row + noise for the envs queued in adv_row
-void launch_advance(const Dev& d, int add_noise, uint32_t sb_write_off, hipStream_t st) {
-  const int rows = ((d.ns + 1) >> 1) + ((d.nl + 1) >> 1);
-  hipLaunchKernelGGL(k_advance, dim3((d.B + 255) / 256, rows), dim3(256), 0, st, d, add_noise, sb_write_off);
+// do_profiles: next profile row + noise for the envs queued in adv_row; do_commit: res_bus commit of
+// the envs flagged by the preceding k_nr_tree launch
+void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off, hipStream_t st) {
+  const int rows = (do_profiles ? ((d.ns + 1) >> 1) + ((d.nl + 1) >> 1) : 0) + (do_commit ? d.nb : 0);
+  if (rows == 0) return;
+  hipLaunchKernelGGL(k_advance, dim3((d.B + 255) / 256, rows), dim3(256), 0, st, d, add_noise, do_profiles, do_commit, sb_write_off);
 }
 void launch_inject_sgen(const Dev& d, int mode, const void* actions, int dtype, int add_noise, hipStream_t st) {
   const dim3 grid((d.B + 255) / 256, d.n_sgb + d.n_mlo);

@@ -125,7 +125,7 @@ int nr_dense_prepare(const Dev& d);
 void launch_nr_dense(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
 int dense_solve_debug(const double* A, const double* b, double* x, int n, int batch, hipStream_t st);
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);
-void launch_advance(const Dev& d, int add_noise, uint32_t sb_write_off, hipStream_t st);
+void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off, hipStream_t st);
 void launch_gather(const Dev& d, const double* base, const int32_t* rows, const double* scales, double scale_all,
                    const int32_t* x_ptr, const int32_t* x_row, void* out, int dtype, int C, hipStream_t st);
 void launch_to_envminor(const Dev& d, const double* src, double* dst, int n, hipStream_t st);

@@ -78,28 +78,6 @@ __device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
   *c = fma(pc, z, 1.0);
 }
 
-// angle(V) = atan2(f, e) of a bus voltage.  Feeder voltages sit within a few degrees of the slack's: for e > 0 and |f| < 7/16 e the
-// angle is fdlibm's atan kernel for |x| < 7/16 (the 11-coefficient odd polynomial of s_atan.c, < 1 ulp) of the correctly rounded
-// quotient f / e — ~45 instructions instead of libm's ~150, which is what lets the res_bus commit live in the solver's epilogue.
-// Branch-free (loops over buses stay unrollable); `nr_angle_fast_ok` says whether the argument was in range, the caller redoes the
-// rare rest with libm's atan2 (nr_angle does both).
-__device__ __forceinline__ bool nr_angle_fast_ok(double f, double e) { return e > 0.0 && fabs(f) < 0.4375 * e; }
-__device__ __forceinline__ double nr_angle_fast(double f, double e) {
-  const double x = f / e;
-  const double z = x * x, w = z * z;
-  const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
-                    w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
-  const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
-                    w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
-  return x - x * (s1 + s2);
-}
-__device__ __forceinline__ double nr_angle(double f, double e) {
-  double a = nr_angle_fast(f, e);
-  const bool slow = !nr_angle_fast_ok(f, e);
-  if (__any(slow)) { if (slow) a = atan2(f, e); }
-  return a;
-}
-
 // =================================================================== fused epilogue
 // The workgroup still holds the solution of its L envs in LDS (sV[k * L] = (e, f) of elimination position k, already
 // offset by the env's lane; position n = slack), so the rest of the env step happens here, spread over the workgroup's
@@ -127,7 +105,7 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
       double* o = gV + (size_t)(VOF * k) * SB;
       o[(size_t)VO_E * SB] = ek; o[(size_t)VO_F * SB] = fk;
       o[(size_t)VO_VM * SB] = sqrt(ek * ek + fk * fk);            // Vm = |V|
-      o[(size_t)VO_VA * SB] = nr_angle(fk, ek);                    // Va = angle(V)
+      o[(size_t)VO_VA * SB] = atan2(fk, ek);                       // Va = angle(V)
     }
     return;
   }
@@ -143,11 +121,10 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
   typedef const __attribute__((address_space(4))) double* c_f64;
   const c_i32 bus_of_pos = (c_i32)(unsigned long long)d.bus_of_pos;
   const c_f64 linec = (c_f64)(unsigned long long)d.lines;          // LineFlow = {int32 fpos, tpos; double y[8]} = 9 x 8 bytes
-  // ---- buses: voltage statistics for the reward and the res_bus commit (|V|, angle(V), p_mw, q_mvar) of the envs whose solve
-  // was accepted.  (Rounds 1-3 left the commit to the wide k_advance launch — 141 rows x B threads with libm's atan2, 6 us of a
-  // 13 us kernel; with the polynomial angle it is ~50 instructions per bus here and the wide launch shrinks to the profile rows.)
-  const c_f64 shunt_p = (c_f64)(unsigned long long)d.shunt_p, shunt_q = (c_f64)(unsigned long long)d.shunt_q;
-  const double2* gS = (const double2*)((const char*)d.nrbuf + d.sb_off) + e;   // the injection this solve used, by node
+  // ---- buses: voltage statistics for the reward; the solution (e, f) goes to Vout, from where the
+  // wide k_post kernel (thread per bus x env) commits res_bus — |V|, angle(V), p_mw, q_mvar — for the
+  // envs flagged in d.commit: throughput work does not belong in this 512-wave kernel
+  double* gV = d.nrbuf + (size_t)d.r_vout * SB + e;
   // this worker's first sgen q values (written by the inject kernel, cold in the cache): requested now, used after the two loops
   constexpr int QPRE = 3;
   double q_pre[QPRE];
@@ -155,7 +132,6 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
   for (int i = 0; i < QPRE; ++i) { const unsigned j = t + (unsigned)i * Wt; q_pre[i] = (j < (unsigned)d.ns) ? d.q_new[(size_t)j * SB + e] : 0.0; }
   // the barrier type is hoisted out of the loop (one branch-free instance per type), so that the unrolled
   // iterations — sqrt and exp chains of different buses — can be interleaved by the scheduler
-  bool slow_angle = false;                       // some committed bus of this worker is outside the fast angle's range (rare)
   auto bus_loop = [&](auto type_tag) {
     constexpr int BT = decltype(type_tag)::value;
 #pragma unroll 4
@@ -163,17 +139,7 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
       const d2 vv = sV[(size_t)k * L];
       const double ek = vv.x, fk = vv.y;
       const double v = sqrt(ek * ek + fk * fk);                      // res_bus.vm_pu = |V|
-      {   // K6 commit of res_bus: vm_pu = |V|, va = angle(V), p_mw / q_mvar = bus demand (-Sbus sn) + shunt |V|^2
-        const double2 sb = gS[(size_t)k * SB];
-        const double va = nr_angle_fast(fk, ek);
-        slow_angle = slow_angle || (commitf && !nr_angle_fast_ok(fk, ek));
-        if (commitf) {
-          const size_t o = (size_t)bus_of_pos[k] * SB + e;
-          const double P = -sb.x * d.sn, Q = -sb.y * d.sn;
-          d.vm[o] = v; d.va[o] = va;
-          d.res_p[o] = P + shunt_p[k] * v * v; d.res_q[o] = Q + shunt_q[k] * v * v;
-        }
-      }
+      if (commitf) { gV[((size_t)VOF * k + VO_E) * SB] = ek; gV[((size_t)VOF * k + VO_F) * SB] = fk; }
       n_lo += (v < vlo) ? 1.0 : 0.0; n_hi += (v > vhi) ? 1.0 : 0.0;
       dev += fabs(v - vref); vsum += v;
       mdrop = fmax(mdrop, (v < vlo) ? (vlo - v) : 0.0);
@@ -188,12 +154,6 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
     case MAPDN_BARRIER_BOWL: bus_loop(std::integral_constant<int, MAPDN_BARRIER_BOWL>{}); break;
     default: bus_loop(std::integral_constant<int, MAPDN_BARRIER_BUMP>{}); break;
   }
-  if (__any(slow_angle)) {                        // wave-uniform, rare: redo those angles with libm's atan2
-    for (unsigned k = t; k < n; k += Wt) {
-      const d2 vv = sV[(size_t)k * L];
-      if (commitf && !nr_angle_fast_ok(vv.y, vv.x)) d.va[(size_t)bus_of_pos[k] * SB + e] = atan2(vv.y, vv.x);
-    }
-  }
   if (t == n % Wt) {                              // the slack bus: committed voltage never changes
     const double v = vroot;
     n_lo += (v < vlo) ? 1.0 : 0.0; n_hi += (v > vhi) ? 1.0 : 0.0;
@@ -201,18 +161,6 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
     mdrop = fmax(mdrop, (v < vlo) ? (vlo - v) : 0.0);
     mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
     bar += barrier(d.barrier_type, v);
-    if (commitf) {                                // ... and its res_bus row: the slack injection -(V conj(I)) sn, I = Y_rr V_r + sum Y_rk V_k
-      double ir = d.yrr0 * vroot, ii = d.yrr1 * vroot;
-      for (int j = 0; j < d.n_root_children; ++j) {
-        const d2 vc = sV[(size_t)d.root_children[j] * L];
-        const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1];
-        ir += g * vc.x - b * vc.y; ii += g * vc.y + b * vc.x;
-      }
-      const size_t o = (size_t)bus_of_pos[n] * SB + e;
-      const double P = -(vroot * ir) * d.sn, Q = (vroot * ii) * d.sn;
-      d.vm[o] = v; d.va[o] = 0.0;
-      d.res_p[o] = P + shunt_p[n] * v * v; d.res_q[o] = Q + shunt_q[n] * v * v;
-    }
   }
   stamp(22);
   if (t == 0 && valid) d.commit[e] = commitf ? 1 : 0;

@@ -338,28 +338,3 @@ def test_tolerance_options(lib):
     for tuning, ok in ((None, True), (dict(tolerance_is_pu=1), True), (dict(tolerance_mva=1e-6), True), (dict(tolerance_mva=-1.0), False)):
         rc, g = _geometry(lib, net, 64, tuning)
         assert (rc == 0) == ok, g
-
-
-def test_fast_angle_polynomial_is_within_an_ulp_of_atan2():
-    """nr_common.hpp::nr_angle_fast — fdlibm's atan kernel for |x| < 7/16 on the quotient f / e — restated in numpy (same
-    association of the operations, no fused multiply-adds here) against numpy's arctan2 on the range the kernel uses it on:
-    feeder voltages 0.5 ... 1.3 p.u. within +-23.6 degrees of the slack.  Both are a few ulp of the angle at worst — 1e-15 rad —
-    against the 1e-9 the parity tests ask of va_degree."""
-    rng = np.random.default_rng(0)
-    mag = rng.uniform(0.5, 1.3, 2_000_000)
-    ang = rng.uniform(-0.41, 0.41, mag.size)
-    e, f = mag * np.cos(ang), mag * np.sin(ang)
-    ok = (e > 0) & (np.abs(f) < 0.4375 * e)
-    assert ok.mean() > 0.99
-    x = f / e
-    z = x * x
-    w = z * z
-    s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 + w * (
-        6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))))
-    s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 + w * (
-        -5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))))
-    a = x - x * (s1 + s2)
-    ref = np.arctan2(f, e)
-    err = np.abs(a - ref)[ok]
-    assert err.max() < 4.5e-16, err.max()
-    assert (err[np.abs(ref[ok]) > 1e-3] / np.abs(ref[ok])[np.abs(ref[ok]) > 1e-3]).max() < 3 * 2.3e-16
