@@ -302,19 +302,20 @@ __global__ void __launch_bounds__(256) k_reset_begin(Dev d, const int64_t* __res
 //      write the buffer of the next solve (`sb_write_off`: the other one in step(), the same one in reset(), where the
 //      advance comes before the solve); the host flips the buffers after every step.
 // =================================================================================================
-__global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void advance_body(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off,
+                                             unsigned blk_x, unsigned blk_y) {
+  const int e = (int)(blk_x * 256u + threadIdx.x);
   if (e >= d.B) return;
   const int npv = (d.ns + 1) >> 1, npl = (d.nl + 1) >> 1;
   const int npairs = do_profiles ? npv + npl : 0;
   const int nmb = 0;
   const size_t S = (size_t)d.Bp;
   double2* const sbw = (double2*)((char*)d.nrbuf + sb_write_off) + e;
-  if ((int)blockIdx.y >= npairs + nmb) {
+  if ((int)blk_y >= npairs + nmb) {
     // ---- K6 commit of res_bus (pandapower pfsoln/_extract_results) for envs whose solve was accepted:
     // vm_pu = |V|, va = angle(V), p_mw/q_mvar = bus demand (-Sbus*sn) + shunt*|V|^2, slack = -(V conj(I))*sn
     if (!d.commit[e]) return;
-    const int k = (int)blockIdx.y - npairs - nmb;  // elimination position, n == slack
+    const int k = (int)blk_y - npairs - nmb;  // elimination position, n == slack
     const size_t o = (size_t)d.bus_of_pos[k] * S + e;
     double v, P, Q;
     if (k < d.n) {
@@ -352,7 +353,7 @@ __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_pr
     sincos(2.0 * M_PI * u2, &sn_, &cs_);
     n0 = fabs(r * cs_); n1 = fabs(r * sn_);
   };
-  int b = blockIdx.y;                              // pair index over [pv pairs | load pairs]
+  int b = (int)blk_y;                              // pair index over [pv pairs | load pairs]
   if (b < npv) {
     const int j0 = 2 * b, j1 = 2 * b + 1;
     const double* trow = d.table + (size_t)row * d.ncol;
@@ -396,6 +397,10 @@ __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_pr
   if (has1) put(j1, p1, q1);
 }
 
+__global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off) {
+  advance_body(d, add_noise, do_profiles, do_commit, sb_write_off, blockIdx.x, blockIdx.y);
+}
+
 // =================================================================================================
 // K8  observe — get_obs (voltage_control_env.py:232-274) / get_state (:213-230).
 //     The effective PV add-back onto res_bus p/q at sgen buses (:238-244) is a per-column list of
@@ -406,10 +411,9 @@ __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_pr
 // =================================================================================================
 #define GATHER_HAS_EXTRA 0x40000000   // flag bit in a row descriptor: the column has add-back rows (x_ptr/x_row)
 template <typename T>
-__global__ void __launch_bounds__(256)
-k_gather(const double* __restrict__ base, const int32_t* rows_g, const double* scales_g,
-         double scale_all, const int32_t* x_ptr_g, const int32_t* x_row_g,
-         T* __restrict__ out, int C, int B, int Bp) {
+__device__ __forceinline__ void gather_body(const double* __restrict__ base, const int32_t* rows_g, const double* scales_g,
+                                            double scale_all, const int32_t* x_ptr_g, const int32_t* x_row_g,
+                                            T* __restrict__ out, int C, int B, int Bp, unsigned blk_x, unsigned blk_y, unsigned grd_x, unsigned grd_y) {
   __shared__ T tile[64][65];                      // output-typed tile: 16.6 KB for f32 -> 8 workgroups per CU
   // descriptors are wave-uniform (a wave handles whole columns): read them through the constant
   // address space -> s_load on the scalar unit, no VMEM round trip ahead of the data loads
@@ -420,10 +424,10 @@ k_gather(const double* __restrict__ base, const int32_t* rows_g, const double* s
   // XCD-aware tile order: consecutive workgroups land on consecutive XCDs (block b on XCD b % 8, observed; only speed depends
   // on it), and a source row of 64 envs is read by every column tile whose zones contain that bus (2.4 of them on average) —
   // so all column tiles of an env tile go to ONE XCD, whose L2 then serves the re-reads: XCD k takes env tiles k, k + 8, ...
-  unsigned bx = blockIdx.x, by = blockIdx.y;
-  if ((gridDim.y & 7u) == 0u) {
-    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7u, slot = lin >> 3;
-    by = (slot / gridDim.x) * 8u + xcd; bx = slot % gridDim.x;
+  unsigned bx = blk_x, by = blk_y;
+  if ((grd_y & 7u) == 0u) {
+    const unsigned lin = blk_y * grd_x + blk_x, xcd = lin & 7u, slot = lin >> 3;
+    by = (slot / grd_x) * 8u + xcd; bx = slot % grd_x;
   }
   const int c0 = (int)bx * 64, e0 = (int)by * 64;
   const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -465,6 +469,34 @@ k_gather(const double* __restrict__ base, const int32_t* rows_g, const double* s
     }
   }
 }
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_gather(const double* __restrict__ base, const int32_t* rows_g, const double* scales_g,
+         double scale_all, const int32_t* x_ptr_g, const int32_t* x_row_g,
+         T* __restrict__ out, int C, int B, int Bp) {
+  gather_body<T>(base, rows_g, scales_g, scale_all, x_ptr_g, x_row_g, out, C, B, Bp, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+
+#ifdef MAPDN_EXP_MERGED_POST
+// TIMING EXPERIMENT ONLY (wrong results: the gather tiles do not wait for the commit rows): the advance rows and the obs gather tiles
+// of one step as ONE launch, to measure what two latency-bound wide kernels cost when they overlap instead of running back to back
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_post_merged(Dev d, int add_noise, uint32_t sb_write_off, unsigned adv_gx, unsigned adv_gy, const double* __restrict__ base,
+              const int32_t* rows_g, const double* scales_g, const int32_t* x_ptr_g, const int32_t* x_row_g, T* __restrict__ out, int C,
+              unsigned g_gx, unsigned g_gy) {
+  const unsigned na = adv_gx * adv_gy;
+  if (blockIdx.x < na) advance_body(d, add_noise, 1, 1, sb_write_off, blockIdx.x % adv_gx, blockIdx.x / adv_gx);
+  else { const unsigned l = blockIdx.x - na; gather_body<T>(base, rows_g, scales_g, 1.0, x_ptr_g, x_row_g, out, C, d.B, d.Bp, l % g_gx, l / g_gx, g_gx, g_gy); }
+}
+void launch_post_merged(const Dev& d, int add_noise, uint32_t sb_write_off, const double* base, const int32_t* rows, const double* scales,
+                        const int32_t* x_ptr, const int32_t* x_row, void* out, int C, hipStream_t st) {
+  const unsigned agx = (d.B + 255) / 256, agy = ((d.ns + 1) >> 1) + ((d.nl + 1) >> 1) + d.nb, ggx = (C + 63) / 64, ggy = d.Bp / 64;
+  hipLaunchKernelGGL(k_post_merged<float>, dim3(agx * agy + ggx * ggy), dim3(256), 0, st, d, add_noise, sb_write_off, agx, agy, base, rows, scales,
+                     x_ptr, x_row, (float*)out, C, ggx, ggy);
+}
+#endif
 
 // env-major [B, n] -> env-minor [n][Bp] (zero-fills the pad lanes)
 __global__ void __launch_bounds__(256)
