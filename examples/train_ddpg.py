@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--update-freq", type=int, default=60)
     ap.add_argument("--voltage-barrier", default="bowl")
     ap.add_argument("--save", default=None)
+    ap.add_argument("--phases", action="store_true", help="per-phase device time of every episode in the JSON line (CUDA events around "
+                                                         "replay insertion / sampling / value update / policy update / target update; rollout = the rest)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
@@ -80,6 +82,7 @@ def main():
                          behaviour_update_freq=a.update_freq, target_update_freq=2 * a.update_freq, num_eval_episodes=a.envs,
                          value_update_epochs=v_ep, policy_update_epochs=p_ep)
     trainer = PGTrainer(args, a.alg, env, device=dev)
+    trainer.profile_phases = a.phases
     for ep in range(a.episodes):
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -94,6 +97,11 @@ def main():
                     "env_steps_per_s": world * a.envs * a.max_steps / dt, "seconds": dt,
                     "replay_transitions": len(trainer.replay_buffer),
                     "hbm_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+            if a.phases:
+                ph = trainer.phase_seconds()
+                ph["rollout_and_host"] = dt - sum(ph.values())
+                line["phase_seconds"] = {k: round(v, 4) for k, v in ph.items()}
+                line["phase_share"] = {k: round(v / dt, 4) for k, v in ph.items()}
             line.update({k: v for k, v in stat.items() if k in (
                 "mean_train_reward", "mean_train_value_loss", "mean_train_policy_loss", "mean_train_totally_controllable_ratio",
                 "mean_train_q_loss")})

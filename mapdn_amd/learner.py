@@ -471,23 +471,66 @@ class PGTrainer:
             stat["mean_train_entropy"] = entropy.detach()
         self._apply(self.policy_optimizer, policy_loss, stat, "policy")
 
+    # ---- optional per-phase device timing of an episode (examples/train_ddpg.py --phases): CUDA events on the current stream around
+    # replay insertion, batch sampling, the value / policy updates and the target update; the rollout is the rest of the episode
+    profile_phases = False
+
+    class _Phase:
+        def __init__(self, trainer, name):
+            self.t, self.name = trainer, name
+
+        def __enter__(self):
+            if self.t.profile_phases and self.t.device.type == "cuda":
+                self.a = torch.cuda.Event(enable_timing=True); self.b = torch.cuda.Event(enable_timing=True)
+                self.a.record()
+            return self
+
+        def __exit__(self, *exc):
+            if self.t.profile_phases and self.t.device.type == "cuda":
+                self.b.record()
+                self.t._phase_events.append((self.name, self.a, self.b))
+
+    def _phase(self, name):
+        if not hasattr(self, "_phase_events"):
+            self._phase_events = []
+        return PGTrainer._Phase(self, name)
+
+    def phase_seconds(self):
+        """{phase: seconds} accumulated since the last call (synchronises); empty unless profile_phases"""
+        out = {}
+        ev = getattr(self, "_phase_events", [])
+        if ev:
+            torch.cuda.synchronize(self.device)
+            for name, a, b in ev:
+                out[name] = out.get(name, 0.0) + a.elapsed_time(b) * 1e-3
+            ev.clear()
+        return out
+
     def value_replay_process(self, stat):
-        self.value_transition_process(stat, self.replay_buffer.get_batch(self.args.batch_size))
+        with self._phase("sample"):
+            batch = self.replay_buffer.get_batch(self.args.batch_size)
+        with self._phase("value_update"):
+            self.value_transition_process(stat, batch)
 
     def policy_replay_process(self, stat):
-        self.policy_transition_process(stat, self.replay_buffer.get_batch(self.args.batch_size))
+        with self._phase("sample"):
+            batch = self.replay_buffer.get_batch(self.args.batch_size)
+        with self._phase("policy_update"):
+            self.policy_transition_process(stat, batch)
 
     def transition_update(self, trans: Batch, stat):
         """models/model.py:39-70 with replay=True, mixer=False"""
         a = self.args
-        self.replay_buffer.add_experience(trans)
+        with self._phase("replay_insert"):
+            self.replay_buffer.add_experience(trans)
         if self.steps > a.replay_warmup and len(self.replay_buffer) >= a.batch_size and self.steps % a.behaviour_update_freq == 0:
             for _ in range(a.value_update_epochs):
                 self.value_replay_process(stat)
             for _ in range(a.policy_update_epochs):
                 self.policy_replay_process(stat)
         if a.target and self.steps % a.target_update_freq == 0:
-            self.behaviour_net.update_target()
+            with self._phase("target_update"):
+                self.behaviour_net.update_target()
 
     # ---- rollouts (models/model.py:197-302): episodes run through the package's one rollout loop (rollout.BatchedRollout) ----
     def _episode(self, stat, train: bool):
