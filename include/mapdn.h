@@ -125,7 +125,8 @@ typedef struct mapdn_env_config {
    * field has an environment-variable override that is read once, inside mapdn_create (named per field). */
   int32_t nr_solver;                /* 0 auto: tree kernel (k_nr_tree) for radial feeders, sparse block program (k_nr_sparse)
                                        for meshed nets; 1: k_nr_sparse on a radial net too (cross-checks); 2: k_nr_dense, the
-                                       LDS-resident dense LU with f64 MFMA trailing updates (<= 65 buses, any topology).
+                                       dense LU with f64 MFMA trailing updates (any topology; the Jacobian LDS-resident up to 65 buses,
+                                       in per-env slabs of global memory up to 513 buses — an exhibit, not a fast path).
                                        env: MAPDN_NR_SPARSE=1 / MAPDN_NR_DENSE=1                                         */
   int32_t nr_waves;                 /* k_nr_tree: waves per workgroup, 0 auto | 1 | 2 | 4              env: MAPDN_NR_WAVES */
   int32_t nr_lanes;                 /* k_nr_tree: envs per workgroup,  0 auto | 8 | 16 | 32            env: MAPDN_NR_LANES
@@ -301,7 +302,8 @@ int mapdn_get_flat_factors(const mapdn_handle* h, double* factors, int32_t* bus_
 int mapdn_get_sparse_program(const mapdn_handle* h, int32_t sub_lanes, int32_t* dims, int32_t* ops, int32_t* order, int32_t* slots_ij);
 
 /* Debug / pin export of the general solver's linear algebra: solves `batch` independent dense systems A x = b
- * (device pointers; A row-major [batch, n, n], b and x [batch, n]; n even, <= 128) with the LDS-resident blocked LU
+ * (device pointers; A row-major [batch, n, n], b and x [batch, n]; n even, <= 1024; LDS-resident up to n = 128, in global scratch —
+ * synchronous — beyond) with the blocked LU
  * (2x2 block pivots, v_mfma_f64_16x16x4_f64 trailing updates) that k_nr_dense runs on the Jacobian — what pandapower
  * does with SuperLU in pypower/newtonpf.py (dx = -spsolve(J, F)).  Tests compare with numpy.linalg.solve. */
 int mapdn_dense_solve(const double* a, const double* b, double* x, int32_t n, int32_t batch, void* stream);

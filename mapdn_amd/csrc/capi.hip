@@ -256,7 +256,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     const bool want_dense = pick == 2;
     const bool want_sparse = !want_dense && (pick == 1 || !P0.radial);
     if (want_dense) {
-      if (2 * P0.n > 128) { h->err = "nr_solver = dense (MAPDN_NR_DENSE): the dense general-topology solver handles at most 65 buses"; return MAPDN_E_TOPOLOGY; }
+      if (2 * P0.n > 1024) { h->err = "nr_solver = dense (MAPDN_NR_DENSE): the dense general-topology solver handles at most 513 buses (one thread per Jacobian row)"; return MAPDN_E_TOPOLOGY; }
       h->solver = 2;
     } else if (want_sparse) {
       SparseProg g0;
@@ -437,6 +437,10 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   // ---- general-topology paths (see the solver choice above)
   if (h->solver == 2) {                           // k_nr_dense (dense.hip): one env per workgroup, dense Jacobian in LDS, f64 MFMA
     d.dense = 1; d.dn_N = (2 * P.n + 15) / 16 * 16; d.dn_lda = d.dn_N + 2;
+    if (d.dn_N > 128) {                            // beyond 65 buses the Jacobian of every env lives in a slab of global memory
+      const size_t per_env = (size_t)d.dn_N * d.dn_lda;
+      rc = dalloc(h, &d.dn_A, per_env * d.Bp); if (rc) return rc;
+    }
     UP(gy_ptr, P.gy_ptr); UP(gy_col, P.gy_col); UP(gy_val, P.gy_val);
     std::vector<int32_t> sbi(P.n);
     for (int k = 0; k < P.n; ++k) sbi[k] = k;

@@ -12,7 +12,12 @@
 // whatever the R/X ratio, while a scalar pivot -Q - B|V|^2 vanishes on a purely resistive line.
 //
 // LDS: A[N][LDA] (N = 2n rounded up to 16, identity on the padding) | rhs[N] | dinv[N/2][4] | V pairs [n+2] | epilogue
-// partials.  N <= 128, i.e. nets of at most 65 buses; larger meshed nets are refused at mapdn_create.
+// partials.  N <= 128 (nets of at most 65 buses) keeps the Jacobian LDS-resident.  Round 4: beyond that — the 141- and 322-bus
+// MAPDN shapes, N = 288 / 656 — the same blocked LU runs with the Jacobian of every env in its own slab of GLOBAL memory
+// (`GA` instantiations, one thread per row: 64 W >= N, up to 1024 threads): the panel, U12 and trailing tiles stream through
+// L1 / L2 / HBM instead of LDS (`double*` is a flat pointer: dense_lu_solve is the same code), right-hand side, pivot inverses and
+// voltages stay in LDS.  It is an exhibit of the one true contraction on this path at the sizes north_star names, not a fast
+// path: a factorisation moves ~2/3 N^3 / 16 x 24 bytes through the memory system.
 // After the solve the workgroup runs the same fused epilogue as the radial kernel (nr_common.hpp).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -139,11 +144,11 @@ __device__ __forceinline__ void dense_lu_solve(double* A, double* rhs, double* d
   __syncthreads();
 }
 
-static inline __host__ __device__ size_t dense_lds_doubles(int N, int LDA, int n, int tpb) {
-  return (size_t)N * LDA + (size_t)N + (size_t)2 * N + (size_t)2 * (n + 2) + (size_t)10 * tpb;
+static inline __host__ __device__ size_t dense_lds_doubles(int N, int LDA, int n, int tpb, bool global_a = false) {
+  return (global_a ? 0 : (size_t)N * LDA) + (size_t)N + (size_t)2 * N + (size_t)2 * (n + 2) + (size_t)10 * tpb;
 }
 
-template <int W>
+template <int W, bool GA>
 __global__ void __launch_bounds__(64 * W)
 k_nr_dense(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ terminated, double* __restrict__ info) {
   extern __shared__ double lds[];
@@ -151,10 +156,10 @@ k_nr_dense(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
   const int tid = (int)threadIdx.x;
   const unsigned e = blockIdx.x;
   const int n = d.n, N = d.dn_N, LDA = d.dn_lda;
-  double* A = lds;
-  double* rhs = A + (size_t)N * LDA;
+  double* A = GA ? d.dn_A + (size_t)e * N * LDA : lds;      // GA: this env's slab of the global Jacobian scratch
+  double* rhs = GA ? lds : A + (size_t)N * LDA;
   double* dinv = rhs + N;
-  d2* sV = (d2*)(dinv + 2 * N);                   // (N * LDA + 3 N is even: 16-byte aligned)
+  d2* sV = (d2*)(dinv + 2 * N);                   // (N * LDA + 3 N and 3 N are even: 16-byte aligned)
   double* s_epi = (double*)(sV + (n + 2));
   const double vroot = d.vroot, tol = d.tol;
   for (int k = tid; k < n + 2; k += TPB) sV[k] = d2{vroot, 0.0};     // runpp init="auto": flat start at the slack set-point
@@ -239,16 +244,16 @@ k_nr_dense(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ t
 
 // debug / pin entry: solve `batch` dense systems (row-major n x n, n even) with the kernel's own LU — tests compare with
 // numpy.linalg.solve (tests/test_gpu_parity.py::test_dense_lu_matches_numpy)
-template <int W>
+template <int W, bool GA>
 __global__ void __launch_bounds__(64 * W) k_dense_solve(const double* __restrict__ Ain, const double* __restrict__ bin,
-                                                       double* __restrict__ xout, int n, int N, int LDA) {
+                                                       double* __restrict__ xout, int n, int N, int LDA, double* __restrict__ scratch) {
   extern __shared__ double lds[];
   constexpr int TPB = 64 * W;
-  double* A = lds;
-  double* rhs = A + (size_t)N * LDA;
+  const size_t s = blockIdx.x;
+  double* A = GA ? scratch + s * (size_t)N * LDA : lds;
+  double* rhs = GA ? lds : A + (size_t)N * LDA;
   double* dinv = rhs + N;
   const int tid = (int)threadIdx.x;
-  const size_t s = blockIdx.x;
   for (int i = tid; i < N * LDA; i += TPB) A[i] = 0.0;
   __syncthreads();
   for (int i = tid; i < n * n; i += TPB) A[(size_t)(i / n) * LDA + i % n] = Ain[s * n * n + i];
@@ -261,40 +266,77 @@ __global__ void __launch_bounds__(64 * W) k_dense_solve(const double* __restrict
   for (int i = tid; i < n; i += TPB) xout[s * n + i] = rhs[i];
 }
 
+// waves per workgroup: one thread per matrix row.  LDS-resident Jacobian: N <= 64 -> 1, <= 128 -> 2; global Jacobian: the
+// instantiated W >= N / 64
+static const int DENSE_GA_W[] = {3, 4, 5, 6, 8, 11, 13, 16};
+static int dense_waves(const Dev& d) {
+  if (!d.dn_A) return d.dn_N <= 64 ? 1 : 2;
+  for (int w : DENSE_GA_W) if (64 * w >= d.dn_N) return w;
+  return 0;
+}
 size_t nr_dense_lds_bytes(const Dev& d) {
-  const int W = d.dn_N <= 64 ? 1 : 2;
-  return dense_lds_doubles(d.dn_N, d.dn_lda, d.n, 64 * W) * sizeof(double);
+  const int W = dense_waves(d);
+  return dense_lds_doubles(d.dn_N, d.dn_lda, d.n, 64 * W, d.dn_A != nullptr) * sizeof(double);
 }
 
 // dynamic LDS limit of k_nr_dense: the CU's 160 KB minus the 256 bytes of static LDS that __syncthreads_and's
 // cross-wave reduction allocates (asking for all 160 KB makes hipFuncSetAttribute fail with invalid value)
 static constexpr size_t DENSE_LDS_MAX = 160 * 1024 - 256;
 
+#define DENSE_GA_FOR_EACH(X) X(3) X(4) X(5) X(6) X(8) X(11) X(13) X(16)
+static const void* dense_fn(const Dev& d) {
+  const int W = dense_waves(d);
+  if (!d.dn_A) return W == 1 ? (const void*)k_nr_dense<1, false> : (const void*)k_nr_dense<2, false>;
+#define X(w) if (W == w) return (const void*)k_nr_dense<w, true>;
+  DENSE_GA_FOR_EACH(X)
+#undef X
+  return nullptr;
+}
+
 int nr_dense_prepare(const Dev& d) {
   const size_t lds = nr_dense_lds_bytes(d);
-  if (d.dn_N > 128 || lds > DENSE_LDS_MAX) return -2;
-  const void* f = d.dn_N <= 64 ? (const void*)k_nr_dense<1> : (const void*)k_nr_dense<2>;
+  const void* f = dense_fn(d);
+  if (!f || (!d.dn_A && d.dn_N > 128) || lds > DENSE_LDS_MAX) return -2;
   return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DENSE_LDS_MAX) == hipSuccess ? 0 : -1;
 }
 
 void launch_nr_dense(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st) {
   const size_t lds = nr_dense_lds_bytes(d);
-  if (d.dn_N <= 64) hipLaunchKernelGGL(k_nr_dense<1>, dim3(d.Bp), dim3(64), lds, st, d, mode, reward, term, info);
-  else hipLaunchKernelGGL(k_nr_dense<2>, dim3(d.Bp), dim3(128), lds, st, d, mode, reward, term, info);
+  const void* f = dense_fn(d);
+  if (!f) return;
+  Dev dd = d;
+  void* args[] = {(void*)&dd, (void*)&mode, (void*)&reward, (void*)&term, (void*)&info};
+  (void)hipLaunchKernel(f, dim3(d.Bp), dim3(64 * dense_waves(d)), args, lds, st);
 }
 
 int dense_solve_debug(const double* A, const double* b, double* x, int n, int batch, hipStream_t st) {
-  if (n < 2 || (n & 1) || n > 128 || batch < 1) return -1;
+  if (n < 2 || (n & 1) || n > 1024 || batch < 1) return -1;
   const int N = (n + 15) / 16 * 16, LDA = N + 2;
-  const size_t lds = ((size_t)N * LDA + 3 * (size_t)N) * sizeof(double);
-  if (N <= 64) {
-    if (hipFuncSetAttribute((const void*)k_dense_solve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
-    hipLaunchKernelGGL(k_dense_solve<1>, dim3(batch), dim3(64), lds, st, A, b, x, n, N, LDA);
-  } else {
-    if (hipFuncSetAttribute((const void*)k_dense_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
-    hipLaunchKernelGGL(k_dense_solve<2>, dim3(batch), dim3(128), lds, st, A, b, x, n, N, LDA);
+  if (N <= 128) {
+    const size_t lds = ((size_t)N * LDA + 3 * (size_t)N) * sizeof(double);
+    const void* f = N <= 64 ? (const void*)k_dense_solve<1, false> : (const void*)k_dense_solve<2, false>;
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+    double* none = nullptr;
+    void* args[] = {(void*)&A, (void*)&b, (void*)&x, (void*)&n, (void*)&N, (void*)&LDA, (void*)&none};
+    if (hipLaunchKernel(f, dim3(batch), dim3(N <= 64 ? 64 : 128), args, lds, st) != hipSuccess) return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
   }
-  return hipGetLastError() == hipSuccess ? 0 : -2;
+  // the matrix in global memory (the form k_nr_dense uses beyond 65 buses); synchronous: the scratch is freed on return
+  int W = 0;
+  for (int w : DENSE_GA_W) if (64 * w >= N) { W = w; break; }
+  if (!W) return -1;
+  double* scratch = nullptr;
+  if (hipMalloc((void**)&scratch, (size_t)batch * N * LDA * sizeof(double)) != hipSuccess) return -2;
+  const void* f = nullptr;
+#define X(w) if (W == w) f = (const void*)k_dense_solve<w, true>;
+  DENSE_GA_FOR_EACH(X)
+#undef X
+  const size_t lds = (3 * (size_t)N) * sizeof(double);
+  void* args[] = {(void*)&A, (void*)&b, (void*)&x, (void*)&n, (void*)&N, (void*)&LDA, (void*)&scratch};
+  int rc = hipLaunchKernel(f, dim3(batch), dim3(64 * W), args, lds, st) == hipSuccess ? 0 : -2;
+  if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) rc = -2;
+  (void)hipFree(scratch);
+  return rc;
 }
 
 }  // namespace mapdn

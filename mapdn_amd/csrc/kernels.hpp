@@ -83,6 +83,7 @@ struct Dev {
   int32_t sparse, sp_lanes, sp_blocks, sp_fill, sp_phases, sp_rows_per_sub, sp_max_nnz;
   const SpOp* sp_ops; uint32_t sp_ops_bytes; const SpNz* sp_nz; uint32_t sp_nz_bytes; const int32_t* sp_fill_slots;
   int32_t dense, dn_N, dn_lda;
+  double* dn_A;              // k_nr_dense beyond 65 buses: per-env slabs [Bp][dn_N][dn_lda] of global memory for the Jacobian (else nullptr: LDS)
   const int32_t *gy_ptr, *gy_col; const double* gy_val;
   // ---- PV-bus injection fused into the k_nr_tree prologue (step(), handles without auto_reset): per launch, set by launch_nr.
   // sgb_rec [n_sgb + n_mlo][8] = Sbus entry of the bus (-1: slack bus, q only) | elimination position | first sgen on the bus (-1:

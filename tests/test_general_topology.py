@@ -88,9 +88,14 @@ def test_large_meshed_nets_are_accepted_and_disconnected_ones_refused_loudly(mon
     lib, h, rc, keep = host_handle(meshed)                  # general sparse solver: any meshed net whose blocks fit in LDS
     assert rc == 0, lib.mapdn_last_error(None)
     lib.mapdn_destroy(h)
-    monkeypatch.setenv("MAPDN_NR_DENSE", "1")               # the dense MFMA solver keeps one env's Jacobian in LDS: <= 65 buses
-    lib, h, rc, keep = host_handle(meshed)
-    assert rc == _lib_E_TOPOLOGY and b"65 buses" in lib.mapdn_last_error(None)
+    monkeypatch.setenv("MAPDN_NR_DENSE", "1")               # the dense MFMA solver: Jacobian in LDS up to 65 buses, in global memory
+    lib, h, rc, keep = host_handle(meshed)                  # (one thread per row) up to 513
+    assert rc == 0, lib.mapdn_last_error(None)
+    lib.mapdn_destroy(h)
+    from mapdn_amd.netspec import _radial_case
+    huge, _ = _radial_case("rand601", 601, 300, 20, 10, 21, 12.47, 10.0, 10.0, 5, 0.05)
+    lib, h, rc, keep = host_handle(huge)
+    assert rc == _lib_E_TOPOLOGY and b"513 buses" in lib.mapdn_last_error(None)
     monkeypatch.delenv("MAPDN_NR_DENSE")
     island = net.copy(); island.line_in_service[3] = 0
     lib, h, rc, keep = host_handle(island)
@@ -132,9 +137,10 @@ gpu = pytest.mark.gpu
 
 
 @gpu
-@pytest.mark.parametrize("n", [2, 14, 16, 30, 32, 48, 64, 66, 96, 126, 128])
+@pytest.mark.parametrize("n", [2, 14, 16, 30, 32, 48, 64, 66, 96, 126, 128, 130, 280, 322, 642])
 def test_dense_lu_matches_numpy(n):
-    """the kernel's LDS-resident blocked LU (2x2 block pivots, f64 MFMA trailing updates) against numpy.linalg.solve;
+    """(n > 128: the same LU on a matrix in global memory — one thread per row, up to 11 waves — as k_nr_dense runs beyond 65 buses)
+    the kernel's LDS-resident blocked LU (2x2 block pivots, f64 MFMA trailing updates) against numpy.linalg.solve;
     includes matrices whose scalar diagonal is ZERO (rotation-like bus blocks: only a block pivot survives) and an
     asymmetric identity-like case that would expose a swapped MFMA fragment layout"""
     import torch
@@ -185,16 +191,17 @@ def _meshed(which):
 @gpu
 @pytest.mark.parametrize("solver,which", [("sparse", w) for w in ["case33_tie1", "case33_tie5", "case141_ties", "case322_ties", "big1", "big2", "big3"]
                                           + [f"rand{s}" for s in range(8)]]
-                         + [("dense", w) for w in ["case33_tie1", "case33_tie5"] + [f"rand{s}" for s in range(8)]])
+                         + [("dense", w) for w in ["case33_tie1", "case33_tie5", "case141_ties", "case322_ties", "big2"] + [f"rand{s}" for s in range(8)]])
 def test_meshed_solve_matches_oracle(solver, which, monkeypatch):
     """both general-topology solvers — the sparse block program (default for meshed nets, any size that fits LDS) and the
-    dense LU with f64 MFMA (MAPDN_NR_DENSE=1, <= 65 buses) — against the oracle's SuperLU Newton"""
+    dense LU with f64 MFMA (MAPDN_NR_DENSE=1; Jacobian in LDS up to 65 buses, in global memory beyond: the 141- / 322-bus nets) —
+    against the oracle's SuperLU Newton"""
     import torch
     from mapdn_amd.env import VoltageControlBatch
     net, prof = _meshed(which)
     if solver == "dense":
         monkeypatch.setenv("MAPDN_NR_DENSE", "1")
-    B = 70
+    B = 70 if not (solver == "dense" and net.n_bus > 65) else 24
     a = dict(episode_limit=240, action_scale=0.8, action_bias=0.0, voltage_barrier_type="l2", seed=1)
     env = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0", obs_dtype=torch.float64)
     assert not env.is_radial
@@ -214,7 +221,7 @@ def test_meshed_solve_matches_oracle(solver, which, monkeypatch):
 
 @gpu
 @pytest.mark.parametrize("solver,case", [("MAPDN_NR_DENSE", "case33"), ("MAPDN_NR_SPARSE", "case33"), ("MAPDN_NR_SPARSE", "case141"),
-                                         ("MAPDN_NR_SPARSE", "case322")])
+                                         ("MAPDN_NR_SPARSE", "case322"), ("MAPDN_NR_DENSE", "case141"), ("MAPDN_NR_DENSE", "case322")])
 def test_general_solvers_equal_the_tree_solver_on_radial_feeders(solver, case, monkeypatch):
     """MAPDN_NR_DENSE=1 / MAPDN_NR_SPARSE=1 force a general solver onto a radial feeder: same Newton iterates as the tree
     elimination (a tree has no fill: the sparse program is then the tree elimination in minimum-degree order)"""
@@ -222,7 +229,7 @@ def test_general_solvers_equal_the_tree_solver_on_radial_feeders(solver, case, m
     from mapdn_amd.env import VoltageControlBatch
     net, prof = make_case(case)
     a = dict(episode_limit=240, action_scale=0.8, action_bias=0.0, voltage_barrier_type="bowl", seed=0)
-    B = 130
+    B = 130 if not (solver == "MAPDN_NR_DENSE" and net.n_bus > 65) else 40
     ins = _solve_inputs(net, prof, B, 9)
     tree = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0")
     rt = [t.cpu().numpy() for t in tree.solve(*ins)]
@@ -237,7 +244,7 @@ def test_general_solvers_equal_the_tree_solver_on_radial_feeders(solver, case, m
 
 @gpu
 @pytest.mark.parametrize("solver,which", [("sparse", "case33_tie5"), ("sparse", "rand2"), ("sparse", "case141_ties"), ("sparse", "big2"),
-                                          ("dense", "case33_tie5"), ("dense", "rand5")])
+                                          ("dense", "case33_tie5"), ("dense", "rand5"), ("dense", "case141_ties")])
 def test_meshed_env_episode_matches_the_oracle_env(solver, which, monkeypatch):
     """the whole step (inject -> general solve -> fused reward epilogue -> commit -> obs) on a meshed net"""
     import torch

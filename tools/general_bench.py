@@ -2,7 +2,8 @@
 """General-topology solvers on meshed nets: env-steps/s of step()+get_obs() and the solver kernel's time.
   default          : k_nr_sparse (host-compiled block elimination program) — case33 with the Baran-Wu ties closed, or
                      case141 / case322 with a few tie lines added (--case, --ties)
-  MAPDN_NR_DENSE=1 : k_nr_dense (dense LU with f64 MFMA, <= 65 buses) + the MFMA share of its LU; profile with
+  MAPDN_NR_DENSE=1 : k_nr_dense (dense LU with f64 MFMA; Jacobian in LDS up to 65 buses, in global memory beyond) + the MFMA
+                     share of its LU; profile with
       rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES -- python tools/general_bench.py
   --ties 0 with MAPDN_NR_SPARSE=1 / MAPDN_NR_DENSE=1: a general solver forced onto the radial feeder (vs the tree kernel)"""
 import argparse, json, os, sys, time
@@ -30,7 +31,7 @@ env = VoltageControlBatch(net, prof, dict(episode_limit=240, action_scale=scale,
                           n_envs=a.envs, device="cuda:0")
 acts = torch.empty(64, a.envs, env.n_sgen, device="cuda:0").uniform_(-scale, scale)
 env.reset()
-for t in range(10):
+for t in range(min(10, max(2, a.steps // 2))):
     env.step(acts[t]); env.get_obs()
 torch.cuda.synchronize()
 env.nr_timing(True)
