@@ -94,6 +94,13 @@ typedef struct mapdn_netspec {
   const double* load_scaling;       /* [n_load] net.load.scaling * in_service (pd2ppc: PD = sum p_mw * scaling); NULL = 1 */
   const double* sgen_scaling;       /* [n_sgen] net.sgen.scaling * in_service; runpp and res_sgen see p, q * scaling, the env
                                        (obs, q clip, :189) the raw table values; NULL = 1                               */
+  const int32_t* bus_alias;         /* [n_bus] bus fusion — closed bus-bus switches (net.switch, et == "b"), which pd2ppc's bus lookup
+                                       merges into ONE ppc bus: bus_alias[b] = the representative of b's group (itself for an unfused
+                                       bus; representatives represent themselves).  Fused buses share the solved voltage but stay
+                                       rows of everything the env reads: res_bus vm_pu / va_degree (equal within a group), their
+                                       OWN p_mw / q_mvar (the ext_grid's injection on the ext_grid's own bus), zone frames,
+                                       get_state, the reward's averages over all buses.  A branch between two buses of one group
+                                       is refused.  NULL = no fusion                                                          */
 } mapdn_netspec;
 
 /* Constructor kwargs of VoltageControl (args/env_args/var_voltage_control.yaml:3-20). */
@@ -268,7 +275,8 @@ int mapdn_solve_only(mapdn_handle* h, const double* p_load, const double* q_load
                      uint8_t* converged, void* stream);
 
 /* Host-side debug export of the per-unit admittance matrix the library built (for parity tests):
- * dense row-major complex [nb, nb] as (re, im) pairs. */
+ * dense row-major complex [nb, nb] as (re, im) pairs (with fused buses — bus_alias — over the merged nodes: nb = the number of
+ * representatives, in ascending order of their bus index). */
 int mapdn_get_ybus_dense(const mapdn_handle* h, double* ybus_re_im);
 /* Host-side export of the integer gather tables of get_obs: kind/index per obs column
  * [n_agents*obs_size] (kinds: 0 zero pad, 1 p_mw, 2 q_mvar, 3 pv, 4 q, 5 vm_pu, 6 va rad). */

@@ -52,7 +52,7 @@ class CNetSpec(C.Structure):
         ("n_load", C.c_int32), ("load_bus", _pi),
         ("n_sgen", C.c_int32), ("sgen_bus", _pi), ("sgen_zone", _pi),
         ("ext_grid_bus", C.c_int32), ("ext_grid_vm_pu", C.c_double), ("sn_mva", C.c_double), ("f_hz", C.c_double),
-        ("br_g_pu", _pd), ("load_scaling", _pd), ("sgen_scaling", _pd),
+        ("br_g_pu", _pd), ("load_scaling", _pd), ("sgen_scaling", _pd), ("bus_alias", _pi),
     ]
 
 
@@ -210,6 +210,7 @@ def make_cnetspec(net: NetSpec):
     s.br_g_pu = _p(net.br_g_pu, _pd)
     s.load_scaling = _p(net.load_scaling, _pd)
     s.sgen_scaling = _p(net.sgen_scaling, _pd)
+    s.bus_alias = _p(net.bus_alias, _pi) if net.has_fused_buses else C.cast(None, _pi)
     return s, keep
 
 

@@ -286,6 +286,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   const Plan& P = h->plan;
   Dev& d = h->d;
   d.B = B; d.Bp = (B + 63) / 64 * 64; d.nb = P.nb; d.n = P.n; d.nl = P.nl; d.ns = P.ns; d.n_line = P.n_line;
+  d.nbo = P.nbo;                                 // original buses (> nb with fused buses): the rows of res_bus / obs / state
   d.ncol = P.ns + 2 * P.nl;
   d.vroot = P.vroot; d.sn = P.sn_mva; d.tol = P.tol; d.max_it = 10;   // runpp max_iteration="auto" -> 10
   d.yrr0 = P.yrr[0]; d.yrr1 = P.yrr[1];
@@ -297,6 +298,14 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   d.env_id_offset = cfg->env_id_offset;
 #define UP(field, vec) do { rc = dupload(h, &d.field, vec); if (rc) return rc; } while (0)
   UP(bus_of_pos, P.bus_of_pos); UP(root_children, P.root_children); UP(root_y, P.root_y);
+  UP(pos_of_obus, P.pos_of_obus); UP(cm_kind, P.cm_kind);
+  d.n_fused = (int32_t)P.fused_obus.size(); d.n_alias = (int32_t)P.alias_pos.size(); d.n_slack_group = (int32_t)P.slack_group.size();
+  if (d.n_fused) {
+    UP(fused_obus, P.fused_obus); UP(ob_load_ptr, P.ob_load_ptr); UP(ob_load_idx, P.ob_load_idx); UP(ob_sgen_ptr, P.ob_sgen_ptr);
+    UP(ob_sgen_idx, P.ob_sgen_idx); UP(ob_shunt_p, P.ob_shunt_p); UP(ob_shunt_q, P.ob_shunt_q);
+    { std::vector<int32_t> sg(P.slack_group); if (sg.empty()) sg.push_back(0); UP(slack_group, sg); }
+    { std::vector<int32_t> ap(P.alias_pos); if (ap.empty()) ap.push_back(0); UP(alias_pos, ap); }
+  }
   d.n_root_children = (int32_t)P.root_children.size();
   UP(load_ptr, P.load_ptr); UP(load_idx, P.load_idx); UP(sgen_ptr, P.sgen_ptr); UP(sgen_idx, P.sgen_idx);
   UP(shunt_p, P.shunt_p); UP(shunt_q, P.shunt_q); UP(load_scale, P.load_scale); UP(sgen_scale, P.sgen_scale);
@@ -342,8 +351,8 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
 #define AL(field, rows) do { rc = dalloc(h, &d.field, (size_t)(rows) * Bp); if (rc) return rc; } while (0)
   AL(q_new, d.ns); AL(cur_pl, d.nl); AL(cur_ql, d.nl); AL(pl, d.n_line);
   // gatherable state block: cur_pv cur_q [ns] | vm va res_p res_q [nb]
-  const int r_pv = 0, r_q = r_pv + d.ns, r_vm = r_q + d.ns, r_va = r_vm + d.nb,
-            r_rp = r_va + d.nb, r_rq = r_rp + d.nb, g_rows = r_rq + d.nb;
+  const int r_pv = 0, r_q = r_pv + d.ns, r_vm = r_q + d.ns, r_va = r_vm + d.nbo,
+            r_rp = r_va + d.nbo, r_rq = r_rp + d.nbo, g_rows = r_rq + d.nbo;
   rc = dalloc(h, &d.gbuf, (size_t)g_rows * Bp); if (rc) return rc;
   d.cur_pv = d.gbuf + (size_t)r_pv * Bp;
   d.cur_q = d.gbuf + (size_t)r_q * Bp; d.vm = d.gbuf + (size_t)r_vm * Bp; d.va = d.gbuf + (size_t)r_va * Bp;
@@ -358,7 +367,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   {  // obs / state columns -> (source row of gbuf, scale, extra rows to add); -1 = zero padding.
      // P/Q columns with the effective PV add-back (voltage_control_env.py:238-244) = res_bus row + the
      // sgen.p_mw / q_mvar rows of the sgens on that bus.
-    std::vector<std::vector<int>> sgens_at(P.nb);
+    std::vector<std::vector<int>> sgens_at(P.nbo);
     for (int j = 0; j < P.ns; ++j) sgens_at[P.sgen_bus[j]].push_back(j);
     auto tables = [&](const std::vector<int32_t>& kind, const std::vector<int32_t>& idx, std::vector<int32_t>& rows,
                       std::vector<double>& scale, std::vector<int32_t>& xptr, std::vector<int32_t>& xrow) {
@@ -391,7 +400,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     rc = dupload(h, &tmp, rows); if (rc) return rc; h->state_rows = (int32_t*)tmp;
     rc = dupload(h, &dt, scale); if (rc) return rc; h->state_scale = (double*)dt;
   }
-  const int maxn = std::max(std::max(d.nb, d.n_line), std::max(d.nl, d.ns));
+  const int maxn = std::max(std::max(d.nbo, d.n_line), std::max(d.nl, d.ns));
   std::vector<int32_t> io(maxn);
   for (int i = 0; i < maxn; ++i) io[i] = i;
   rc = dupload(h, &tmp, io); if (rc) return rc; h->iota_idx = (int32_t*)tmp;
@@ -428,8 +437,8 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     double* rootv = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * P.n) * Bp;
     HIPCHK(h, hipMemcpy(rootv + (size_t)VO_E * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(rootv + (size_t)VO_VM * Bp, row.data(), Bp * sizeof(double), hipMemcpyHostToDevice));
-    std::vector<int32_t> vmrow(P.nb), varow(P.nb);
-    for (int b = 0; b < P.nb; ++b) { const int k = P.pos_of_bus[b]; vmrow[b] = (int)d.r_vout + VOF * k + VO_VM; varow[b] = (int)d.r_vout + VOF * k + VO_VA; }
+    std::vector<int32_t> vmrow(P.nbo), varow(P.nbo);
+    for (int b = 0; b < P.nbo; ++b) { const int k = P.pos_of_obus[b]; vmrow[b] = (int)d.r_vout + VOF * k + VO_VM; varow[b] = (int)d.r_vout + VOF * k + VO_VA; }
     rc = dupload(h, &tmp, vmrow); if (rc) return rc; h->vm_row = (int32_t*)tmp;
     rc = dupload(h, &tmp, varow); if (rc) return rc; h->va_row = (int32_t*)tmp;
     return MAPDN_OK;
@@ -529,6 +538,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     if (fi == 1 && !can) { h->err = "fuse_inject = 1 needs a handle without auto_reset and without inject_full"; return MAPDN_E_INVALID; }
     h->fuse_inject = can && fi != 2;
     h->overlap = knob_int(cfg->overlap_advance, "MAPDN_OVERLAP_ADVANCE") != 0;
+    if (h->overlap && d.n_fused) { h->err = "overlap_advance is not available on a net with fused buses (bus_alias)"; return MAPDN_E_INVALID; }
     if (h->overlap) {
       HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
       HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -561,7 +571,7 @@ void mapdn_destroy(mapdn_handle* h) {
 int mapdn_dims(const mapdn_handle* h, mapdn_dims_t* out) {
   if (!h || !out) return MAPDN_E_INVALID;
   const Plan& P = h->plan;
-  out->n_envs = h->d.B; out->n_bus = P.nb; out->n_line = P.n_line; out->n_load = P.nl; out->n_sgen = P.ns;
+  out->n_envs = h->d.B; out->n_bus = P.nbo; out->n_line = P.n_line; out->n_load = P.nl; out->n_sgen = P.ns;
   out->n_agents = P.n_agents; out->n_actions = 1; out->obs_size = P.obs_size; out->state_size = P.state_size;
   out->n_info = MAPDN_N_INFO; out->is_radial = P.radial ? 1 : 0; out->max_zone_size = P.max_zone;
   return MAPDN_OK;
@@ -661,9 +671,11 @@ static int step_launches(mapdn_handle* h, const void* actions, int32_t actions_d
     HIPCHK(h, hipEventRecord(h->ev_join, h->side));
     nr_launch(h, MODE_STEP, reward, terminated, info, st);
     HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+    launch_commit_fused(d, st);     // (with fused buses the side stream's profile rows race with this: overlap is an experiment switch)
     launch_advance(d, 0, 0, 1, d.sb_off_alt, st);
   } else {
     nr_launch(h, MODE_STEP, reward, terminated, info, st, fused ? actions : nullptr, actions_dtype);
+    launch_commit_fused(d, st);     // (only with fused buses: their own p_mw / q_mvar, before the element tables advance)
     launch_advance(d, add_noise, 1, 1, d.sb_off_alt, st);   // next profile row (-> the Sbus buffer of the next solve) + res_bus commit
   }
   std::swap(h->d.sb_off, h->d.sb_off_alt);
@@ -683,6 +695,7 @@ int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, i
     launch_advance(d, add_noise, 1, 0, d.sb_off, st);   // the advance precedes the solve here: it fills the buffer the solve reads
     inject_launch(h, MODE_RESET, nullptr, MAPDN_F64, add_noise, st);
     nr_launch(h, MODE_RESET, nullptr, nullptr, nullptr, st);
+    launch_commit_fused(d, st);
     launch_advance(d, 0, 0, 1, d.sb_off, st);    // res_bus commit of the envs that found a solvable start
   }
   HIPCHK(h, hipGetLastError());
@@ -769,10 +782,10 @@ int mapdn_get_results(mapdn_handle* h, double* vm_pu, double* va_degree, double*
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   const Dev& d = h->d;
-  if (vm_pu) transpose_out(h, d.vm, 1.0, h->iota_idx, vm_pu, d.nb, st);
-  if (va_degree) transpose_out(h, d.va, 180.0 / M_PI, h->iota_idx, va_degree, d.nb, st);
-  if (p_mw) transpose_out(h, d.res_p, 1.0, h->iota_idx, p_mw, d.nb, st);
-  if (q_mvar) transpose_out(h, d.res_q, 1.0, h->iota_idx, q_mvar, d.nb, st);
+  if (vm_pu) transpose_out(h, d.vm, 1.0, h->iota_idx, vm_pu, d.nbo, st);
+  if (va_degree) transpose_out(h, d.va, 180.0 / M_PI, h->iota_idx, va_degree, d.nbo, st);
+  if (p_mw) transpose_out(h, d.res_p, 1.0, h->iota_idx, p_mw, d.nbo, st);
+  if (q_mvar) transpose_out(h, d.res_q, 1.0, h->iota_idx, q_mvar, d.nbo, st);
   if (pl_mw) transpose_out(h, d.pl, 1.0, h->iota_idx, pl_mw, d.n_line, st);
   if (sgen_p) transpose_out(h, d.cur_pv, 1.0, h->iota_idx, sgen_p, d.ns, st);
   if (sgen_q) transpose_out(h, d.cur_q, 1.0, h->iota_idx, sgen_q, d.ns, st);
@@ -832,8 +845,8 @@ int mapdn_solve_only(mapdn_handle* h, const double* p_load, const double* q_load
   launch_inject(d, MODE_SOLVE, nullptr, MAPDN_F64, h->t_pl, h->t_ql, h->t_pv, h->t_q, 0, st);
   h->sbus_stale = true;                          // Sbus now holds the caller's loads, not cur_pl / cur_ql
   nr_launch(h, MODE_SOLVE, nullptr, nullptr, nullptr, st);
-  if (vm_pu) transpose_out(h, d.nrbuf, 1.0, h->vm_row, vm_pu, d.nb, st);
-  if (va_degree) transpose_out(h, d.nrbuf, 180.0 / M_PI, h->va_row, va_degree, d.nb, st);
+  if (vm_pu) transpose_out(h, d.nrbuf, 1.0, h->vm_row, vm_pu, d.nbo, st);
+  if (va_degree) transpose_out(h, d.nrbuf, 180.0 / M_PI, h->va_row, va_degree, d.nbo, st);
   if (iterations) launch_copy_i32(d.iters, iterations, d.B, st);
   if (converged) launch_copy_u8(d.conv, converged, d.B, st);
   HIPCHK(h, hipGetLastError());

@@ -315,8 +315,9 @@ __device__ __forceinline__ void advance_body(const Dev& d, int add_noise, int do
     // ---- K6 commit of res_bus (pandapower pfsoln/_extract_results) for envs whose solve was accepted:
     // vm_pu = |V|, va = angle(V), p_mw/q_mvar = bus demand (-Sbus*sn) + shunt*|V|^2, slack = -(V conj(I))*sn
     if (!d.commit[e]) return;
-    const int k = (int)blk_y - npairs - nmb;  // elimination position, n == slack
-    const size_t o = (size_t)d.bus_of_pos[k] * S + e;
+    const int b_ = (int)blk_y - npairs - nmb;      // ORIGINAL bus (bus fusion: several buses may share an electrical node)
+    const int k = d.pos_of_obus[b_];               // elimination position of its node, n == slack
+    const size_t o = (size_t)b_ * S + e;
     double v, P, Q;
     if (k < d.n) {
       const double* vo = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * k) * S + e;
@@ -336,7 +337,8 @@ __device__ __forceinline__ void advance_body(const Dev& d, int add_noise, int do
       P = -(d.vroot * ir) * d.sn; Q = (d.vroot * ii) * d.sn;
     }
     d.vm[o] = v;
-    d.res_p[o] = P + d.shunt_p[k] * v * v; d.res_q[o] = Q + d.shunt_q[k] * v * v;
+    if (d.cm_kind[b_] == 0) { d.res_p[o] = P + d.shunt_p[k] * v * v; d.res_q[o] = Q + d.shunt_q[k] * v * v; }
+    // (a bus of a fused group reports its OWN elements: k_commit_fused wrote p_mw / q_mvar before this launch)
     return;
   }
   const int64_t row = d.adv_row[e];
@@ -399,6 +401,49 @@ __device__ __forceinline__ void advance_body(const Dev& d, int add_noise, int do
 
 __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off) {
   advance_body(d, add_noise, do_profiles, do_commit, sb_write_off, blockIdx.x, blockIdx.y);
+}
+
+// K6'  res_bus p_mw / q_mvar of the buses of FUSED groups (closed bus-bus switches): pandapower reports, per pandapower bus, the bus's
+//      own loads - sgens + shunt |V|^2 (results_bus._get_p_q_results), the ext_grid's injection on the ext_grid's own bus.  thread =
+//      (fused bus, env), launched after the solve and BEFORE the profile advance overwrites the element tables.
+__global__ void __launch_bounds__(256) k_commit_fused(Dev d) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.B || !d.commit[e]) return;
+  const size_t S = (size_t)d.Bp;
+  auto own = [&](int i, double& P, double& Q) {      // own demand of fused bus i: loads - sgens (the q the accepted solve used)
+    P = 0.0; Q = 0.0;
+    for (int q = d.ob_load_ptr[i]; q < d.ob_load_ptr[i + 1]; ++q) {
+      const int li = d.ob_load_idx[q];
+      P += d.cur_pl[(size_t)li * S + e] * d.load_scale[li]; Q += d.cur_ql[(size_t)li * S + e] * d.load_scale[li];
+    }
+    for (int q = d.ob_sgen_ptr[i]; q < d.ob_sgen_ptr[i + 1]; ++q) {
+      const int j = d.ob_sgen_idx[q];
+      P -= d.cur_pv[(size_t)j * S + e] * d.sgen_scale[j]; Q -= d.cur_q[(size_t)j * S + e] * d.sgen_scale[j];
+    }
+  };
+  const int i = blockIdx.y;
+  const int b_ = d.fused_obus[i], k = d.pos_of_obus[b_];
+  double v = d.vroot;
+  if (k < d.n) {
+    const double* vo = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * k) * S + e;
+    const double ek = vo[(size_t)VO_E * S], fk = vo[(size_t)VO_F * S];
+    v = sqrt(ek * ek + fk * fk);
+  }
+  double P, Q;
+  own(i, P, Q);
+  P += d.ob_shunt_p[i] * v * v; Q += d.ob_shunt_q[i] * v * v;
+  if (d.cm_kind[b_] == 2) {                          // the ext_grid's own bus: minus the ext_grid's injection = (demand of the whole
+    double Dp = 0.0, Dq = 0.0;                       // group) + (power the slack node feeds into the network)
+    for (int m = 0; m < d.n_slack_group; ++m) { double p_, q_; own(d.slack_group[m], p_, q_); Dp += p_; Dq += q_; }
+    double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;
+    for (int j = 0; j < d.n_root_children; ++j) {
+      const double* cb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * d.root_children[j]) * S + e;
+      const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ec = cb[(size_t)VO_E * S], fc = cb[(size_t)VO_F * S];
+      ir += g * ec - b * fc; ii += g * fc + b * ec;
+    }
+    P -= Dp + (d.vroot * ir) * d.sn; Q -= Dq - (d.vroot * ii) * d.sn;
+  }
+  d.res_p[(size_t)b_ * S + e] = P; d.res_q[(size_t)b_ * S + e] = Q;
 }
 
 // =================================================================================================
@@ -492,7 +537,7 @@ k_post_merged(Dev d, int add_noise, uint32_t sb_write_off, unsigned adv_gx, unsi
 }
 void launch_post_merged(const Dev& d, int add_noise, uint32_t sb_write_off, const double* base, const int32_t* rows, const double* scales,
                         const int32_t* x_ptr, const int32_t* x_row, void* out, int C, hipStream_t st) {
-  const unsigned agx = (d.B + 255) / 256, agy = ((d.ns + 1) >> 1) + ((d.nl + 1) >> 1) + d.nb, ggx = (C + 63) / 64, ggy = d.Bp / 64;
+  const unsigned agx = (d.B + 255) / 256, agy = ((d.ns + 1) >> 1) + ((d.nl + 1) >> 1) + d.nbo, ggx = (C + 63) / 64, ggy = d.Bp / 64;
   hipLaunchKernelGGL(k_post_merged<float>, dim3(agx * agy + ggx * ggy), dim3(256), 0, st, d, add_noise, sb_write_off, agx, agy, base, rows, scales,
                      x_ptr, x_row, (float*)out, C, ggx, ggy);
 }
@@ -617,9 +662,12 @@ void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, 
 // do_profiles: next profile row + noise for the envs queued in adv_row; do_commit: res_bus commit of
 // the envs flagged by the preceding k_nr_tree launch
 void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off, hipStream_t st) {
-  const int rows = (do_profiles ? ((d.ns + 1) >> 1) + ((d.nl + 1) >> 1) : 0) + (do_commit ? d.nb : 0);
+  const int rows = (do_profiles ? ((d.ns + 1) >> 1) + ((d.nl + 1) >> 1) : 0) + (do_commit ? d.nbo : 0);
   if (rows == 0) return;
   hipLaunchKernelGGL(k_advance, dim3((d.B + 255) / 256, rows), dim3(256), 0, st, d, add_noise, do_profiles, do_commit, sb_write_off);
+}
+void launch_commit_fused(const Dev& d, hipStream_t st) {
+  if (d.n_fused > 0) hipLaunchKernelGGL(k_commit_fused, dim3((d.B + 255) / 256, d.n_fused), dim3(256), 0, st, d);
 }
 void launch_inject_sgen(const Dev& d, int mode, const void* actions, int dtype, int add_noise, hipStream_t st) {
   const dim3 grid((d.B + 255) / 256, d.n_sgb + d.n_mlo);

@@ -85,6 +85,10 @@ struct Dev {
   int32_t dense, dn_N, dn_lda;
   double* dn_A;              // k_nr_dense beyond 65 buses: per-env slabs [Bp][dn_N][dn_lda] of global memory for the Jacobian (else nullptr: LDS)
   const int32_t *gy_ptr, *gy_col; const double* gy_val;
+  // ---- bus fusion (plan.hpp): original buses, nbo of them, vs electrical nodes (nb); all nullptr / 0 / nbo == nb without fusion
+  int32_t nbo, n_fused, n_alias, n_slack_group;
+  const int32_t *pos_of_obus, *cm_kind, *fused_obus, *ob_load_ptr, *ob_load_idx, *ob_sgen_ptr, *ob_sgen_idx, *slack_group, *alias_pos;
+  const double *ob_shunt_p, *ob_shunt_q;
   // ---- PV-bus injection fused into the k_nr_tree prologue (step(), handles without auto_reset): per launch, set by launch_nr.
   // sgb_rec [n_sgb + n_mlo][8] = Sbus entry of the bus (-1: slack bus, q only) | elimination position | first sgen on the bus (-1:
   // a load-only bus with several loads) | (number of sgens << 8) | min(number of loads, 2) || first load | second load | 0 | 0
@@ -127,6 +131,8 @@ void launch_nr_dense(const Dev& d, int mode, double* reward, uint8_t* term, doub
 int dense_solve_debug(const double* A, const double* b, double* x, int n, int batch, hipStream_t st);
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);
 void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off, hipStream_t st);
+// res_bus p_mw / q_mvar of the buses of fused groups (their OWN elements), after the solve and before the profile advance
+void launch_commit_fused(const Dev& d, hipStream_t st);
 void launch_gather(const Dev& d, const double* base, const int32_t* rows, const double* scales, double scale_all,
                    const int32_t* x_ptr, const int32_t* x_row, void* out, int dtype, int C, hipStream_t st);
 void launch_to_envminor(const Dev& d, const double* src, double* dst, int n, hipStream_t st);

@@ -162,6 +162,18 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
     mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
     bar += barrier(d.barrier_type, v);
   }
+  if (d.n_alias) {                                // bus fusion (wave-uniform; no fused buses: not taken): a fused bus is a row of res_bus
+    for (unsigned a = t; a < (unsigned)d.n_alias; a += Wt) {       // too, so the reward statistics count its node's voltage once more
+      const unsigned k = (unsigned)d.alias_pos[a];
+      double v = vroot;
+      if (k < n) { const d2 vv = sV[(size_t)k * L]; v = sqrt(vv.x * vv.x + vv.y * vv.y); }
+      n_lo += (v < vlo) ? 1.0 : 0.0; n_hi += (v > vhi) ? 1.0 : 0.0;
+      dev += fabs(v - vref); vsum += v;
+      mdrop = fmax(mdrop, (v < vlo) ? (vlo - v) : 0.0);
+      mrise = fmax(mrise, (v > vhi) ? (v - vhi) : 0.0);
+      bar += barrier(d.barrier_type, v);
+    }
+  }
   stamp(22);
   if (t == 0 && valid) d.commit[e] = commitf ? 1 : 0;
   // ---- res_line.pl_mw = Re(Sf + St) * sn   (out-of-service rows: fpos = tpos = slack, all-zero admittances)
@@ -200,8 +212,8 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
   // statistics come from the PREVIOUS committed state (voltage_control_env.py:190 restores last_powergrid)
   if (mode == MODE_STEP && __any(act && !conv)) {
     double a_lo = 0, a_hi = 0, a_dev = 0, a_sum = 0, a_drop = 0, a_rise = 0, a_bar = 0, a_ll = 0, a_ql = 0;
-    for (unsigned k = t; k <= n; k += Wt) {
-      const double v = valid ? d.vm[(size_t)bus_of_pos[k] * SB + e] : 1.0;
+    for (unsigned k = t; k < (unsigned)d.nbo; k += Wt) {           // every row of res_bus (original buses)
+      const double v = valid ? d.vm[(size_t)k * SB + e] : 1.0;
       a_lo += (v < vlo) ? 1.0 : 0.0; a_hi += (v > vhi) ? 1.0 : 0.0;
       a_dev += fabs(v - vref); a_sum += v;
       a_drop = fmax(a_drop, (v < vlo) ? (vlo - v) : 0.0);
@@ -255,7 +267,7 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
   for (int q = 0; q < 10; ++q) tot[q] = sm[(size_t)(q * Wt) * L];
   {
     const bool ok = conv;
-    const double inv_nb = 1.0 / (double)d.nb;
+    const double inv_nb = 1.0 / (double)d.nbo;     // all rows of res_bus (voltage_control_env.py:584-589)
     const double out = (tot[0] + tot[1]) * inv_nb;
     const double ql = tot[8] / (double)d.ns, qf = tot[9] / (double)d.ns;
     const double v_loss = tot[6] * inv_nb * d.voltage_weight;

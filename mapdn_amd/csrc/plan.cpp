@@ -42,8 +42,97 @@ PiBranch pi_from_pu(const mapdn_netspec& net, int k) {
 
 }  // namespace
 
-int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, std::string& err) {
+static int build_plan_nodes(const mapdn_netspec& net, const mapdn_netspec& net_o, const mapdn_env_config& cfg, Plan& P, std::string& err);
+
+// pd2ppc's bus lookup: the buses joined by closed bus-bus switches (mapdn_netspec.bus_alias) are ONE electrical node.  The plan is
+// built on the merged net (nodes = the representatives, in ascending order); what the env reads per pandapower bus — zone frames,
+// get_state, res_bus rows — keeps the original buses (Plan::nbo, pos_of_obus, cm_kind ...).
+int build_plan(const mapdn_netspec& net_o, const mapdn_env_config& cfg, Plan& P, std::string& err) {
+  const int nbo = net_o.n_bus;
+  if (nbo < 2) { err = "netspec: need at least 2 buses"; return MAPDN_E_INVALID; }
+  std::vector<int32_t> alias(nbo);
+  bool fused = false;
+  for (int b = 0; b < nbo; ++b) {
+    alias[b] = net_o.bus_alias ? net_o.bus_alias[b] : b;
+    if (alias[b] < 0 || alias[b] >= nbo) { err = "netspec: bus_alias out of range"; return MAPDN_E_INVALID; }
+    fused = fused || alias[b] != b;
+  }
+  for (int b = 0; b < nbo; ++b) if (alias[alias[b]] != alias[b]) { err = "netspec: bus_alias must map every bus to a representative that represents itself"; return MAPDN_E_INVALID; }
+  if (!fused) {
+    int rc = build_plan_nodes(net_o, net_o, cfg, P, err);
+    if (rc) return rc;
+    P.nbo = nbo; P.pos_of_obus = P.pos_of_bus; P.cm_kind.assign(nbo, 0);
+    return MAPDN_OK;
+  }
+  // ---- the merged net: node ids = the representatives in ascending order
+  std::vector<int32_t> eid(nbo, -1);
+  int nbe = 0;
+  for (int b = 0; b < nbo; ++b) if (alias[b] == b) eid[b] = nbe++;
+  for (int b = 0; b < nbo; ++b) eid[b] = eid[alias[b]];
+  auto bad = [&](int b) { return b < 0 || b >= nbo; };
+  auto remap = [&](const int32_t* a, int n, std::vector<int32_t>& out, const char* what) {
+    out.resize(std::max(n, 1));
+    for (int i = 0; i < n; ++i) { if (bad(a[i])) { err = std::string("netspec: ") + what + " bus out of range"; return false; } out[i] = eid[a[i]]; }
+    return true;
+  };
+  std::vector<int32_t> lf, lt, bf, bt, lb, sb, hb, zone_e(nbe, 0);
+  std::vector<double> vn_e(nbe, 0.0);
+  if (!remap(net_o.line_from_bus, net_o.n_line, lf, "line") || !remap(net_o.line_to_bus, net_o.n_line, lt, "line") ||
+      !remap(net_o.br_from_bus, net_o.n_branch_pu, bf, "branch") || !remap(net_o.br_to_bus, net_o.n_branch_pu, bt, "branch") ||
+      !remap(net_o.load_bus, net_o.n_load, lb, "load") || !remap(net_o.sgen_bus, net_o.n_sgen, sb, "sgen") ||
+      !remap(net_o.shunt_bus, net_o.n_shunt, hb, "shunt")) return MAPDN_E_INVALID;
+  if (bad(net_o.ext_grid_bus)) { err = "netspec: ext_grid_bus out of range"; return MAPDN_E_INVALID; }
+  for (int l = 0; l < net_o.n_line; ++l) if (lf[l] == lt[l]) {
+    if (net_o.line_in_service[l]) { err = "netspec: line " + std::to_string(l) + " joins two buses of one fused group (bus_alias): not supported"; return MAPDN_E_INVALID; }
+    lt[l] = (lf[l] + 1) % nbe;                    // out of service: any valid pair of ends
+  }
+  for (int k = 0; k < net_o.n_branch_pu; ++k) if (bf[k] == bt[k]) { err = "netspec: branch " + std::to_string(k) + " joins two buses of one fused group (bus_alias): not supported"; return MAPDN_E_INVALID; }
+  for (int b = 0; b < nbo; ++b) if (alias[b] == b) { vn_e[eid[b]] = net_o.bus_vn_kv[b]; zone_e[eid[b]] = net_o.bus_zone[b]; }
+  mapdn_netspec E = net_o;
+  E.n_bus = nbe; E.bus_vn_kv = vn_e.data(); E.bus_zone = zone_e.data(); E.line_from_bus = lf.data(); E.line_to_bus = lt.data();
+  E.br_from_bus = bf.data(); E.br_to_bus = bt.data(); E.load_bus = lb.data(); E.sgen_bus = sb.data(); E.shunt_bus = hb.data();
+  E.ext_grid_bus = eid[net_o.ext_grid_bus]; E.bus_alias = nullptr;
+  int rc = build_plan_nodes(E, net_o, cfg, P, err);
+  if (rc) return rc;
+  // ---- the reporting layer
+  P.nbo = nbo;
+  P.pos_of_obus.resize(nbo);
+  std::vector<int> gsize(nbe, 0);
+  for (int b = 0; b < nbo; ++b) { P.pos_of_obus[b] = P.pos_of_bus[eid[b]]; gsize[eid[b]]++; }
+  P.cm_kind.assign(nbo, 0);
+  P.fused_obus.clear(); P.alias_pos.clear(); P.slack_group.clear();
+  for (int b = 0; b < nbo; ++b) {
+    if (gsize[eid[b]] > 1) {
+      P.cm_kind[b] = b == net_o.ext_grid_bus ? 2 : 1;
+      if (eid[b] == E.ext_grid_bus) P.slack_group.push_back((int32_t)P.fused_obus.size());
+      P.fused_obus.push_back(b);
+    }
+    if (alias[b] != b) P.alias_pos.push_back(P.pos_of_obus[b]);
+  }
+  const int nf = (int)P.fused_obus.size();
+  std::vector<int> fidx(nbo, -1);
+  for (int i = 0; i < nf; ++i) fidx[P.fused_obus[i]] = i;
+  auto own = [&](int n_el, const int32_t* el_bus, std::vector<int32_t>& ptr, std::vector<int32_t>& idx) {
+    ptr.assign(nf + 1, 0); idx.clear();
+    for (int i = 0; i < nf; ++i) {
+      for (int j = 0; j < n_el; ++j) if (el_bus[j] == P.fused_obus[i]) idx.push_back(j);      // ascending element index
+      ptr[i + 1] = (int32_t)idx.size();
+    }
+    if (idx.empty()) idx.push_back(0);
+  };
+  own(net_o.n_load, net_o.load_bus, P.ob_load_ptr, P.ob_load_idx);
+  own(net_o.n_sgen, net_o.sgen_bus, P.ob_sgen_ptr, P.ob_sgen_idx);
+  P.ob_shunt_p.assign(std::max(nf, 1), 0.0); P.ob_shunt_q.assign(std::max(nf, 1), 0.0);
+  for (int i = 0; i < net_o.n_shunt; ++i) if (fidx[net_o.shunt_bus[i]] >= 0) {
+    P.ob_shunt_p[fidx[net_o.shunt_bus[i]]] += net_o.shunt_p_mw[i]; P.ob_shunt_q[fidx[net_o.shunt_bus[i]]] += net_o.shunt_q_mvar[i]; }
+  return MAPDN_OK;
+}
+
+// the plan of the electrical nodes of `net` (a net without fusion, or the merged net); zone frames / get_state / the sgens' buses
+// follow the ORIGINAL net `net_o`
+static int build_plan_nodes(const mapdn_netspec& net, const mapdn_netspec& net_o, const mapdn_env_config& cfg, Plan& P, std::string& err) {
   const int nb = net.n_bus;
+  const int nbo = net_o.n_bus;
   if (nb < 2) { err = "netspec: need at least 2 buses"; return MAPDN_E_INVALID; }
   if (net.ext_grid_bus < 0 || net.ext_grid_bus >= nb) { err = "netspec: ext_grid_bus out of range"; return MAPDN_E_INVALID; }
   if (!(net.sn_mva > 0)) { err = "netspec: sn_mva must be > 0"; return MAPDN_E_INVALID; }
@@ -58,7 +147,7 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   for (int i = 0; i < net.n_sgen; ++i) {
     if (bad_bus(net.sgen_bus[i])) { err = "netspec: sgen bus out of range"; return MAPDN_E_INVALID; }
     // reference: `.loc[sgen_bus]` on the zone frame raises KeyError otherwise (voltage_control_env.py:239)
-    if (net.bus_zone[net.sgen_bus[i]] != net.sgen_zone[i]) {
+    if (net_o.bus_zone[net_o.sgen_bus[i]] != net_o.sgen_zone[i]) {
       err = "netspec: sgen " + std::to_string(i) + " sits on a bus outside its own zone (reference get_obs would raise KeyError)";
       return MAPDN_E_INVALID; }
     if (net.sgen_zone[i] <= 0) { err = "netspec: sgen zone must be a non-main zone"; return MAPDN_E_INVALID; }
@@ -231,7 +320,7 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   csr(net.n_load, net.load_bus, P.load_ptr, P.load_idx);
   csr(net.n_sgen, net.sgen_bus, P.sgen_ptr, P.sgen_idx);
   for (int b = 0; b < nb; ++b) { P.shunt_p[P.pos_of_bus[b]] = sh_p_bus[b]; P.shunt_q[P.pos_of_bus[b]] = sh_q_bus[b]; }
-  P.sgen_bus.assign(net.sgen_bus, net.sgen_bus + net.n_sgen);
+  P.sgen_bus.assign(net_o.sgen_bus, net_o.sgen_bus + net_o.n_sgen);      // ORIGINAL bus ids (the add-back rows of get_obs)
   P.load_scale.assign(net.n_load, 1.0); P.sgen_scale.assign(net.n_sgen, 1.0);
   if (net.load_scaling) P.load_scale.assign(net.load_scaling, net.load_scaling + net.n_load);
   if (net.sgen_scaling) P.sgen_scale.assign(net.sgen_scaling, net.sgen_scaling + net.n_sgen);
@@ -246,7 +335,7 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
            ((ss & MAPDN_SS_VM_PU) ? z : 0) + ((ss & MAPDN_SS_VA_DEGREE) ? z : 0);
   };
   for (int i = 0; i < net.n_sgen; ++i) {
-    for (int b = 0; b < nb; ++b) if (net.bus_zone[b] == net.sgen_zone[i]) zone_rows[i].push_back(b);  // ascending bus index (:536)
+    for (int b = 0; b < nbo; ++b) if (net_o.bus_zone[b] == net_o.sgen_zone[i]) zone_rows[i].push_back(b);  // ascending bus index (:536)
     max_len = std::max(max_len, obs_len(zone_rows[i].size()));
     P.max_zone = std::max<int32_t>(P.max_zone, (int32_t)zone_rows[i].size());
   }
@@ -267,11 +356,11 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& P, s
   // ---- get_state — voltage_control_env.py:213-230 -------------------------------------------------
   P.state_kind.clear(); P.state_idx.clear();
   auto sput = [&](int32_t kind, int32_t idx) { P.state_kind.push_back(kind); P.state_idx.push_back(idx); };
-  if (ss & MAPDN_SS_DEMAND) { for (int b = 0; b < nb; ++b) sput(G_P, b); for (int b = 0; b < nb; ++b) sput(G_Q, b); }
+  if (ss & MAPDN_SS_DEMAND) { for (int b = 0; b < nbo; ++b) sput(G_P, b); for (int b = 0; b < nbo; ++b) sput(G_Q, b); }
   if (ss & MAPDN_SS_PV) for (int j = 0; j < net.n_sgen; ++j) sput(G_SGEN_P, j);
   if (ss & MAPDN_SS_REACTIVE) for (int j = 0; j < net.n_sgen; ++j) sput(G_SGEN_Q, j);
-  if (ss & MAPDN_SS_VM_PU) for (int b = 0; b < nb; ++b) sput(G_VM, b);
-  if (ss & MAPDN_SS_VA_DEGREE) for (int b = 0; b < nb; ++b) sput(G_VA_DEG, b);
+  if (ss & MAPDN_SS_VM_PU) for (int b = 0; b < nbo; ++b) sput(G_VM, b);
+  if (ss & MAPDN_SS_VA_DEGREE) for (int b = 0; b < nbo; ++b) sput(G_VA_DEG, b);
   P.state_size = (int32_t)P.state_kind.size();
   return MAPDN_OK;
 }

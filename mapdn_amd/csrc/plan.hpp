@@ -116,6 +116,18 @@ struct Plan {
   std::vector<int32_t> gy_ptr, gy_col;          // Ybus rows of the non-slack buses by position, CSR (columns: positions, n == slack)
   std::vector<double> gy_val;                   // (re, im) per entry — read by the general-topology kernel (dense.hip)
 
+  // ---- bus fusion (mapdn_netspec.bus_alias: closed bus-bus switches).  nb / n / positions / every array above and the element CSRs
+  // below describe the ELECTRICAL nodes (one per group of fused buses).  The env's tables are per ORIGINAL bus (nbo of them):
+  int32_t nbo = 0;                              // original buses (== nb without fusion)
+  std::vector<int32_t> pos_of_obus;             // [nbo] elimination position of the electrical node of original bus b
+  std::vector<int32_t> cm_kind;                 // [nbo] res_bus p / q of bus b: 0 = the node's (-Sbus sn + shunt |V|^2; slack: its injection),
+                                                //       1 = the bus's OWN elements (fused group), 2 = own elements - ext_grid (its own bus)
+  std::vector<int32_t> fused_obus;              // original buses with cm_kind >= 1
+  std::vector<int32_t> ob_load_ptr, ob_load_idx, ob_sgen_ptr, ob_sgen_idx;   // own elements of the fused buses, CSR over fused_obus
+  std::vector<double> ob_shunt_p, ob_shunt_q;   // [fused] own shunts (MW / MVAr at 1 p.u.)
+  std::vector<int32_t> slack_group;             // indices into fused_obus of the members of the slack's group (kind 2 needs their sum)
+  std::vector<int32_t> alias_pos;               // position of the node of every NON-representative bus (reward statistics count it again)
+
   std::vector<LineFlow> lines;                  // [n_line]
   // element -> bus CSR by position (0..nb-1, root last)
   std::vector<int32_t> load_ptr, load_idx, sgen_ptr, sgen_idx;

@@ -147,9 +147,8 @@ def from_pandapower(net) -> NetSpec:
     runpp's defaults.  Converted: buses (0..n-1, all in service), lines (an open line / trafo switch takes the branch out
     when that is exact — no shunt terms, or open at both ends — and is refused otherwise), two-winding transformers (trafo_to_pi), loads / sgens with `scaling` and `in_service`,
     non-consecutive bus indices (mapped to the positions of the sorted index, pd2ppc's bus lookup),
-    shunts (step, in_service), one ext_grid.  Refused loudly, never guessed: voltage-dependent loads
-    (const_z_percent / const_i_percent: the constant-Z share would be a time-varying shunt), closed bus-bus switches
-    (bus fusion), generators, three-winding transformers, impedances, wards, dc lines, storage."""
+    shunts (step, in_service), one ext_grid, closed bus-bus switches (bus fusion -> NetSpec.bus_alias).  Refused loudly, never guessed: voltage-dependent loads
+    (const_z_percent / const_i_percent: the constant-Z share would be a time-varying shunt), generators, three-winding transformers, impedances, wards, dc lines, storage."""
     def table(name):
         t = net[name] if name in net else None
         return t if t is not None and len(t) else None
@@ -179,11 +178,30 @@ def from_pandapower(net) -> NetSpec:
     trafo = table("trafo")
     trafo_on = None if trafo is None else trafo.sort_index()["in_service"].to_numpy(bool).copy()
     sw = table("switch")
+    fused_alias = None
     if sw is not None:
         closed = sw["closed"].to_numpy(bool)
         et = sw["et"].to_numpy()
-        if np.any((et == "b") & closed):
-            raise NotImplementedError("closed bus-bus switches (bus fusion) are not converted")
+        # closed bus-bus switches: bus fusion (pd2ppc's bus lookup merges the buses into one ppc bus) -> NetSpec.bus_alias;
+        # the representative of a group is the ext_grid's bus if the group holds it, else the smallest bus (any choice gives
+        # the same result tables)
+        bb = (et == "b") & closed
+        if np.any(bb):
+            parent_ = np.arange(len(bus_index))
+
+            def find(x):
+                while parent_[x] != x:
+                    parent_[x] = parent_[parent_[x]]
+                    x = parent_[x]
+                return x
+            for a_, b_ in zip(rb(sw["bus"].to_numpy()[bb]), rb(sw["element"].to_numpy()[bb])):
+                ra, rb_ = find(int(a_)), find(int(b_))
+                if ra != rb_:
+                    parent_[max(ra, rb_)] = min(ra, rb_)
+            fused_alias = np.array([find(i) for i in range(len(bus_index))])
+            eg = int(rb([net.ext_grid["bus"].iloc[0]])[0])
+            grp = fused_alias == fused_alias[eg]
+            fused_alias[grp] = eg
         # An OPEN line / trafo switch: runpp's default (neglect_open_switch_branches=False, build_branch._switch_branches)
         # re-terminates the open end on an auxiliary bus, so the branch stays energised from its closed end and still draws
         # its charging / magnetising current.  That is the same as taking the branch out ONLY if it has no shunt terms, or
@@ -228,6 +246,8 @@ def from_pandapower(net) -> NetSpec:
         load_scaling=_col(load, "scaling", 1.0) * on(load), sgen_scaling=_col(sgen, "scaling", 1.0) * on(sgen),
         ext_grid_bus=int(rb([net.ext_grid["bus"].iloc[0]])[0]), ext_grid_vm_pu=float(net.ext_grid["vm_pu"].iloc[0]),
         sn_mva=float(net.sn_mva), f_hz=float(net.f_hz))
+    if fused_alias is not None:
+        kw["bus_alias"] = fused_alias
     if trafo is not None:
         t = trafo.sort_index().copy()
         t["in_service"] = trafo_on

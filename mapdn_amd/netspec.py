@@ -68,6 +68,10 @@ class NetSpec:
     # empty = all ones
     load_scaling: np.ndarray = field(default_factory=lambda: np.zeros(0))
     sgen_scaling: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    # bus fusion (closed bus-bus switches, pd2ppc's bus lookup): bus_alias[b] = the REPRESENTATIVE bus of b's group, b itself for a bus
+    # that is not fused.  Fused buses are one electrical node — same vm_pu / va in res_bus — but stay rows of every table the env
+    # reads: their own p_mw / q_mvar, their own place in the zone frames, the reward's averages.  empty = no fusion
+    bus_alias: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
 
     def __post_init__(self):
         f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
@@ -82,9 +86,13 @@ class NetSpec:
             self.load_scaling = np.ones(np.shape(self.load_bus)[0])
         if self.sgen_scaling.shape[0] == 0:
             self.sgen_scaling = np.ones(np.shape(self.sgen_bus)[0])
+        if np.shape(self.bus_alias)[0] == 0:
+            self.bus_alias = np.arange(np.shape(self.bus_vn_kv)[0])
         for k in ("bus_zone", "line_from_bus", "line_to_bus", "line_parallel", "load_bus",
-                  "sgen_bus", "sgen_zone", "br_from_bus", "br_to_bus", "shunt_bus"):
+                  "sgen_bus", "sgen_zone", "br_from_bus", "br_to_bus", "shunt_bus", "bus_alias"):
             setattr(self, k, i32(getattr(self, k)))
+        if not np.array_equal(self.bus_alias[self.bus_alias], self.bus_alias):
+            raise ValueError("bus_alias must map every bus to a representative that represents itself")
         self.line_in_service = np.ascontiguousarray(self.line_in_service, dtype=np.uint8)
 
     # ---- sizes -------------------------------------------------------------------------------
@@ -107,6 +115,10 @@ class NetSpec:
     @property
     def n_sgen(self) -> int:
         return int(self.sgen_bus.shape[0])
+
+    @property
+    def has_fused_buses(self) -> bool:
+        return bool((self.bus_alias != np.arange(self.n_bus)).any())
 
     @property
     def n_zones(self) -> int:
@@ -378,6 +390,24 @@ def synth_profiles(p_nom_load, q_nom_load, p_pv_max, days=10, seed=0, time_delta
 
 
 _CASES = {}
+
+
+def add_fused_buses(net: NetSpec, reps, move_loads=(), move_sgens=(), move_shunts=()) -> NetSpec:
+    """`net` plus one new bus per entry of `reps`, each FUSED with that existing bus (a closed bus-bus switch: bus_alias), and
+    some elements moved onto the new buses — (element index, which new bus) pairs.  Electrically nothing changes (the fused buses
+    are one node); the env's tables get more rows.  Test nets for the bus-fusion path."""
+    nb, k = net.n_bus, len(reps)
+    reps = np.asarray(reps, dtype=np.int32)
+    lb, sb, hb = net.load_bus.copy(), net.sgen_bus.copy(), net.shunt_bus.copy()
+    for arr, moves in ((lb, move_loads), (sb, move_sgens), (hb, move_shunts)):
+        for el, which in moves:
+            if net.bus_alias[arr[el]] != net.bus_alias[reps[which]]:
+                raise ValueError("an element can only move within its fused group")
+            arr[el] = nb + which
+    return dataclasses.replace(
+        net, name=net.name + f"_fused{k}", bus_vn_kv=np.concatenate([net.bus_vn_kv, net.bus_vn_kv[reps]]),
+        bus_zone=np.concatenate([net.bus_zone, net.bus_zone[reps]]), bus_alias=np.concatenate([net.bus_alias, net.bus_alias[reps]]),
+        load_bus=lb, sgen_bus=sb, shunt_bus=hb)
 
 
 def make_case(name: str, days: int = 10, seed: int = 0):

@@ -201,6 +201,8 @@ def runpp_restated(net, p_load, q_load, p_sgen, q_sgen, raise_on_fail=False, cac
     not installable here; tests/test_pandapower_pin.py::test_tolerance_rule_on_sn_mva_not_one decides it wherever pandapower is).
     `tolerance_is_pu=True` is the other reading (||F||inf < tolerance_mva, no division) — mapdn_env_config.tolerance_is_pu.
     """
+    if getattr(net, "has_fused_buses", False):
+        return _runpp_fused(net, p_load, q_load, p_sgen, q_sgen, raise_on_fail, cache, tolerance_mva, tolerance_is_pu)
     if cache:
         ybus, yf, yt, br = _cached_ybus(net)
     else:
@@ -239,6 +241,59 @@ def runpp_restated(net, p_load, q_load, p_sgen, q_sgen, raise_on_fail=False, cac
     pl_full[net.line_in_service.astype(bool)] = pl
     return PPResult(vm_pu=vm, va_degree=va_deg, p_mw=p_bus, q_mvar=q_bus, pl_mw=pl_full,
                     converged=converged, iterations=it, V=v, Sbus=sbus)
+
+
+# ---- bus fusion (closed bus-bus switches) ------------------------------------------------------------------------------
+# pd2ppc gives all buses joined by closed bus-bus switches ONE ppc bus (build_bus._build_bus_ppc: `bus_lookup` maps every member of a
+# group to the same row) and runs the power flow on the merged buses; the result tables go back per pandapower bus: vm_pu / va_degree
+# of a bus = those of its ppc bus, p_mw / q_mvar = the bus's OWN elements (results_bus._get_p_q_results sums loads / sgens / shunts
+# per pandapower bus; the ext_grid's injection lands on the ext_grid's own bus).  [PP-recalled, like the rest of this file.]
+_REDUCED = {}
+
+
+def reduced_net(net):
+    """(NetSpec on the merged buses, eid [n_bus]: electrical bus of every original bus).  Merged bus ids = the representatives in
+    ascending order; zones of the reduced net are placeholders (they have no electrical meaning)."""
+    key = id(net)
+    hit = _REDUCED.get(key)
+    if hit is not None and hit[0] is net:
+        return hit[1], hit[2]
+    import dataclasses
+    alias = np.asarray(net.bus_alias)
+    reps = np.flatnonzero(alias == np.arange(net.n_bus))
+    comp = np.full(net.n_bus, -1); comp[reps] = np.arange(reps.shape[0])
+    eid = comp[alias]
+    if np.any(eid[net.line_from_bus[net.line_in_service.astype(bool)]] == eid[net.line_to_bus[net.line_in_service.astype(bool)]]) or \
+            np.any(eid[net.br_from_bus] == eid[net.br_to_bus]):
+        raise NotImplementedError("a branch between two buses of one fused group is not supported")
+    lf, lt = eid[net.line_from_bus], eid[net.line_to_bus]
+    dead = lf == lt                                   # (only out-of-service lines can get here): keep them out of service with valid ends
+    lt = np.where(dead, (lf + 1) % reps.shape[0], lt)
+    red = dataclasses.replace(
+        net, name=net.name + "_merged", bus_vn_kv=net.bus_vn_kv[reps], bus_zone=net.bus_zone[reps], line_from_bus=lf, line_to_bus=lt,
+        br_from_bus=eid[net.br_from_bus], br_to_bus=eid[net.br_to_bus], load_bus=eid[net.load_bus], sgen_bus=eid[net.sgen_bus],
+        shunt_bus=eid[net.shunt_bus], ext_grid_bus=int(eid[net.ext_grid_bus]), bus_alias=np.arange(reps.shape[0]))
+    _REDUCED[key] = (net, red, eid)
+    return red, eid
+
+
+def _runpp_fused(net, p_load, q_load, p_sgen, q_sgen, raise_on_fail, cache, tolerance_mva, tolerance_is_pu):
+    red, eid = reduced_net(net)
+    r = runpp_restated(red, p_load, q_load, p_sgen, q_sgen, raise_on_fail, cache, tolerance_mva, tolerance_is_pu)
+    vm, va = r.vm_pu[eid], r.va_degree[eid]
+    pd_, qd = bus_demand(net, p_load, q_load, p_sgen, q_sgen)          # per ORIGINAL bus: own loads - own sgens
+    p_bus, q_bus = pd_.copy(), qd.copy()
+    if net.shunt_bus.shape[0]:
+        np.add.at(p_bus, net.shunt_bus, net.shunt_p_mw * vm[net.shunt_bus] ** 2)
+        np.add.at(q_bus, net.shunt_bus, net.shunt_q_mvar * vm[net.shunt_bus] ** 2)
+    # the ext_grid's own bus: its elements minus the ext_grid's injection.  The merged slack row of the reduced result is
+    # (everything on the group) - ext_grid, so ext_grid = (sum over the group of the per-bus values above) - that row
+    e0, slack_e = int(net.ext_grid_bus), int(eid[net.ext_grid_bus])
+    grp = eid == slack_e
+    p_ext, q_ext = p_bus[grp].sum() - r.p_mw[slack_e], q_bus[grp].sum() - r.q_mvar[slack_e]
+    p_bus[e0] -= p_ext; q_bus[e0] -= q_ext
+    return PPResult(vm_pu=vm, va_degree=va, p_mw=p_bus, q_mvar=q_bus, pl_mw=r.pl_mw, converged=r.converged, iterations=r.iterations,
+                    V=r.V[eid], Sbus=r.Sbus[eid])
 
 
 def residual_inf(net, v, p_load, q_load, p_sgen, q_sgen):
