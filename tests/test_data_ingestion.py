@@ -161,7 +161,6 @@ def test_what_cannot_be_represented_is_refused():
     for mutate, msg in [
         (lambda n: n["load"].__setitem__("const_z_percent", 30.0), "const_z_percent"),
         (lambda n: n["load"].__setitem__("const_i_percent", 10.0), "const_i_percent"),
-        (lambda n: n.__setitem__("switch", pd.DataFrame({"bus": [2], "element": [3], "et": ["b"], "type": ["CB"], "closed": [True]})), "bus-bus"),
         (lambda n: n.__setitem__("gen", pd.DataFrame({"bus": [3], "p_mw": [1.0], "vm_pu": [1.0], "in_service": [True]})), "net.gen"),
         (lambda n: n["trafo"].__setitem__("tap_step_degree", 2.0), "tap_step_degree"),
         (lambda n: n["trafo"].__setitem__("tap_phase_shifter", True), "tap_phase_shifter"),
@@ -171,6 +170,16 @@ def test_what_cannot_be_represented_is_refused():
         mutate(pnet)
         with pytest.raises(NotImplementedError, match=msg):
             from_pandapower(pnet)
+
+
+def test_closed_bus_bus_switch_becomes_a_bus_alias():
+    """round 4: bus fusion is converted (NetSpec.bus_alias), no longer refused; an open bus-bus switch changes nothing"""
+    pnet = substation_net()
+    pnet["switch"] = pd.DataFrame({"bus": [2, 4], "element": [3, 5], "et": ["b", "b"], "type": ["CB", "CB"], "closed": [True, False]})
+    a = from_pandapower(pnet)
+    want = np.arange(a.n_bus); want[3] = 2
+    assert np.array_equal(a.bus_alias, want)
+    assert not from_pandapower(substation_net()).has_fused_buses
 
 
 def test_host_plan_accepts_the_converted_net_and_builds_the_same_ybus():
