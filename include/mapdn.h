@@ -342,6 +342,12 @@ int mapdn_layernorm64_backward(const float* dy, const float* x, const float* gam
                                const float* rstd, float* dx, float* dgamma, float* dbeta, float* partial, int64_t rows,
                                int32_t relu, void* stream);
 
+/* Calibration aid for the HBM counters (tools/calibrate_traffic.py): copies rows x Bp x 16 bytes from src to dst (device pointers) with
+ * the solver's own global access pattern — raw-buffer 16-byte loads / stores of env-minor pair rows, 256 contiguous bytes per
+ * 16-lane worker (pattern 0) — or with whole waves on one row (pattern 1), so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be read
+ * against a known byte count.  Bp a multiple of 256, rows x Bp x 16 < 4 GiB. */
+int mapdn_debug_stream(const double* src, double* dst, int32_t rows, int32_t Bp, int32_t pattern, void* stream);
+
 /* counters (host, synchronises the given stream): number of envs whose last reset exhausted
  * max_tries; mean / max NR iterations of the last solve */
 int mapdn_stats(mapdn_handle* h, int64_t* reset_failures, double* mean_iters, int32_t* max_iters,

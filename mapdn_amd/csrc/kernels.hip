@@ -586,6 +586,43 @@ __global__ void __launch_bounds__(256) k_stats(Dev d, long long* out) {
 }
 
 // =================================================================================================
+// Calibration of the rocprofv3 HBM counters on THIS library's global access pattern (the MI355X guide: FETCH_SIZE reports half the
+// bytes of a wide 16 B / lane streaming read on gfx950; "other access widths and WRITE_SIZE are uncalibrated: calibrate on a
+// known byte count in your own access pattern").  k_nr_tree moves its scratch as raw-buffer 16-byte loads / stores of env-minor
+// pair rows: the 16 lanes of a worker touch 256 contiguous bytes, the four workers of a wave four different rows.
+//   pattern 0: that one (workgroup = 16 envs x 16 workers, worker w of pass i takes pair row 16 i + w);
+//   pattern 1: a whole wave on one row (64 lanes x 16 B = 1 KB contiguous: the guide's "wide coalesced streaming read").
+// Copies rows x Bp x 16 bytes from src to dst (known byte count each way).  tools/calibrate_traffic.py
+// =================================================================================================
+__global__ void __launch_bounds__(256) k_calib_stream(const double* __restrict__ src, double* __restrict__ dst, int rows, int Bp, int pattern) {
+  const unsigned pb = (unsigned)Bp * 16u;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(src), 0, (unsigned)rows * pb, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (unsigned)rows * pb, 0x00020000);
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  if (pattern == 0) {
+    const unsigned el = threadIdx.x & 15u, w = threadIdx.x >> 4, e = blockIdx.x * 16u + el;
+    for (unsigned r = w; r < (unsigned)rows; r += 16u) {
+      const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, e * 16u, r * pb, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rd, e * 16u, r * pb, 0);
+    }
+  } else {
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    for (unsigned r = blockIdx.y; r < (unsigned)rows; r += gridDim.y) {
+      const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, e * 16u, r * pb, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rd, e * 16u, r * pb, 0);
+    }
+  }
+}
+}  // namespace mapdn
+extern "C" int mapdn_debug_stream(const double* src, double* dst, int32_t rows, int32_t Bp, int32_t pattern, void* stream) {
+  if (!src || !dst || rows < 1 || Bp < 256 || (Bp & 255) || (size_t)rows * Bp * 16 >= 0xffffffffull) return MAPDN_E_INVALID;
+  if (pattern == 0) hipLaunchKernelGGL(mapdn::k_calib_stream, dim3(Bp / 16), dim3(256), 0, (hipStream_t)stream, src, dst, rows, Bp, 0);
+  else hipLaunchKernelGGL(mapdn::k_calib_stream, dim3(Bp / 256, 64), dim3(256), 0, (hipStream_t)stream, src, dst, rows, Bp, 1);
+  return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
+}
+namespace mapdn {
+
+// =================================================================================================
 // launchers (host)
 // =================================================================================================
 
