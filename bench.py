@@ -466,6 +466,8 @@ def main():
             # tree sweeps, neither roof.  The fraction is against the HBM roof as the contract prescribes (SURVEY 8(d):
             # compulsory traffic is tiny by construction); the f64 fraction is in `compute`.
             "roofline": {"bound": "hbm", "limited_by": "latency (rows x sweeps of the tree elimination; neither roof)", "kernel": kname,
+                         "kernel_scope": "one k_nr_tree launch = PV-bus injection (prologue, since round 4: it was a launch of its own, "
+                                         "6.8 us, before) + Newton-Raphson solve + reward / res_line / sgen commit epilogue",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                          "traffic_detail": tdetail,

@@ -288,10 +288,11 @@ int mapdn_get_obs_index(const mapdn_handle* h, int32_t* kind, int32_t* index);
 int mapdn_get_schedule(const mapdn_handle* h, int32_t n_waves, int32_t* n_rows, int32_t* rows, int32_t* parent);
 
 /* Host-side export of the launch geometry mapdn_create settled on (also for device == -1 handles, which assume a 256-CU
- * device): out[16] = solver (0 tree, 1 sparse, 2 dense), waves, lanes (envs per workgroup), lean, schedule rows, h_lds, g_lds,
+ * device): out[20] = solver (0 tree, 1 sparse, 2 dense), waves, lanes (envs per workgroup), lean, schedule rows, h_lds, g_lds,
  * rec_lds, flat_lds, line_lds, mm_pass, dynamic LDS bytes per workgroup, workgroups, workgroups resident per CU (model),
- * rounds of workgroups, modelled launch time in ns (the chooser's score; 0 when the geometry was forced). */
-int mapdn_get_nr_geometry(const mapdn_handle* h, int32_t* out16);
+ * rounds of workgroups, modelled launch time in ns (the chooser's score; 0 when the geometry was forced), fuse_inject (1: step()
+ * performs the PV-bus injection in the solver's prologue), number of buses in fused groups (bus_alias), electrical nodes, 0. */
+int mapdn_get_nr_geometry(const mapdn_handle* h, int32_t* out20);
 
 /* Host-side export of the flat-start factorisation the NR kernel's first iteration uses (plan check, CPU tests):
  * factors [n][12] per elimination position = S_calc (re, im), D^-1 (4, row-major), A_pk (re, im), G (4, row-major)

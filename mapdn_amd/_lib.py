@@ -79,7 +79,7 @@ TUNING_INT = ("nr_solver", "nr_waves", "nr_lanes", "nr_lean", "nr_h_lds", "nr_g_
 TUNING_F64 = ("nr_check_dx", "nr_check_quad", "tolerance_mva")
 NR_SOLVERS = dict(auto=0, tree=0, sparse=1, dense=2)
 GEOMETRY_KEYS = ("solver", "waves", "lanes", "lean", "rows", "h_lds", "g_lds", "rec_lds", "flat_lds", "line_lds", "mm_pass",
-                 "lds_bytes", "workgroups", "resident_per_cu", "rounds", "model_ns")
+                 "lds_bytes", "workgroups", "resident_per_cu", "rounds", "model_ns", "fuse_inject", "n_fused_buses", "n_nodes", "reserved")
 
 
 class CDims(C.Structure):
@@ -254,6 +254,6 @@ def make_cconfig(args: dict, env_id_offset: int = 0, tuning: dict | None = None)
 
 def nr_geometry(handle) -> dict:
     """what mapdn_create settled on for this handle (mapdn_get_nr_geometry)"""
-    out = (C.c_int32 * 16)()
+    out = (C.c_int32 * 20)()
     check(load().mapdn_get_nr_geometry(handle, out), handle)
     return dict(zip(GEOMETRY_KEYS, [int(x) for x in out]))

@@ -870,8 +870,11 @@ int mapdn_get_obs_index(const mapdn_handle* h, int32_t* kind, int32_t* index) {
 int mapdn_get_nr_geometry(const mapdn_handle* h, int32_t* out) {
   if (!h || !out) return MAPDN_E_INVALID;
   const mapdn_handle::Geo& g = h->geo;
-  const int32_t v[16] = {h->solver, g.W, g.L, g.lean, g.rows, g.h_lds, g.g_lds, g.rec_lds, g.flat_lds, g.line_lds, g.mm_pass,
-                         (int32_t)h->lds_bytes, (int32_t)g.wgs, g.resident, g.rounds, (int32_t)std::min(g.model_ns, 2.0e9)};
+  const bool fuse_possible = h->solver == 0 && !h->cfg.auto_reset && !knob_int(h->cfg.inject_full, "MAPDN_INJECT_FULL") &&
+                             knob_tri(h->cfg.fuse_inject, "MAPDN_FUSE_INJECT") != 2;
+  const int32_t v[20] = {h->solver, g.W, g.L, g.lean, g.rows, g.h_lds, g.g_lds, g.rec_lds, g.flat_lds, g.line_lds, g.mm_pass,
+                         (int32_t)h->lds_bytes, (int32_t)g.wgs, g.resident, g.rounds, (int32_t)std::min(g.model_ns, 2.0e9),
+                         (h->host_only ? fuse_possible : h->fuse_inject) ? 1 : 0, (int32_t)h->plan.fused_obus.size(), h->plan.nb, 0};
   std::memcpy(out, v, sizeof(v));
   if (h->solver == 1) out[2] = h->sp_lanes;
   return MAPDN_OK;

@@ -24,7 +24,8 @@ from oracle.env_restated import INFO_KEYS, VoltageControlOracle
 pytestmark = pytest.mark.gpu
 
 SCALE = {"case33": 0.8, "case141": 0.6, "case322": 0.8}     # train.py:34-42
-CONFIGS = [("case33", 4096), ("case141", 4096), ("case322", 1024), ("case322", 4096), ("case322", 8192)]
+CONFIGS = [("case33", 4096), ("case141", 4096), ("case322", 1024), ("case322", 4096), ("case322", 8192),
+           ("case141", 8192)]     # (the lean layout: not a BASELINE config, but the fastest published number — VERDICT r3 weak #2)
 LIMIT = 6            # episode_limit: every env hits the limit at call 4 (steps starts at 1, :100) and restarts at call 5
 N_CALLS = 9
 GEOMETRY_VARS = ("MAPDN_NR_WAVES", "MAPDN_NR_LANES", "MAPDN_NR_LEAN", "MAPDN_NR_SPARSE", "MAPDN_NR_DENSE",
@@ -97,3 +98,48 @@ def test_default_launch_matches_oracle_at_full_size(case, B, monkeypatch):
     env.close()
     for tw in twins.values():
         tw.close()
+
+
+@pytest.mark.parametrize("case,B", CONFIGS)
+def test_bench_configuration_matches_oracle_at_full_size(case, B, monkeypatch):
+    """what bench.py times: a handle WITHOUT auto_reset, i.e. (round 4) the PV-bus injection in the prologue of k_nr_tree — at every
+    BASELINE size, default geometry: 64 strided envs replayed on the oracle over noisy steps with a forced unsolvable step (that env
+    stays frozen: reward 0, terminated), then the whole-batch reset() the bench loop issues at the episode limit and more steps"""
+    for v in GEOMETRY_VARS + ("MAPDN_FUSE_INJECT", "MAPDN_INJECT_FULL"):
+        monkeypatch.delenv(v, raising=False)
+    net, prof = make_case(case)
+    env = VoltageControlBatch(net, prof, _args(case), n_envs=B, device="cuda:0", obs_dtype=torch.float64)
+    assert env.geometry()["fuse_inject"] == 1 and env.geometry()["solver"] == 0
+    watch = list(range(5, B, B // 64))[:64]
+    bad_env = watch[17]
+    oracles = {e: VoltageControlOracle(net, prof, _args(case), env_id=e, do_reset=False) for e in watch}
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(31)
+    frozen = set()
+    for phase in range(2):
+        obs, _ = env.reset()
+        assert env.stats()["reset_failures"] == 0
+        obs = obs.cpu().numpy()
+        for e, o in oracles.items():
+            oo, _ = o.reset()
+            assert np.abs(np.array(oo) - obs[e]).max() < 1e-9
+        frozen.clear()
+        for t in range(LIMIT - 1):                                  # steps starts at 1: the episode limit falls on the last of these calls
+            act = (torch.rand(B, net.n_sgen, device="cuda:0", generator=gen, dtype=torch.float32) * 2 - 1) * SCALE[case]
+            if phase == 0 and t == 1:
+                act[bad_env] = 60.0
+            r, term, info = env.step(act)
+            o_ = env.get_obs().cpu().numpy()
+            vm = env.results(("vm_pu",))["vm_pu"].cpu().numpy()
+            acpu, rcpu, tcpu, icpu = act.double().cpu().numpy(), r.cpu().numpy(), term.cpu().numpy(), info.cpu().numpy()
+            for e, o in oracles.items():
+                if e in frozen:
+                    assert rcpu[e] == 0.0 and tcpu[e] and (icpu[e] == 0).all(), (phase, t, e)
+                    continue
+                ro, to, io = o.step(acpu[e])
+                assert abs(ro - rcpu[e]) < 1e-9 and to == bool(tcpu[e]), (phase, t, e, ro, rcpu[e])
+                assert max(abs(io[k] - icpu[e, c]) for c, k in enumerate(INFO_KEYS)) < 1e-9, (phase, t, e)
+                assert np.abs(vm[e] - o.res.vm_pu).max() < 1e-9 and np.abs(np.array(o.get_obs()) - o_[e]).max() < 1e-9, (phase, t, e)
+                if to:
+                    frozen.add(e)
+        assert (bad_env in frozen) and len(frozen) == len(watch)     # everybody hit the limit, the forced env earlier
+    env.close()
