@@ -69,13 +69,13 @@ class CEnvConfig(C.Structure):
         ("nr_mm_pass", C.c_int32), ("sp_lanes", C.c_int32), ("inject_full", C.c_int32),
         ("nr_check_dx", C.c_double), ("nr_check_quad", C.c_double), ("debug_geometry", C.c_int32),
         ("tolerance_mva", C.c_double), ("tolerance_is_pu", C.c_int32), ("nr_init", C.c_int32),
-        ("fuse_inject", C.c_int32), ("overlap_advance", C.c_int32),
+        ("fuse_inject", C.c_int32), ("overlap_advance", C.c_int32), ("xcd_map", C.c_int32),
     ]
 
 
 # keys of the `tuning` dict of VoltageControlBatch (== the appended fields of mapdn_env_config)
 TUNING_INT = ("nr_solver", "nr_waves", "nr_lanes", "nr_lean", "nr_h_lds", "nr_g_lds", "nr_rec_lds", "nr_flat_lds", "nr_line_lds",
-              "nr_mm_pass", "sp_lanes", "inject_full", "debug_geometry", "tolerance_is_pu", "nr_init", "fuse_inject", "overlap_advance")
+              "nr_mm_pass", "sp_lanes", "inject_full", "debug_geometry", "tolerance_is_pu", "nr_init", "fuse_inject", "overlap_advance", "xcd_map")
 TUNING_F64 = ("nr_check_dx", "nr_check_quad", "tolerance_mva")
 NR_SOLVERS = dict(auto=0, tree=0, sparse=1, dense=2)
 GEOMETRY_KEYS = ("solver", "waves", "lanes", "lean", "rows", "h_lds", "g_lds", "rec_lds", "flat_lds", "line_lds", "mm_pass",

@@ -537,6 +537,9 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     const bool can = !d.auto_reset && !h->inject_full;
     if (fi == 1 && !can) { h->err = "fuse_inject = 1 needs a handle without auto_reset and without inject_full"; return MAPDN_E_INVALID; }
     h->fuse_inject = can && fi != 2;
+    // XCD-aligned env order of the wide kernels (tree solver; the group size is the solver's envs per workgroup)
+    const int xm = knob_tri(cfg->xcd_map, "MAPDN_XCD_MAP");
+    d.xcd_lanes = (xm != 2 && (64 % d.nr_lanes) == 0) ? d.nr_lanes : 0;
     h->overlap = knob_int(cfg->overlap_advance, "MAPDN_OVERLAP_ADVANCE") != 0;
     if (h->overlap && d.n_fused) { h->err = "overlap_advance is not available on a net with fused buses (bus_alias)"; return MAPDN_E_INVALID; }
     if (h->overlap) {

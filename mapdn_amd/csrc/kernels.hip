@@ -304,8 +304,8 @@ __global__ void __launch_bounds__(256) k_reset_begin(Dev d, const int64_t* __res
 // =================================================================================================
 __device__ __forceinline__ void advance_body(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off,
                                              unsigned blk_x, unsigned blk_y) {
-  const int e = (int)(blk_x * 256u + threadIdx.x);
-  if (e >= d.B) return;
+  const int e = d.xcd_lanes ? xcd_env(blk_x, threadIdx.x, 256u, (unsigned)d.xcd_lanes, (unsigned)(d.Bp / d.xcd_lanes)) : (int)(blk_x * 256u + threadIdx.x);
+  if (e < 0 || e >= d.B) return;
   const int npv = (d.ns + 1) >> 1, npl = (d.nl + 1) >> 1;
   const int npairs = do_profiles ? npv + npl : 0;
   const int nmb = 0;
@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256) k_commit_fused(Dev d) {
 template <typename T>
 __device__ __forceinline__ void gather_body(const double* __restrict__ base, const int32_t* rows_g, const double* scales_g,
                                             double scale_all, const int32_t* x_ptr_g, const int32_t* x_row_g,
-                                            T* __restrict__ out, int C, int B, int Bp, unsigned blk_x, unsigned blk_y, unsigned grd_x, unsigned grd_y) {
+                                            T* __restrict__ out, int C, int B, int Bp, unsigned blk_x, unsigned blk_y, unsigned grd_x, unsigned grd_y, int xl) {
   __shared__ T tile[64][65];                      // output-typed tile: 16.6 KB for f32 -> 8 workgroups per CU
   // descriptors are wave-uniform (a wave handles whole columns): read them through the constant
   // address space -> s_load on the scalar unit, no VMEM round trip ahead of the data loads
@@ -476,6 +476,9 @@ __device__ __forceinline__ void gather_body(const double* __restrict__ base, con
   }
   const int c0 = (int)bx * 64, e0 = (int)by * 64;
   const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // the 64 envs of this tile: consecutive, or (xl: XCD-aligned order) the tile's groups of xl envs of XCD by % 8
+  auto env_of = [&](int r) { return xl ? xcd_env(by, (unsigned)r, 64u, (unsigned)xl, (unsigned)(Bp / xl)) : e0 + r; };
+  const int etx = max(env_of(tx), 0);                // (a slot beyond the batch reads env 0 and is never written)
   int rw[16]; double sc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {                 // all descriptor reads first, then the data
@@ -486,12 +489,12 @@ __device__ __forceinline__ void gather_body(const double* __restrict__ base, con
   double v[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i)
-    v[i] = (rw[i] >= 0) ? base[(size_t)(rw[i] & ~GATHER_HAS_EXTRA) * Bp + e0 + tx] * sc[i] : 0.0;
+    v[i] = (rw[i] >= 0) ? base[(size_t)(rw[i] & ~GATHER_HAS_EXTRA) * Bp + etx] * sc[i] : 0.0;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     if (rw[i] >= 0 && (rw[i] & GATHER_HAS_EXTRA)) {   // wave-uniform, only the PV-bus columns
       const int c = c0 + ty + 4 * i;
-      for (int q = x_ptr[c]; q < x_ptr[c + 1]; ++q) v[i] += base[(size_t)x_row[q] * Bp + e0 + tx];
+      for (int q = x_ptr[c]; q < x_ptr[c + 1]; ++q) v[i] += base[(size_t)x_row[q] * Bp + etx];
     }
     tile[ty + 4 * i][tx] = (T)v[i];
   }
@@ -502,8 +505,8 @@ __device__ __forceinline__ void gather_body(const double* __restrict__ base, con
   const bool vec = (C % 4) == 0 && ((unsigned long long)out % (sizeof(T) * 4)) == 0;
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
-    const int r = er + 16 * pass, e = e0 + r, c = c0 + q4;
-    if (e >= B || c >= C) continue;
+    const int r = er + 16 * pass, e = env_of(r), c = c0 + q4;
+    if (e < 0 || e >= B || c >= C) continue;
     T* o = out + (size_t)e * C + c;
     if (vec) {                                   // C % 4 == 0 and c % 4 == 0: the 4 columns exist and are aligned
       struct alignas(sizeof(T) * 4) V4 { T a, b, c, d; };
@@ -519,8 +522,8 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_gather(const double* __restrict__ base, const int32_t* rows_g, const double* scales_g,
          double scale_all, const int32_t* x_ptr_g, const int32_t* x_row_g,
-         T* __restrict__ out, int C, int B, int Bp) {
-  gather_body<T>(base, rows_g, scales_g, scale_all, x_ptr_g, x_row_g, out, C, B, Bp, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+         T* __restrict__ out, int C, int B, int Bp, int xl) {
+  gather_body<T>(base, rows_g, scales_g, scale_all, x_ptr_g, x_row_g, out, C, B, Bp, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, xl);
 }
 
 #ifdef MAPDN_EXP_MERGED_POST
@@ -533,7 +536,7 @@ k_post_merged(Dev d, int add_noise, uint32_t sb_write_off, unsigned adv_gx, unsi
               unsigned g_gx, unsigned g_gy) {
   const unsigned na = adv_gx * adv_gy;
   if (blockIdx.x < na) advance_body(d, add_noise, 1, 1, sb_write_off, blockIdx.x % adv_gx, blockIdx.x / adv_gx);
-  else { const unsigned l = blockIdx.x - na; gather_body<T>(base, rows_g, scales_g, 1.0, x_ptr_g, x_row_g, out, C, d.B, d.Bp, l % g_gx, l / g_gx, g_gx, g_gy); }
+  else { const unsigned l = blockIdx.x - na; gather_body<T>(base, rows_g, scales_g, 1.0, x_ptr_g, x_row_g, out, C, d.B, d.Bp, l % g_gx, l / g_gx, g_gx, g_gy, 0); }
 }
 void launch_post_merged(const Dev& d, int add_noise, uint32_t sb_write_off, const double* base, const int32_t* rows, const double* scales,
                         const int32_t* x_ptr, const int32_t* x_row, void* out, int C, hipStream_t st) {
@@ -701,7 +704,8 @@ void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, 
 void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off, hipStream_t st) {
   const int rows = (do_profiles ? ((d.ns + 1) >> 1) + ((d.nl + 1) >> 1) : 0) + (do_commit ? d.nbo : 0);
   if (rows == 0) return;
-  hipLaunchKernelGGL(k_advance, dim3((d.B + 255) / 256, rows), dim3(256), 0, st, d, add_noise, do_profiles, do_commit, sb_write_off);
+  const unsigned gx = d.xcd_lanes ? xcd_blocks((unsigned)d.Bp, 256u, (unsigned)d.xcd_lanes) : (unsigned)((d.B + 255) / 256);
+  hipLaunchKernelGGL(k_advance, dim3(gx, rows), dim3(256), 0, st, d, add_noise, do_profiles, do_commit, sb_write_off);
 }
 void launch_commit_fused(const Dev& d, hipStream_t st) {
   if (d.n_fused > 0) hipLaunchKernelGGL(k_commit_fused, dim3((d.B + 255) / 256, d.n_fused), dim3(256), 0, st, d);
@@ -713,9 +717,10 @@ void launch_inject_sgen(const Dev& d, int mode, const void* actions, int dtype, 
 }
 void launch_gather(const Dev& d, const double* base, const int32_t* rows, const double* scales, double scale_all,
                    const int32_t* x_ptr, const int32_t* x_row, void* out, int dtype, int C, hipStream_t st) {
-  dim3 grid((C + 63) / 64, d.Bp / 64);
-  if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_gather<float>, grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (float*)out, C, d.B, d.Bp);
-  else hipLaunchKernelGGL(k_gather<double>, grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (double*)out, C, d.B, d.Bp);
+  const int xl = d.xcd_lanes;
+  dim3 grid((C + 63) / 64, xl ? xcd_blocks((unsigned)d.Bp, 64u, (unsigned)xl) : (unsigned)(d.Bp / 64));
+  if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_gather<float>, grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (float*)out, C, d.B, d.Bp, xl);
+  else hipLaunchKernelGGL(k_gather<double>, grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (double*)out, C, d.B, d.Bp, xl);
 }
 void launch_to_envminor(const Dev& d, const double* src, double* dst, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_to_envminor, dim3((n + 63) / 64, d.Bp / 64), dim3(256), 0, st, src, dst, n, d.B, d.Bp);

@@ -85,6 +85,11 @@ struct Dev {
   int32_t dense, dn_N, dn_lda;
   double* dn_A;              // k_nr_dense beyond 65 buses: per-env slabs [Bp][dn_N][dn_lda] of global memory for the Jacobian (else nullptr: LDS)
   const int32_t *gy_ptr, *gy_col; const double* gy_val;
+  // ---- XCD-aligned env order of the wide kernels (0 = off: block b serves envs 256 b ...): a k_nr_tree workgroup i serves envs
+  // [L i, L i + L) and lands on XCD i % 8 (observed), so env e "lives" on XCD (e / L) % 8; with xcd_lanes = L the wide kernels give
+  // block b the L-env groups of XCD b % 8, and what one kernel writes the next reads from the same XCD's L2 (the L2s of the eight XCDs
+  // are not coherent with each other: a line written on another XCD comes back from memory)
+  int32_t xcd_lanes;
   // ---- bus fusion (plan.hpp): original buses, nbo of them, vs electrical nodes (nb); all nullptr / 0 / nbo == nb without fusion
   int32_t nbo, n_fused, n_alias, n_slack_group;
   const int32_t *pos_of_obus, *cm_kind, *fused_obus, *ob_load_ptr, *ob_load_idx, *ob_sgen_ptr, *ob_sgen_idx, *slack_group, *alias_pos;
@@ -130,6 +135,14 @@ int nr_dense_prepare(const Dev& d);
 void launch_nr_dense(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st);
 int dense_solve_debug(const double* A, const double* b, double* x, int n, int batch, hipStream_t st);
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st);
+// slot t of block `blk` (T slots per block) of a wide kernel -> env (XCD-aligned order, see Dev::xcd_lanes); -1 beyond the batch
+__host__ __device__ static inline int xcd_env(unsigned blk, unsigned t, unsigned T, unsigned L, unsigned NG) {
+  const unsigned c = blk & 7u, chunk = blk >> 3, gpb = T / L;
+  const unsigned gid = (chunk * gpb + t / L) * 8u + c;
+  return gid < NG ? (int)(gid * L + t % L) : -1;
+}
+// blocks of T env slots that cover a padded batch of Bp envs in that order (a multiple of 8)
+static inline unsigned xcd_blocks(unsigned Bp, unsigned T, unsigned L) { const unsigned ng = Bp / L, gpb = T / L; return 8u * (((ng + 7u) / 8u + gpb - 1u) / gpb); }
 void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off, hipStream_t st);
 // res_bus p_mw / q_mvar of the buses of fused groups (their OWN elements), after the solve and before the profile advance
 void launch_commit_fused(const Dev& d, hipStream_t st);
