@@ -187,10 +187,10 @@ typedef struct mapdn_env_config {
   int32_t overlap_advance;          /* step(): 1 — the profile rows of the advance (next row of the tables + noise, independent of
                                        the solve) run on an internal side stream beside the solver launch, fork / join by events;
                                        0 (default) everything on the caller's stream.              env: MAPDN_OVERLAP_ADVANCE=1/0 */
-  int32_t xcd_map;                  /* 0 / 1 (default): the wide kernels (profile advance + commit, obs gather) serve the envs in the order
-                                       that keeps an env on the XCD its solver workgroup runs on (env e of an L-env workgroup i = e / L:
-                                       XCD i % 8), so that what one launch writes the next reads from that XCD's L2; 2: plain order
-                                       (same results)                                                     env: MAPDN_XCD_MAP=1/0 */
+  int32_t xcd_map;                  /* 1: the wide kernels (profile advance + commit, obs gather) serve the envs in the order that keeps an
+                                       env on the XCD its solver workgroup runs on (env e of an L-env workgroup i = e / L: XCD i % 8), so
+                                       that what one launch writes the next reads from that XCD's L2; 0 (default) / 2: plain order.
+                                       Same results; measured a wash (solver -1 us, gather +1 us), so it is opt-in.   env: MAPDN_XCD_MAP */
 } mapdn_env_config;
 
 typedef struct mapdn_dims_t {

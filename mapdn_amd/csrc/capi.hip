@@ -539,7 +539,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     h->fuse_inject = can && fi != 2;
     // XCD-aligned env order of the wide kernels (tree solver; the group size is the solver's envs per workgroup)
     const int xm = knob_tri(cfg->xcd_map, "MAPDN_XCD_MAP");
-    d.xcd_lanes = (xm != 2 && (64 % d.nr_lanes) == 0) ? d.nr_lanes : 0;
+    d.xcd_lanes = (xm == 1 && (64 % d.nr_lanes) == 0) ? d.nr_lanes : 0;     // opt-in: measured a wash (profiles/r04_xcd_map_ab.txt)
     h->overlap = knob_int(cfg->overlap_advance, "MAPDN_OVERLAP_ADVANCE") != 0;
     if (h->overlap && d.n_fused) { h->err = "overlap_advance is not available on a net with fused buses (bus_alias)"; return MAPDN_E_INVALID; }
     if (h->overlap) {

@@ -1064,3 +1064,22 @@ def test_tolerance_options_follow_the_oracle_on_a_net_with_sn_mva_100(tuning):
         assert np.abs(vm[e] - r.vm_pu).max() < (1e-9 if "tolerance_mva" not in tuning else 1e-6)
         its.add(int(it[e]))
     assert its
+
+
+@pytest.mark.parametrize("case,B", [("case141", 300), ("case322", 70)])
+def test_xcd_aligned_env_order_changes_nothing(case, B):
+    """mapdn_env_config.xcd_map = 1: the wide kernels walk the envs in XCD-aligned order (a permutation of which thread serves
+    which env) — bit-identical steps, observations, state and result tables, batch sizes that are not multiples of anything"""
+    net, prof, a = make(case, B, tuning=dict(xcd_map=1), episode_limit=6, auto_reset=True)
+    _, _, b = make(case, B, episode_limit=6, auto_reset=True)
+    oa, sa = a.reset(); ob, sb = b.reset()
+    assert torch.equal(oa, ob) and torch.equal(sa, sb)
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(3)
+    for t in range(8):
+        act = (torch.rand(B, net.n_sgen, device="cuda:0", generator=gen, dtype=torch.float64) * 2 - 1) * SCALE[case]
+        ra, ta, ia = a.step(act); rb, tb, ib = b.step(act)
+        assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(ia, ib)
+        assert torch.equal(a.get_obs(), b.get_obs()) and torch.equal(a.get_state(), b.get_state())
+        fa, fb = a.results(), b.results()
+        assert all(torch.equal(fa[k], fb[k]) for k in fa)
+    a.close(); b.close()
