@@ -298,13 +298,6 @@ int mapdn_get_schedule(const mapdn_handle* h, int32_t n_waves, int32_t* n_rows, 
  * performs the PV-bus injection in the solver's prologue), number of buses in fused groups (bus_alias), electrical nodes, 0. */
 int mapdn_get_nr_geometry(const mapdn_handle* h, int32_t* out20);
 
-/* Host-side export of the step records' index words for `workers` workers, `workers_per_wave` of them per wavefront (plan check, CPU
- * tests — in particular of the row-barrier analysis): words [workers * (*n_rows) * 4] = (flags, slots, chs, kp) per (worker, row) as
- * documented at `StepRec` in csrc/plan.hpp (S_* / SU_* bits incl. SU_FBAR / SU_XBAR / SU_SBAR; slot ids; node | parent << 16), overflow
- * child list in clist [*n_clist] (either may be NULL to query the sizes first). */
-int mapdn_get_schedule_records(const mapdn_handle* h, int32_t workers, int32_t workers_per_wave, int32_t* n_rows, uint32_t* words,
-                               int32_t* n_clist, int32_t* clist);
-
 /* Host-side export of the flat-start factorisation the NR kernel's first iteration uses (plan check, CPU tests):
  * factors [n][12] per elimination position = S_calc (re, im), D^-1 (4, row-major), A_pk (re, im), G (4, row-major)
  * of the block LU of the Jacobian at V = ext_grid vm_pu everywhere, unknowns [dtheta, d|V|/|V|];

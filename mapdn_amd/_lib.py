@@ -32,7 +32,7 @@ EXPORTS = (
     "mapdn_solve_only", "mapdn_get_ybus_dense", "mapdn_get_obs_index", "mapdn_get_schedule", "mapdn_get_flat_factors", "mapdn_stats", "mapdn_nr_timing",
     "mapdn_nr_time_ms", "mapdn_get_auto_reset_mask", "mapdn_dense_solve", "mapdn_step_obs", "mapdn_get_sparse_program", "mapdn_policy_forward",
     "mapdn_policy_forward_fits", "mapdn_layernorm64_forward", "mapdn_layernorm64_backward", "mapdn_layernorm64_backward_blocks",
-    "mapdn_get_nr_geometry", "mapdn_debug_stream", "mapdn_get_schedule_records",
+    "mapdn_get_nr_geometry", "mapdn_debug_stream",
 )
 
 _pd = C.POINTER(C.c_double)
@@ -142,7 +142,6 @@ def load():
     lib.mapdn_get_schedule.argtypes = [vp, C.c_int32, _pi, _pi, _pi]
     lib.mapdn_get_flat_factors.argtypes = [vp, _pd, _pi]
     lib.mapdn_get_nr_geometry.argtypes = [vp, _pi]
-    lib.mapdn_get_schedule_records.argtypes = [vp, C.c_int32, C.c_int32, _pi, C.POINTER(C.c_uint32), _pi, _pi]
     lib.mapdn_debug_stream.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.mapdn_get_sparse_program.argtypes = [vp, C.c_int32, _pi, _pi, _pi, _pi]
     lib.mapdn_policy_forward.argtypes = [vp] * 14 + [C.c_int32] * 4 + [C.c_float, vp]

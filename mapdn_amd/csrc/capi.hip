@@ -220,9 +220,9 @@ static int settle_tree_geometry(mapdn_handle* h, int Bp, int n_cu) {
   h->geo = best; h->sched = std::move(bestS); h->lds_bytes = best.lds;
   if (knob_int(c.debug_geometry, "MAPDN_DEBUG_GEOMETRY"))
     fprintf(stderr, "[mapdn] k_nr_tree geometry: W %d L %d lean %d rows %d cslots %d | LDS: h %d rec %d flat %d line %d G %d = %zu B | "
-                    "%ld workgroups, %d per CU, %d round(s), model %.1f us | row barriers kept: forward %d, x-propagation %d, x slots %d of %d\n",
+                    "%ld workgroups, %d per CU, %d round(s), model %.1f us\n",
             best.W, best.L, best.lean, best.rows, h->sched.n_cslots, best.h_lds, best.rec_lds, best.flat_lds, best.line_lds, best.g_lds,
-            best.lds, best.wgs, best.resident, best.rounds, best.model_ns * 1e-3, h->sched.n_fbar, h->sched.n_xbar, h->sched.n_sbar, best.rows - 1);
+            best.lds, best.wgs, best.resident, best.rounds, best.model_ns * 1e-3);
   return MAPDN_OK;
 }
 
@@ -905,18 +905,6 @@ int mapdn_get_schedule(const mapdn_handle* h, int32_t W, int32_t* n_rows, int32_
   *n_rows = S.R;
   if (rows) for (size_t i = 0; i < S.steps.size(); ++i) rows[i] = (S.steps[i].flags & S_LIVE) ? (int32_t)(S.steps[i].kp & 0xffffu) : -1;
   if (parent) std::memcpy(parent, h->plan.par.data(), h->plan.par.size() * sizeof(int32_t));
-  return MAPDN_OK;
-}
-
-int mapdn_get_schedule_records(const mapdn_handle* h, int32_t W, int32_t wpw, int32_t* n_rows, uint32_t* words, int32_t* n_clist, int32_t* clist) {
-  if (!h || !n_rows || W < 1 || W > 64 || wpw < 1 || W % wpw) return MAPDN_E_INVALID;
-  if (!h->plan.radial) return MAPDN_E_TOPOLOGY;
-  Schedule S;
-  build_schedule(h->plan, W, S, 0, wpw, 0);
-  *n_rows = S.R;
-  if (n_clist) *n_clist = (int32_t)S.clist.size();
-  if (words) for (size_t i = 0; i < S.steps.size(); ++i) { const StepRec& T = S.steps[i]; words[4 * i] = T.flags; words[4 * i + 1] = T.slots; words[4 * i + 2] = T.chs; words[4 * i + 3] = T.kp; }
-  if (clist) std::memcpy(clist, S.clist.data(), S.clist.size() * sizeof(int32_t));
   return MAPDN_OK;
 }
 

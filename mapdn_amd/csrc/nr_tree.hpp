@@ -73,11 +73,6 @@ static __device__ unsigned long long g_stamps[4096];   // one copy per translati
 #endif
 
 
-#ifdef MAPDN_ALL_ROW_BARRIERS          // A/B builds only: a barrier at every row, as in rounds 1-3
-#define NR_ROWBAR(x) true
-#else
-#define NR_ROWBAR(x) (x)
-#endif
 #ifndef MAPDN_EXP
 #define MAPDN_EXP 0      // debug experiments only (timing A/B builds); 0 in the product
 #endif
@@ -586,9 +581,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
           if (flu & SU_W_ANY) cs[(size_t)(slots & 1023u) * (4 * L)] = d2{apk_r, apk_i};
         }
         STAMP2(202 + 10 * K);
-        // the row barrier orders LDS hand-offs between waves: it is only issued when the NEXT row holds a cross-wave hazard
-        // (SU_FBAR, workgroup-uniform, from the host's replay of the schedule) or this is the last row of the sweep
-        if (W > 1 && (r >= R - 1 || NR_ROWBAR(uni(Tq[(u + 1) % 3].ix.x) & SU_FBAR))) lds_barrier();
+        if (W > 1) lds_barrier();
         STAMP(100 + K);
       }
     };
@@ -664,7 +657,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const unsigned k = kp & 0xffffu;
         if (HL) sH[(size_t)k * L] = d2{h0, h1}; else bst2(d2{h0, h1}, rs, voE + k * bb, sF_H);
         STAMP2(232);
-        if (W > 1 && (r >= R - 1 || NR_ROWBAR(uni(Tq[(u + 1) % 3].ix.x) & SU_FBAR))) lds_barrier();
+        if (W > 1) lds_barrier();
         STAMP(102);
         ++r;
       }
@@ -740,7 +733,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const uint32_t fl = ixq[u % 4].x, kp = ixq[u % 4].w;
         const uint32_t flu = uni(fl);
         const unsigned k = kp & 0xffffu, p = kp >> 16;
-        if (W > 1 && NR_ROWBAR(flu & SU_XBAR)) lds_barrier();   // some wave of this row reads an x another wave wrote since the last barrier
         // (1) the parent's x (its h slot, already overwritten; 0 for elimination roots), this node's h and G
         d2 q;
         const bool xr = (flu & SU_XR_ANY) != 0;
@@ -761,6 +753,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         x0 = y0; x1 = y1;
         sH[(size_t)k * L] = d2{y0, y1};            // (idle steps: the trash node)
         STAMP2(242);
+        if (W > 1) lds_barrier();
         STAMP(110 + SRC);
         --r;
       }
@@ -771,7 +764,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const uint32_t fl = ixs[i].x, kp = ixs[i].w;
         const uint32_t flu = uni(fl);
         const unsigned k = kp & 0xffffu, p = kp >> 16;
-        if (W > 1 && NR_ROWBAR(flu & SU_XBAR)) lds_barrier();
         d2 q;
         const bool xr = (flu & SU_XR_ANY) != 0;
         if (xr) q = sH[(size_t)p * L];
@@ -784,10 +776,10 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const double y1 = hh.y - (G2 * p0 + G3 * p1);
         x0 = y0; x1 = y1;
         sH[(size_t)k * L] = d2{y0, y1};
+        if (W > 1) lds_barrier();
         STAMP(110 + SRC);
       }
     });
-    if (W > 1) lds_barrier();                      // the update pass reads every node's x, whichever wave wrote it
     // (3) update of every node from its x, three nodes per pass (loads first)
     for (unsigned kb = t; kb < n; kb += (unsigned)UPN * Wt) {
       unsigned kk[UPN]; d2 xx[UPN], vv[UPN]; bool lv[UPN];
@@ -907,7 +899,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const uint32_t fl = ix.x, slots = ix.y;
         const uint32_t flu = uni(fl);
         const unsigned k = ix.w & 0xffffu;
-        if (W > 1 && NR_ROWBAR(flu & SU_SBAR)) lds_barrier();   // a cross-wave hazard on an x slot since the last barrier
         // (1) the parent's x (ZERO slot for slack parents), this node's factors and voltage
         d2 q;
         const bool xr = (flu & SU_XR_ANY) != 0;
@@ -930,6 +921,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         x0 = y0; x1 = y1;
         if (flu & SU_XW_ANY) xs[(size_t)((slots >> 10) & 1023u) * L] = d2{y0, y1};   // TRASH unless S_X_OUT
         py0 = y0; py1 = y1; pvk = vk; pk = k; pLive = (fl & S_LIVE) != 0;
+        if (W > 1) lds_barrier();
         STAMP(110 + SRC);
         --r;
       }
@@ -940,7 +932,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       const uint32_t fl = ix.x, slots = ix.y;
       const uint32_t flu = uni(fl);
       const unsigned k = ix.w & 0xffffu;
-      if (W > 1 && NR_ROWBAR(flu & SU_SBAR)) lds_barrier();
       d2 q;
       const bool xr = (flu & SU_XR_ANY) != 0;
       if (xr) q = xs[(size_t)((slots >> 20) & 1023u) * L];
@@ -957,6 +948,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       x0 = y0; x1 = y1;
       if (flu & SU_XW_ANY) xs[(size_t)((slots >> 10) & 1023u) * L] = d2{y0, y1};
       py0 = y0; py1 = y1; pvk = vk; pk = k; pLive = (fl & S_LIVE) != 0;
+      if (W > 1) lds_barrier();
       STAMP(110 + SRC);
     });
     apply_update(py0, py1, pvk, pk, pLive);

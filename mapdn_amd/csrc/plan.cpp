@@ -638,75 +638,6 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw, i
       }
       for (int w = w0; w < w0 + Sw; ++w) S.steps[(size_t)w * R + r].flags |= (gmax << SU_GMAX_SHIFT) | any;
     }
-  // ---- which row barriers are needed (SU_FBAR / SU_XBAR / SU_SBAR, plan.hpp): replay of the LDS accesses, wave by wave
-  S.n_fbar = S.n_xbar = S.n_sbar = 0;
-  if (W / Sw > 1) {
-    const int nslot_c = S.n_cslots, nslot_x = S.n_xslots;
-    auto wave_of_w = [&](int w) { return (uint32_t)1u << (w / Sw); };
-    auto mark = [&](int r, uint32_t bit) { for (int w = 0; w < W; ++w) S.steps[(size_t)w * R + r].flags |= bit; };
-    // forward: reads = the contribution slots of the slot children, write = the own slot (TRASH / ZERO never matter)
-    {
-      std::vector<uint32_t> wm(nslot_c, 0), rm(nslot_c, 0);
-      for (int r = 0; r < R; ++r) {
-        bool need = false;
-        std::vector<std::pair<int, uint32_t>> rd, wr;
-        for (int w = 0; w < W; ++w) {
-          const int k = rows[r][w];
-          if (k < 0) continue;
-          const uint32_t me = wave_of_w(w);
-          const int cc = chain_child(k);
-          if (cc >= 0 && !carry_out[cc]) rd.push_back({oslot[cc], me});
-          for (int ch : children[k]) if (ch != cc) rd.push_back({oslot[ch], me});
-          if (P.par[k] < n && !carry_out[k]) wr.push_back({oslot[k], me});
-        }
-        for (auto& a : rd) if (wm[a.first] & ~a.second) need = true;
-        for (auto& a : wr) if ((wm[a.first] | rm[a.first]) & ~a.second) need = true;
-        if (need && r > 0) { mark(r, SU_FBAR); ++S.n_fbar; std::fill(wm.begin(), wm.end(), 0u); std::fill(rm.begin(), rm.end(), 0u); }
-        for (auto& a : rd) rm[a.first] |= a.second;
-        for (auto& a : wr) wm[a.first] |= a.second;
-      }
-    }
-    // backward, x in place of h (node-indexed LDS array): read = the parent's entry (unless carried in registers), write = the own
-    {
-      std::vector<uint32_t> wm(n + 2, 0), rm(n + 2, 0);
-      for (int r = R - 1; r >= 0; --r) {
-        bool need = false;
-        std::vector<std::pair<int, uint32_t>> rd, wr;
-        for (int w = 0; w < W; ++w) {
-          const int k = rows[r][w];
-          if (k < 0) continue;
-          const uint32_t me = wave_of_w(w);
-          if (P.par[k] < n && !carry_out[k]) rd.push_back({P.par[k], me});
-          wr.push_back({k, me});
-        }
-        for (auto& a : rd) if (wm[a.first] & ~a.second) need = true;
-        for (auto& a : wr) if ((wm[a.first] | rm[a.first]) & ~a.second) need = true;
-        if (need && r < R - 1) { mark(r, SU_XBAR); ++S.n_xbar; std::fill(wm.begin(), wm.end(), 0u); std::fill(rm.begin(), rm.end(), 0u); }
-        for (auto& a : rd) rm[a.first] |= a.second;
-        for (auto& a : wr) wm[a.first] |= a.second;
-      }
-    }
-    // backward through x slots: read = the parent's x slot (unless carried), write = the own x slot when some child reads it
-    {
-      std::vector<uint32_t> wm(nslot_x, 0), rm(nslot_x, 0);
-      for (int r = R - 1; r >= 0; --r) {
-        bool need = false;
-        std::vector<std::pair<int, uint32_t>> rd, wr;
-        for (int w = 0; w < W; ++w) {
-          const int k = rows[r][w];
-          if (k < 0) continue;
-          const uint32_t me = wave_of_w(w);
-          if (P.par[k] < n && !carry_out[k]) rd.push_back({xslot[P.par[k]], me});
-          if (xslot[k] >= 0) wr.push_back({xslot[k], me});
-        }
-        for (auto& a : rd) if (wm[a.first] & ~a.second) need = true;
-        for (auto& a : wr) if ((wm[a.first] | rm[a.first]) & ~a.second) need = true;
-        if (need && r < R - 1) { mark(r, SU_SBAR); ++S.n_sbar; std::fill(wm.begin(), wm.end(), 0u); std::fill(rm.begin(), rm.end(), 0u); }
-        for (auto& a : rd) rm[a.first] |= a.second;
-        for (auto& a : wr) wm[a.first] |= a.second;
-      }
-    }
-  }
   if (S.clist.empty()) S.clist.push_back(0);
   // ---- canonical child lists (independent of W: the same order the records above encode)
   S.mm_ptr.assign(1, 0); S.mm_child.clear();

@@ -63,13 +63,6 @@ enum : uint32_t {
   SU_XW_ANY = 512u,      // backward: some worker writes a real x slot
   SU_XR_ANY = 1024u,     // backward: some worker reads its parent's x from a slot
   SU_SLACK_ANY = 2048u,  // some worker's node neighbours the slack (cks != 0)
-  // WORKGROUP-uniform (the same value in every record of a row): which row barriers are actually needed (round 4).  A row barrier
-  // orders LDS hand-offs between WAVES (a wave's own LDS accesses execute in order); the host replays the schedule's slot /
-  // node accesses and marks the rows before which some wave reads what another wave wrote since the last barrier, or rewrites
-  // what another wave read or wrote (plan.cpp::build_schedule).  Rows without the mark run without a barrier in front.
-  SU_FBAR = 4096u,       // forward sweeps (rows 0 .. R-1): a barrier is needed BEFORE this row
-  SU_XBAR = 8192u,       // backward x-propagation in the LDS h array (rows R-1 .. 0): ... before this row
-  SU_SBAR = 16384u,      // backward sweep through x slots (layouts without h in LDS): ... before this row
 };
 
 struct Schedule {
@@ -83,7 +76,6 @@ struct Schedule {
   // LDS slots (reused by interval colouring): 4 resp. 1 pairs of doubles per env each; the last two of each kind
   // are the ZERO slot (n-2) and the TRASH slot (n-1)
   int32_t n_cslots = 0, n_xslots = 0;
-  int32_t n_fbar = 0, n_xbar = 0, n_sbar = 0;   // rows that keep their barrier in the three sweep forms (of R each)
   // Flat-start constants, [W][R][FLAT_N] doubles: at the flat start every voltage equals the slack set-point, so
   // the Jacobian of the FIRST Newton iteration — and with it the whole block LU — is the same for all envs
   // and is factorised here once; only the right-hand side (mismatch against the env's Sbus) is per env.

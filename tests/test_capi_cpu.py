@@ -338,90 +338,3 @@ def test_tolerance_options(lib):
     for tuning, ok in ((None, True), (dict(tolerance_is_pu=1), True), (dict(tolerance_mva=1e-6), True), (dict(tolerance_mva=-1.0), False)):
         rc, g = _geometry(lib, net, 64, tuning)
         assert (rc == 0) == ok, g
-
-
-def _records(lib, net, workers, wpw):
-    rc, h = host_handle(lib, net)
-    assert rc == 0
-    R, ncl = C.c_int32(), C.c_int32()
-    assert lib.mapdn_get_schedule_records(h, workers, wpw, C.byref(R), None, C.byref(ncl), None) == 0
-    words = np.zeros(workers * R.value * 4, np.uint32)
-    clist = np.zeros(max(ncl.value, 1), np.int32)
-    assert lib.mapdn_get_schedule_records(h, workers, wpw, C.byref(R), words.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(ncl),
-                                          clist.ctypes.data_as(_lib._pi)) == 0
-    lib.mapdn_destroy(h)
-    return words.reshape(workers, R.value, 4), clist, R.value
-
-
-@pytest.mark.parametrize("case,workers,wpw", [("case141", 16, 4), ("case141", 8, 4), ("case141_deep", 16, 4), ("case322", 32, 8),
-                                              ("case322", 16, 4), ("case33", 8, 4), ("case33", 16, 2), ("case141", 32, 8)])
-def test_row_barrier_analysis_leaves_no_cross_wave_hazard(case, workers, wpw):
-    """Round 4: k_nr_tree issues a row barrier only where the host's replay of the schedule found a cross-WAVE hazard since the last
-    barrier (SU_FBAR / SU_XBAR / SU_SBAR in the step records).  Independent check from the exported records: walk the rows, track who
-    wrote / read every contribution slot, x slot and node entry since the last KEPT barrier, and demand that no read-after-write,
-    write-after-read or write-after-write pair of two different waves is left without a barrier in between — for the forward
-    sweeps (contribution slots), the x-propagation in the LDS h array (node entries) and the x-slot form.  Also: barriers do get
-    dropped (that is the point), and they are workgroup-uniform."""
-    lib = _lib.load()
-    net, _ = make_case(case)
-    rec, clist, R = _records(lib, net, workers, wpw)
-    n = net.n_bus - 1
-    S_CARRY_OUT, S_SCRATCH_OUT, S_X_OUT, S_LIVE = 2, 8, 16, 32
-    FBAR, XBAR, SBAR = 4096, 8192, 16384
-    flags, slots, chs, kp = rec[..., 0], rec[..., 1], rec[..., 2], rec[..., 3]
-    for bit in (FBAR, XBAR, SBAR):                                   # workgroup-uniform
-        assert ((flags & bit != 0).all(0) | (flags & bit == 0).all(0)).all()
-    ncs, nxs = int((slots & 1023).max()) + 1, int(((slots >> 10) & 1023).max()) + 1
-    c_zero, c_trash = ncs - 2, ncs - 1                               # the last two of each kind: ZERO, TRASH
-
-    def walk(order, bar_bit, accesses):
-        """accesses(w, r) -> (reads, writes) lists of resource ids; returns the number of barriers kept"""
-        wm, rm, kept = {}, {}, 0
-        for r in order:
-            if flags[0, r] & bar_bit:
-                wm.clear(); rm.clear(); kept += 1
-            for w in range(workers):
-                if not flags[w, r] & S_LIVE:
-                    continue
-                me = w // wpw
-                rd, wr = accesses(w, r)
-                for s_ in rd:
-                    assert all(v == me for v in wm.get(s_, ())), ("RAW", case, r, w, s_)
-                for s_ in wr:
-                    assert all(v == me for v in wm.get(s_, ())) and all(v == me for v in rm.get(s_, ())), ("WAR/WAW", case, r, w, s_)
-            for w in range(workers):
-                if not flags[w, r] & S_LIVE:
-                    continue
-                me = w // wpw
-                rd, wr = accesses(w, r)
-                for s_ in rd:
-                    rm.setdefault(s_, set()).add(me)
-                for s_ in wr:
-                    wm.setdefault(s_, set()).add(me)
-        return kept
-
-    def fwd(w, r):
-        nch = int((flags[w, r] >> 16) & 255)
-        kids = [int(chs[w, r] & 1023), int((chs[w, r] >> 10) & 1023), int((chs[w, r] >> 20) & 1023)][:min(nch, 3)]
-        if nch > 3:
-            cptr = int(flags[w, r] >> 24) | (int(slots[w, r] >> 30) << 8) | (int(chs[w, r] >> 30) << 10)
-            kids += [int(x) for x in clist[cptr:cptr + nch - 3]]
-        wr = [int(slots[w, r] & 1023)] if flags[w, r] & S_SCRATCH_OUT else []
-        return [k for k in kids if k not in (c_zero, c_trash)], wr
-
-    def xprop(w, r):
-        k, p = int(kp[w, r] & 0xffff), int(kp[w, r] >> 16)
-        rd = [p] if (p < n and not flags[w, r] & S_CARRY_OUT) else []
-        return rd, [k]
-
-    def xslots(w, r):
-        rd = [int((slots[w, r] >> 20) & 1023)] if (flags[w, r] & S_SCRATCH_OUT) else []
-        wr = [int((slots[w, r] >> 10) & 1023)] if flags[w, r] & S_X_OUT else []
-        return rd, wr
-
-    kept_f = walk(range(R), FBAR, fwd)
-    kept_x = walk(range(R - 1, -1, -1), XBAR, xprop)
-    kept_s = walk(range(R - 1, -1, -1), SBAR, xslots)
-    assert kept_f <= R - 1 and kept_x <= R - 1 and kept_s <= R - 1
-    if case != "case322":
-        assert kept_x < R - 1                                        # some barriers really are dropped
