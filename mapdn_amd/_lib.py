@@ -118,6 +118,12 @@ def load():
                 f"{LIB_PATH} not found and could not be built ({exc}); build it with "
                 "`python -m mapdn_amd.build` (hipcc --offload-arch=gfx950); there is no CPU fallback") from exc
     lib = C.CDLL(os.environ.get("MAPDN_LIB_PATH", LIB_PATH))      # override: A/B experiments with debug builds only
+    if "MAPDN_LIB_PATH" in os.environ:                              # an OLDER build for a same-box A/B may lack the newest exports
+        for name in EXPORTS:
+            if not hasattr(lib, name):
+                def _missing(*a, _n=name, **k):
+                    raise AttributeError(f"{os.environ['MAPDN_LIB_PATH']} does not export {_n}")
+                lib.__dict__[name] = _missing
     vp = C.c_void_p
     lib.mapdn_last_error.restype = C.c_char_p
     lib.mapdn_last_error.argtypes = [vp]

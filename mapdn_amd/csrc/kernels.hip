@@ -16,31 +16,11 @@
 #include <type_traits>
 
 #include "kernels.hpp"
+#include "philox.hpp"     // Philox4x32-10, u53 (host-checkable: tests/test_philox.py)
 #include "nr_common.hpp"
 #include "nr_inst_list.hpp"
 
 namespace mapdn {
-
-// =================================================================================================
-// Philox4x32-10 (Salmon et al. SC'11), keyed (seed) / counter (env, draw, stream, block);
-// mapping documented in oracle/philox.py (the checker restates the same mapping).
-// =================================================================================================
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
-  return (double)(((uint64_t)(hi >> 5) << 26) + (uint64_t)(lo >> 6));
-}
 
 // =================================================================================================
 // K1  inject — _clip_reactive_power (voltage_control_env.py:568-572) for step(), or the random
@@ -164,6 +144,8 @@ k_inject(Dev d, int mode, const AT* __restrict__ actions, const double* __restri
 //      (PV bus, env) — 22 rows instead of 141 on the 141-bus feeder: q = a sqrt(s_max^2 - p^2) of the bus's sgens and
 //      Sbus = -((loads) - (sgens)) / sn, the same expressions in the same order as k_inject (bit-identical).
 //      An env that auto-resets in this call (rare) refreshes ALL its loads here, its threads striding over the load buses.
+//      (n_sgb >= 1 always: build_plan refuses a net without sgens — no agents — so row 0, which does the step bookkeeping, exists.)
+//      Round 4: in step() of a handle without auto_reset these rows run in the prologue of k_nr_tree instead (nr_tree.hpp).
 template <typename AT>
 __global__ void __launch_bounds__(256)
 k_inject_sgen(Dev d, int mode, const AT* __restrict__ actions, int add_noise) {
@@ -455,7 +437,7 @@ __global__ void __launch_bounds__(256) k_commit_fused(Dev d) {
 //                both the env-minor reads and the env-major writes are coalesced.
 // =================================================================================================
 #define GATHER_HAS_EXTRA 0x40000000   // flag bit in a row descriptor: the column has add-back rows (x_ptr/x_row)
-template <typename T>
+template <typename T, bool XM>
 __device__ __forceinline__ void gather_body(const double* __restrict__ base, const int32_t* rows_g, const double* scales_g,
                                             double scale_all, const int32_t* x_ptr_g, const int32_t* x_row_g,
                                             T* __restrict__ out, int C, int B, int Bp, unsigned blk_x, unsigned blk_y, unsigned grd_x, unsigned grd_y, int xl) {
@@ -477,7 +459,7 @@ __device__ __forceinline__ void gather_body(const double* __restrict__ base, con
   const int c0 = (int)bx * 64, e0 = (int)by * 64;
   const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // the 64 envs of this tile: consecutive, or (xl: XCD-aligned order) the tile's groups of xl envs of XCD by % 8
-  auto env_of = [&](int r) { return xl ? xcd_env(by, (unsigned)r, 64u, (unsigned)xl, (unsigned)(Bp / xl)) : e0 + r; };
+  auto env_of = [&](int r) { if constexpr (XM) return xcd_env(by, (unsigned)r, 64u, (unsigned)xl, (unsigned)(Bp / xl)); else return e0 + r; };
   const int etx = max(env_of(tx), 0);                // (a slot beyond the batch reads env 0 and is never written)
   int rw[16]; double sc[16];
 #pragma unroll
@@ -518,12 +500,12 @@ __device__ __forceinline__ void gather_body(const double* __restrict__ base, con
   }
 }
 
-template <typename T>
+template <typename T, bool XM>
 __global__ void __launch_bounds__(256)
 k_gather(const double* __restrict__ base, const int32_t* rows_g, const double* scales_g,
          double scale_all, const int32_t* x_ptr_g, const int32_t* x_row_g,
          T* __restrict__ out, int C, int B, int Bp, int xl) {
-  gather_body<T>(base, rows_g, scales_g, scale_all, x_ptr_g, x_row_g, out, C, B, Bp, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, xl);
+  gather_body<T, XM>(base, rows_g, scales_g, scale_all, x_ptr_g, x_row_g, out, C, B, Bp, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, xl);
 }
 
 #ifdef MAPDN_EXP_MERGED_POST
@@ -536,7 +518,7 @@ k_post_merged(Dev d, int add_noise, uint32_t sb_write_off, unsigned adv_gx, unsi
               unsigned g_gx, unsigned g_gy) {
   const unsigned na = adv_gx * adv_gy;
   if (blockIdx.x < na) advance_body(d, add_noise, 1, 1, sb_write_off, blockIdx.x % adv_gx, blockIdx.x / adv_gx);
-  else { const unsigned l = blockIdx.x - na; gather_body<T>(base, rows_g, scales_g, 1.0, x_ptr_g, x_row_g, out, C, d.B, d.Bp, l % g_gx, l / g_gx, g_gx, g_gy, 0); }
+  else { const unsigned l = blockIdx.x - na; gather_body<T, false>(base, rows_g, scales_g, 1.0, x_ptr_g, x_row_g, out, C, d.B, d.Bp, l % g_gx, l / g_gx, g_gx, g_gy, 0); }
 }
 void launch_post_merged(const Dev& d, int add_noise, uint32_t sb_write_off, const double* base, const int32_t* rows, const double* scales,
                         const int32_t* x_ptr, const int32_t* x_row, void* out, int C, hipStream_t st) {
@@ -719,8 +701,13 @@ void launch_gather(const Dev& d, const double* base, const int32_t* rows, const 
                    const int32_t* x_ptr, const int32_t* x_row, void* out, int dtype, int C, hipStream_t st) {
   const int xl = d.xcd_lanes;
   dim3 grid((C + 63) / 64, xl ? xcd_blocks((unsigned)d.Bp, 64u, (unsigned)xl) : (unsigned)(d.Bp / 64));
-  if (dtype == MAPDN_F32) hipLaunchKernelGGL(k_gather<float>, grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (float*)out, C, d.B, d.Bp, xl);
-  else hipLaunchKernelGGL(k_gather<double>, grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (double*)out, C, d.B, d.Bp, xl);
+  if (dtype == MAPDN_F32) {
+    if (xl) hipLaunchKernelGGL((k_gather<float, true>), grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (float*)out, C, d.B, d.Bp, xl);
+    else hipLaunchKernelGGL((k_gather<float, false>), grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (float*)out, C, d.B, d.Bp, 0);
+  } else {
+    if (xl) hipLaunchKernelGGL((k_gather<double, true>), grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (double*)out, C, d.B, d.Bp, xl);
+    else hipLaunchKernelGGL((k_gather<double, false>), grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (double*)out, C, d.B, d.Bp, 0);
+  }
 }
 void launch_to_envminor(const Dev& d, const double* src, double* dst, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_to_envminor, dim3((n + 63) / 64, d.Bp / 64), dim3(256), 0, st, src, dst, n, d.B, d.Bp);

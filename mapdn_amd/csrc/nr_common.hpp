@@ -117,9 +117,7 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
   // store of this kernel can alias them and batches the loads of the unrolled, branch-free loops
   // (only the stores are predicated).  Envs whose solve failed (rare) take statistics from the
   // rolled-back state in a separate slow path.
-  typedef const __attribute__((address_space(4))) int32_t* c_i32;
   typedef const __attribute__((address_space(4))) double* c_f64;
-  const c_i32 bus_of_pos = (c_i32)(unsigned long long)d.bus_of_pos;
   const c_f64 linec = (c_f64)(unsigned long long)d.lines;          // LineFlow = {int32 fpos, tpos; double y[8]} = 9 x 8 bytes
   // ---- buses: voltage statistics for the reward; the solution (e, f) goes to Vout, from where the
   // wide k_post kernel (thread per bus x env) commits res_bus — |V|, angle(V), p_mw, q_mvar — for the
