@@ -284,88 +284,91 @@ __global__ void __launch_bounds__(256) k_reset_begin(Dev d, const int64_t* __res
 //      write the buffer of the next solve (`sb_write_off`: the other one in step(), the same one in reset(), where the
 //      advance comes before the solve); the host flips the buffers after every step.
 // =================================================================================================
-__device__ __forceinline__ void advance_body(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off,
-                                             unsigned blk_x, unsigned blk_y) {
-  const int e = d.xcd_lanes ? xcd_env(blk_x, threadIdx.x, 256u, (unsigned)d.xcd_lanes, (unsigned)(d.Bp / d.xcd_lanes)) : (int)(blk_x * 256u + threadIdx.x);
-  if (e < 0 || e >= d.B) return;
-  const int npv = (d.ns + 1) >> 1, npl = (d.nl + 1) >> 1;
-  const int npairs = do_profiles ? npv + npl : 0;
-  const int nmb = 0;
-  const size_t S = (size_t)d.Bp;
-  double2* const sbw = (double2*)((char*)d.nrbuf + sb_write_off) + e;
-  if ((int)blk_y >= npairs + nmb) {
-    // ---- K6 commit of res_bus (pandapower pfsoln/_extract_results) for envs whose solve was accepted:
-    // vm_pu = |V|, va = angle(V), p_mw/q_mvar = bus demand (-Sbus*sn) + shunt*|V|^2, slack = -(V conj(I))*sn
-    if (!d.commit[e]) return;
-    const int b_ = (int)blk_y - npairs - nmb;      // ORIGINAL bus (bus fusion: several buses may share an electrical node)
-    const int k = d.pos_of_obus[b_];               // elimination position of its node, n == slack
-    const size_t o = (size_t)b_ * S + e;
-    double v, P, Q;
-    if (k < d.n) {
-      const double* vo = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * k) * S + e;
-      const double2 sb = ((const double2*)((const char*)d.nrbuf + d.sb_off))[(size_t)d.sb_index[k] * S + e];
-      const double ek = vo[(size_t)VO_E * S], fk = vo[(size_t)VO_F * S];
-      v = sqrt(ek * ek + fk * fk);
-      d.va[o] = atan2(fk, ek);
-      P = -sb.x * d.sn; Q = -sb.y * d.sn;
-    } else {
-      v = d.vroot; d.va[o] = 0.0;
-      double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;     // I = Y_rr V_r + sum_neighbours Y_rk V_k
-      for (int j = 0; j < d.n_root_children; ++j) {
-        const double* cb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * d.root_children[j]) * S + e;
-        const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ec = cb[(size_t)VO_E * S], fc = cb[(size_t)VO_F * S];
-        ir += g * ec - b * fc; ii += g * fc + b * ec;
-      }
-      P = -(d.vroot * ir) * d.sn; Q = (d.vroot * ii) * d.sn;
-    }
-    d.vm[o] = v;
-    if (d.cm_kind[b_] == 0) { d.res_p[o] = P + d.shunt_p[k] * v * v; d.res_q[o] = Q + d.shunt_q[k] * v * v; }
-    // (a bus of a fused group reports its OWN elements: k_commit_fused wrote p_mw / q_mvar before this launch)
+// the pieces of k_advance as device functions:
+// Box-Muller pair of Philox block b of a stream: the two half-normal noise factors of columns 2b, 2b + 1
+__device__ __forceinline__ void noise_pair(const Dev& d, int e, uint32_t draw, int stream, int b, double& n0, double& n1) {
+  uint32_t x[4];
+  philox4x32_10((uint32_t)(d.env_id_offset + e), draw, (uint32_t)stream, (uint32_t)b, d.seed_lo, d.seed_hi, x);
+  const double u1 = (u53(x[0], x[1]) + 0.5) * (1.0 / 9007199254740992.0);
+  const double u2 = u53(x[2], x[3]) * (1.0 / 9007199254740992.0);
+  const double r = sqrt(-2.0 * log(u1));
+  double sn_, cs_;
+  sincos(2.0 * M_PI * u2, &sn_, &cs_);
+  n0 = fabs(r * cs_); n1 = fabs(r * sn_);
+}
+// K6 commit of one res_bus row (ORIGINAL bus b_; bus fusion: several buses may share an electrical node) of env e, for envs whose
+// solve was accepted (pandapower pfsoln / _extract_results): vm_pu = |V|, va = angle(V), p_mw / q_mvar = bus demand (-Sbus sn) +
+// shunt |V|^2, slack = -(V conj(I)) sn.  WANT: the caller needs the row as res_bus holds it after this call in any case
+// (a fused commit + obs launch was tried and removed: profiles/r04_wide_kernel_parts_experiment.txt).
+template <bool WANT>
+__device__ __forceinline__ void commit_bus(const Dev& d, int b_, int e, size_t S, double& v, double& va, double& P, double& Q) {
+  const size_t o = (size_t)b_ * S + e;
+  if (!d.commit[e]) {
+    if (WANT) { v = d.vm[o]; va = d.va[o]; P = d.res_p[o]; Q = d.res_q[o]; }
     return;
   }
+  const int k = d.pos_of_obus[b_];               // elimination position of its node, n == slack
+  if (k < d.n) {
+    const double* vo = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * k) * S + e;
+    const double2 sb = ((const double2*)((const char*)d.nrbuf + d.sb_off))[(size_t)d.sb_index[k] * S + e];
+    const double ek = vo[(size_t)VO_E * S], fk = vo[(size_t)VO_F * S];
+    v = sqrt(ek * ek + fk * fk);
+    va = atan2(fk, ek);
+    P = -sb.x * d.sn; Q = -sb.y * d.sn;
+  } else {
+    v = d.vroot; va = 0.0;
+    double ir = d.yrr0 * d.vroot, ii = d.yrr1 * d.vroot;     // I = Y_rr V_r + sum_neighbours Y_rk V_k
+    for (int j = 0; j < d.n_root_children; ++j) {
+      const double* cb = d.nrbuf + ((size_t)d.r_vout + (size_t)VOF * d.root_children[j]) * S + e;
+      const double g = d.root_y[2 * j], b = d.root_y[2 * j + 1], ec = cb[(size_t)VO_E * S], fc = cb[(size_t)VO_F * S];
+      ir += g * ec - b * fc; ii += g * fc + b * ec;
+    }
+    P = -(d.vroot * ir) * d.sn; Q = (d.vroot * ii) * d.sn;
+  }
+  d.va[o] = va;
+  d.vm[o] = v;
+  if (d.cm_kind[b_] == 0) { P = P + d.shunt_p[k] * v * v; Q = Q + d.shunt_q[k] * v * v; d.res_p[o] = P; d.res_q[o] = Q; }
+  // (a bus of a fused group reports its OWN elements: k_commit_fused wrote p_mw / q_mvar before this launch)
+  else if (WANT) { P = d.res_p[o]; Q = d.res_q[o]; }
+}
+// PV columns 2b, 2b + 1 of the next profile row (one Philox block + one Box-Muller pair)
+template <bool WANT>
+__device__ __forceinline__ void advance_pv_pair(const Dev& d, int e, int b, int add_noise, size_t S, double& v0, double& v1) {
+  const int j0 = 2 * b, j1 = 2 * b + 1;
   const int64_t row = d.adv_row[e];
-  if (row < 0 || row >= d.T) return;               // never read outside the table
-  const uint32_t draw = d.adv_draw[e];
-  // Box-Muller pair of Philox block b of a stream: the two half-normal noise factors of columns 2b, 2b + 1
-  auto noise_pair = [&](int stream, int b, double& n0, double& n1) {
-    uint32_t x[4];
-    philox4x32_10((uint32_t)(d.env_id_offset + e), draw, (uint32_t)stream, (uint32_t)b, d.seed_lo, d.seed_hi, x);
-    const double u1 = (u53(x[0], x[1]) + 0.5) * (1.0 / 9007199254740992.0);
-    const double u2 = u53(x[2], x[3]) * (1.0 / 9007199254740992.0);
-    const double r = sqrt(-2.0 * log(u1));
-    double sn_, cs_;
-    sincos(2.0 * M_PI * u2, &sn_, &cs_);
-    n0 = fabs(r * cs_); n1 = fabs(r * sn_);
-  };
-  int b = (int)blk_y;                              // pair index over [pv pairs | load pairs]
-  if (b < npv) {
-    const int j0 = 2 * b, j1 = 2 * b + 1;
-    const double* trow = d.table + (size_t)row * d.ncol;
-    double v0 = trow[j0], v1 = (j1 < d.ns) ? trow[j1] : 0.0;
-    if (add_noise) {
-      double n0, n1;
-      noise_pair(STREAM_PV, b, n0, n1);
-      v0 += d.stdv[j0] * n0;
-      if (j1 < d.ns) v1 += d.stdv[j1] * n1;
-    }
-    d.cur_pv[(size_t)j0 * S + e] = v0;
-    if (j1 < d.ns) d.cur_pv[(size_t)j1 * S + e] = v1;
+  if (row < 0 || row >= d.T) {                     // never read outside the table
+    if (WANT) { v0 = d.cur_pv[(size_t)j0 * S + e]; v1 = (j1 < d.ns) ? d.cur_pv[(size_t)j1 * S + e] : 0.0; }
     return;
   }
-  // ---- two loads: their P (stream LOAD_P) and Q (stream LOAD_Q) values.  A load that is ALONE on its bus is the bus's whole
-  // load sum (0 + p * scaling, as k_inject forms it), so the (P, Q) pair goes straight to where the next k_inject_sgen / solve
-  // reads it, as one 16-byte store — ld_dest[li] = entry << 2 | kind: kind 0 Sbus entry of the next solve, 1 bus_ld row of a
-  // PV bus, 2 nothing (bus with several loads: the rows above; loads on the slack bus)
-  b -= npv;
+  const double* trow = d.table + (size_t)row * d.ncol;
+  v0 = trow[j0]; v1 = (j1 < d.ns) ? trow[j1] : 0.0;
+  if (add_noise) {
+    double n0, n1;
+    noise_pair(d, e, d.adv_draw[e], STREAM_PV, b, n0, n1);
+    v0 += d.stdv[j0] * n0;
+    if (j1 < d.ns) v1 += d.stdv[j1] * n1;
+  }
+  d.cur_pv[(size_t)j0 * S + e] = v0;
+  if (j1 < d.ns) d.cur_pv[(size_t)j1 * S + e] = v1;
+}
+// loads 2b, 2b + 1: their P (stream LOAD_P) and Q (stream LOAD_Q) values.  A load that is ALONE on its bus is the bus's whole
+// load sum (0 + p * scaling, as k_inject forms it), so the (P, Q) pair goes straight to where the next k_inject_sgen / solve
+// reads it, as one 16-byte store — ld_dest[li] = entry << 2 | kind: kind 0 Sbus entry of the next solve, 1 bus_ld row of a
+// PV bus, 2 nothing (bus with several loads: the rows above; loads on the slack bus)
+__device__ __forceinline__ void advance_load_pair(const Dev& d, int e, int b, int add_noise, size_t S, uint32_t sb_write_off) {
+  const int64_t row = d.adv_row[e];
+  if (row < 0 || row >= d.T) return;
+  double2* const sbw = (double2*)((char*)d.nrbuf + sb_write_off) + e;
   const int j0 = 2 * b, j1 = 2 * b + 1;
   const bool has1 = j1 < d.nl;
   const double* trp = d.table + (size_t)row * d.ncol + d.ns;
   const double* trq = trp + d.nl;
   double p0 = trp[j0], q0 = trq[j0], p1 = has1 ? trp[j1] : 0.0, q1 = has1 ? trq[j1] : 0.0;
   if (add_noise) {
+    const uint32_t draw = d.adv_draw[e];
     double n0, n1, m0, m1;
-    noise_pair(STREAM_LOAD_P, b, n0, n1);
-    noise_pair(STREAM_LOAD_Q, b, m0, m1);
+    noise_pair(d, e, draw, STREAM_LOAD_P, b, n0, n1);
+    noise_pair(d, e, draw, STREAM_LOAD_Q, b, m0, m1);
     p0 += d.stdv[d.ns + j0] * n0; q0 += d.stdv[d.ns + d.nl + j0] * m0;
     if (has1) { p1 += d.stdv[d.ns + j1] * n1; q1 += d.stdv[d.ns + d.nl + j1] * m1; }
   }
@@ -379,6 +382,22 @@ __device__ __forceinline__ void advance_body(const Dev& d, int add_noise, int do
   };
   put(j0, p0, q0);
   if (has1) put(j1, p1, q1);
+}
+
+__device__ __forceinline__ void advance_body(const Dev& d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off,
+                                             unsigned blk_x, unsigned blk_y) {
+  const int e = d.xcd_lanes ? xcd_env(blk_x, threadIdx.x, 256u, (unsigned)d.xcd_lanes, (unsigned)(d.Bp / d.xcd_lanes)) : (int)(blk_x * 256u + threadIdx.x);
+  if (e < 0 || e >= d.B) return;
+  const int npv = (d.ns + 1) >> 1, npl = (d.nl + 1) >> 1;
+  const int npairs = do_profiles ? npv + npl : 0;
+  const size_t S = (size_t)d.Bp;
+  if ((int)blk_y >= npairs) {                      // rows [npairs, npairs + nbo): thread = (original bus, env)
+    double v, va, P, Q;
+    commit_bus<false>(d, (int)blk_y - npairs, e, S, v, va, P, Q);
+    return;
+  }
+  if ((int)blk_y < npv) { double v0, v1; advance_pv_pair<false>(d, e, (int)blk_y, add_noise, S, v0, v1); }
+  else advance_load_pair(d, e, (int)blk_y - npv, add_noise, S, sb_write_off);
 }
 
 __global__ void __launch_bounds__(256) k_advance(Dev d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off) {
