@@ -26,10 +26,16 @@ __device__ __forceinline__ double barrier(int type, double v) {
     }
     case MAPDN_BARRIER_BOWL: {                                                 // bowl.py:6-12
       const double dv = fabs(v - 1.0);
-      if (dv > 0.05) return 2.0 * dv - 0.095;
-      const double scale = 0.1;
-      const double nrm = 1.0 / sqrt(2.0 * M_PI * scale * scale) * exp(-0.5 * (v - 1.0) * (v - 1.0) / (scale * scale));
-      return -0.01 * nrm + 0.04;
+      // inside the band the exponent x = -(v - 1)^2 / (2 scale^2) lies in [-0.125, 0]: exp as its Taylor polynomial to x^11 (remainder
+      // < 3e-20; libm's exp with its range reduction and the division by scale^2 were a third of the epilogue's bus loop, which runs
+      // at one wave per SIMD), the division as a multiplication by the rounded 1 / (2 scale^2) — within 2 ulp of the reference's value
+      const double x = (v - 1.0) * (v - 1.0) * -50.0;
+      double ex = 1.0 / 39916800.0;
+      ex = fma(ex, x, 1.0 / 3628800.0); ex = fma(ex, x, 1.0 / 362880.0); ex = fma(ex, x, 1.0 / 40320.0); ex = fma(ex, x, 1.0 / 5040.0);
+      ex = fma(ex, x, 1.0 / 720.0); ex = fma(ex, x, 1.0 / 120.0); ex = fma(ex, x, 1.0 / 24.0); ex = fma(ex, x, 1.0 / 6.0);
+      ex = fma(ex, x, 0.5); ex = fma(ex, x, 1.0); ex = fma(ex, x, 1.0);
+      const double inside = fma(-0.01 * 3.9894228040143270, ex, 0.04);       // 1 / sqrt(2 pi scale^2) = 3.98942280401432...
+      return (dv > 0.05) ? 2.0 * dv - 0.095 : inside;
     }
     default: {                                                                 // bump.py:6-12
       if (fabs(v) < 1.0) return exp(-1.0 / (1.0 - v * v * v * v));
