@@ -821,17 +821,14 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     }
     STAMP(31);
     if (W > 1) lds_barrier();
-    // (2) S_k, F_k, verdict.  The index words run three turns ahead, the constants and the Sbus entry (whose address needs the index
-    // word) two turns ahead: a turn is ~350 cycles of arithmetic, an L2 round trip ~1 000 — one turn of distance (rounds 3-4) made
-    // every turn wait for its own operands (9 turns x 1 020 cycles on the 141-bus feeder).
+    // (2) S_k, F_k, verdict.  The index words run two turns ahead, the constants and the Sbus entry (whose address needs the index
+    // word) one turn ahead.
     {
       const unsigned voSb = d.sb_off + e * 16u;
       auto cl = [&](int j) { return row_s(min(j, NPs - 1), TB); };
-      u32x4 ixA = bldu4(rsP, voP, 0u), ixB = bldu4(rsP, voP, cl(1)), ixC = bldu4(rsP, voP, cl(2));
+      u32x4 ixA = bldu4(rsP, voP, 0u), ixB = bldu4(rsP, voP, cl(1));
       d2 ykkN = bld2(rsP, voP + 16u, 0u), ykpN = bld2(rsP, voP + 32u, 0u), cksN = bld2(rsP, voP + 64u, 0u);
       d2 sbN = bld2(rs, voSb + (ixA.w & 0xffffu) * pb, 0u);
-      d2 ykkM = bld2(rsP, voP + 16u, cl(1)), ykpM = bld2(rsP, voP + 32u, cl(1)), cksM = bld2(rsP, voP + 64u, cl(1));
-      d2 sbM = bld2(rs, voSb + (ixB.w & 0xffffu) * pb, 0u);
       for (int j = 0; j < NPs; ++j) {
         const u32x4 ix = ixA;
         const d2 ykk = ykkN, ykp = ykpN, cks = cksN, sb = sbN;
@@ -840,11 +837,10 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const d2 vk = sV[(size_t)k * L], vp = sV[(size_t)pp * L];
         const d2 a0 = sH[(size_t)(ix.y & 0xffffu) * L], a1 = sH[(size_t)(ix.y >> 16) * L], a2 = sH[(size_t)(ix.z & 0xffffu) * L];
         {
-          ykkN = ykkM; ykpN = ykpM; cksN = cksM; sbN = sbM;
-          const unsigned s2 = cl(j + 2);
-          ykkM = bld2(rsP, voP + 16u, s2); ykpM = bld2(rsP, voP + 32u, s2); cksM = bld2(rsP, voP + 64u, s2);
-          sbM = bld2(rs, voSb + (ixC.w & 0xffffu) * pb, 0u);
-          ixA = ixB; ixB = ixC; ixC = bldu4(rsP, voP, cl(j + 3));
+          const unsigned s1 = cl(j + 1);
+          ykkN = bld2(rsP, voP + 16u, s1); ykpN = bld2(rsP, voP + 32u, s1); cksN = bld2(rsP, voP + 64u, s1);
+          sbN = bld2(rs, voSb + (ixB.w & 0xffffu) * pb, 0u);
+          ixA = ixB; ixB = bldu4(rsP, voP, cl(j + 2));
         }
         const double gkk = ykk.x, bkk = ykk.y, gkp = ykp.x, bkp = ykp.y;
         const double ek = vk.x, fk = vk.y, ep = vp.x, fp = vp.y;
@@ -864,6 +860,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         }
         const double sr = base_r + aS0, si = base_i + aS1;
         note_mismatch(sr - sb.x, si - sb.y, (ix.x & 1u) != 0);
+        STAMP(120);
       }
     }
   };

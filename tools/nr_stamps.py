@@ -39,7 +39,7 @@ st = [(out[i] >> 48, out[i] & 0xffffffffffff) for i in range(1, n + 1)]
 if n == 0:
     n = max(i for i in range(1, 4096) if out[i])
 names = {1: "start", 2: "init done", 10: "fwd begin", 11: "fwd verdict", 12: "bwd begin", 30: "update pass", 31: "mismatch pass: A_pk written", 20: "solve end", 21: "epilogue body done", 22: "epilogue: buses done", 23: "epilogue: lines done", 24: "epilogue: combine + outputs done",
-         100: "row full", 101: "row light", 102: "row flat", 110: "row bwd(flat G)", 111: "row bwd"}
+         100: "row full", 101: "row light", 102: "row flat", 110: "row bwd(flat G)", 111: "row bwd", 120: "mismatch pass turn"}
 if any(sid >= 200 for sid, _ in st):       # fine mode: dump the sequence of one full fwd sweep and one bwd sweep
     seq = [(sid, c) for sid, c in st]
     out_lines = []
