@@ -124,7 +124,7 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
   // (only the stores are predicated).  Envs whose solve failed (rare) take statistics from the
   // rolled-back state in a separate slow path.
   typedef const __attribute__((address_space(4))) double* c_f64;
-  const c_f64 linec = (c_f64)(unsigned long long)d.lines;          // LineFlow = {int32 fpos, tpos; double y[8]} = 9 x 8 bytes
+  const c_f64 linec = (c_f64)(unsigned long long)d.lines;          // LineFlow = {int32 fpos, tpos; double c[4]} = 5 x 8 bytes
   // ---- buses: voltage statistics for the reward; the solution (e, f) goes to Vout, from where the
   // wide k_post kernel (thread per bus x env) commits res_bus — |V|, angle(V), p_mw, q_mvar — for the
   // envs flagged in d.commit: throughput work does not belong in this 512-wave kernel
@@ -181,21 +181,19 @@ __device__ __forceinline__ void nr_epilogue(const Dev& d, int mode, double* __re
   stamp(22);
   if (t == 0 && valid) d.commit[e] = commitf ? 1 : 0;
   // ---- res_line.pl_mw = Re(Sf + St) * sn   (out-of-service rows: fpos = tpos = slack, all-zero admittances)
-  // LineFlow = {int32 fpos, tpos; double y[8]}: from LDS when staged there, else through the constant address space
+  // LineFlow = {int32 fpos, tpos; double c[4]}: from LDS when staged there, else through the constant address space
   auto line_loop = [&](auto Lbase) {
 #pragma unroll 4
     for (unsigned l = t; l < (unsigned)d.n_line; l += Wt) {
-      const auto Lc = Lbase + (size_t)l * 9;
+      const auto Lc = Lbase + (size_t)l * 5;
       const double ab = Lc[0];
       const unsigned a = (unsigned)__double2loint(ab), b = (unsigned)__double2hiint(ab);
-      const double yffr = Lc[1], yffi = Lc[2], yftr = Lc[3], yfti = Lc[4], ytfr = Lc[5], ytfi = Lc[6], yttr = Lc[7], ytti = Lc[8];
+      const double gff = Lc[1], gtt = Lc[2], gs = Lc[3], bd = Lc[4];
       const d2 vf = sV[(size_t)a * L], vt = sV[(size_t)b * L];
       const double ef = vf.x, ff = vf.y, et = vt.x, ft = vt.y;
-      const double ifr = yffr * ef - yffi * ff + yftr * et - yfti * ft;
-      const double ifi = yffr * ff + yffi * ef + yftr * ft + yfti * et;
-      const double itr = ytfr * ef - ytfi * ff + yttr * et - ytti * ft;
-      const double iti = ytfr * ff + ytfi * ef + yttr * ft + ytti * et;
-      const double pl = ((ef * ifr + ff * ifi) + (et * itr + ft * iti)) * d.sn;
+      // Re(Vf conj(If) + Vt conj(It)) with the products of the two ends collected: w = Vf conj(Vt) = wr + j wi
+      const double wr = ef * et + ff * ft, wi = ff * et - ef * ft;
+      const double pl = ((gff * (ef * ef + ff * ff) + gtt * (et * et + ft * ft)) + (gs * wr + bd * wi)) * d.sn;
       if (commitf) d.pl[(size_t)l * SB + e] = pl;
       line_loss += pl;
     }

@@ -285,7 +285,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   double* s_epi = (double*)(cs - el) + el;                   // epilogue partials s_epi[(q*Wt + worker)*L], 10*64*W doubles: they re-use the
                                                              // contribution slots, dead once the solve is over (host: cslots >= nr_min_cslots)
   int32_t* s_clist = (int32_t*)(s_ok + 64 * W + 64 * W * sizeof(double));
-  double* s_lines = (double*)(s_clist + ((d.nr_nclist + 3) & ~3));   // LineFlow rows of net.line (9 doubles each) when d.nr_line_lds
+  double* s_lines = (double*)(s_clist + ((d.nr_nclist + 3) & ~3));   // LineFlow rows of net.line (5 doubles each) when d.nr_line_lds
   // step records (80 B) and flat-start constants (96 B) of all workers, when they fit (d.nr_rec_lds / d.nr_flat_lds): a
   // worker's 16 lanes read the same 16 bytes (LDS broadcast)
   char* s_rec = (char*)s_lines + (d.nr_line_lds ? nr_line_bytes(d.n_line) : 0);

@@ -305,8 +305,7 @@ static int build_plan_nodes(const mapdn_netspec& net, const mapdn_netspec& net_o
     if (!net.line_in_service[l]) { L = LineFlow{}; L.fpos = L.tpos = P.n; continue; }   // zero admittances at the slack: pl == 0
     const PiBranch& b = line_pi[l];
     L.fpos = P.pos_of_bus[b.f]; L.tpos = P.pos_of_bus[b.t];
-    L.yff[0] = b.yff.real(); L.yff[1] = b.yff.imag(); L.yft[0] = b.yft.real(); L.yft[1] = b.yft.imag();
-    L.ytf[0] = b.ytf.real(); L.ytf[1] = b.ytf.imag(); L.ytt[0] = b.ytt.real(); L.ytt[1] = b.ytt.imag();
+    L.c[0] = b.yff.real(); L.c[1] = b.ytt.real(); L.c[2] = b.yft.real() + b.ytf.real(); L.c[3] = b.yft.imag() - b.ytf.imag();
   }
 
   // ---- element CSR by position ------------------------------------------------------------------

@@ -93,9 +93,9 @@ struct Schedule {
 // per-step layout of Schedule::flat
 enum { FL_SR = 0, FL_SI, FL_I0, FL_I1, FL_I2, FL_I3, FL_APR, FL_API, FL_G0, FL_G1, FL_G2, FL_G3, FLAT_N };
 
-struct LineFlow {      // pi-model admittances of one net.line row for res_line.pl_mw
-  int32_t fpos, tpos;  // elimination positions (n == root); out of service: both n with zero admittances
-  double yff[2], yft[2], ytf[2], ytt[2];
+struct LineFlow {      // res_line.pl_mw of one net.line row from the pi model: pl / sn = Re(Sf + St) with If = yff Vf + yft Vt,
+  int32_t fpos, tpos;  // It = ytf Vf + ytt Vt  ==  gff |Vf|^2 + gtt |Vt|^2 + (gft + gtf) a + (bft - btf) b,  a + jb = Vf conj(Vt)
+  double c[4];         // gff, gtt, gft + gtf, bft - btf  (elimination positions, n == root; out of service: both n, all zero)
 };
 
 struct Plan {
