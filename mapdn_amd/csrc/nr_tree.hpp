@@ -731,12 +731,12 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       for (int u = 0; u < 4; ++u) {
         if (r < KP) break;
         const uint32_t fl = ixq[u % 4].x, kp = ixq[u % 4].w;
-        const uint32_t flu = uni(fl);
         const unsigned k = kp & 0xffffu, p = kp >> 16;
-        // (1) the parent's x (its h slot, already overwritten; 0 for elimination roots), this node's h and G
-        d2 q;
-        const bool xr = (flu & SU_XR_ANY) != 0;
-        if (xr) q = sH[(size_t)p * L];
+        // (1) the parent's x (its h slot, already overwritten; the slack entry holds the 0 that elimination roots read), this node's
+        // h and G.  The parent's entry is read unconditionally, together with h (round 4): behind the SU_XR_ANY hint the read sat in a
+        // scalar branch of its own and its wait came before the other requests of the row were issued — one more exposed LDS round trip
+        // in a row that consists of three.
+        const d2 q = sH[(size_t)p * L];
         const d2 hh = sH[(size_t)k * L];
         d2 g01, g23;
         if constexpr (SRC == 1 && GL) { g01 = sG[(size_t)(2 * k) * L]; g23 = sG[(size_t)(2 * k + 1) * L]; }
@@ -747,7 +747,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         if constexpr (SRC == 0 || gG) { g01 = g01q[u % 4]; g23 = g23q[u % 4]; }
         // (2) x_k = h_k - G_k x_parent
         const bool cout = (fl & S_CARRY_OUT) != 0;
-        const double p0 = cout ? x0 : (xr ? q.x : 0.0), p1 = cout ? x1 : (xr ? q.y : 0.0);
+        const double p0 = cout ? x0 : q.x, p1 = cout ? x1 : q.y;
         const double y0 = hh.x - (g01.x * p0 + g01.y * p1);
         const double y1 = hh.y - (g23.x * p0 + g23.y * p1);
         x0 = y0; x1 = y1;
@@ -762,15 +762,12 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       constexpr int i = decltype(ic)::value;
       {
         const uint32_t fl = ixs[i].x, kp = ixs[i].w;
-        const uint32_t flu = uni(fl);
         const unsigned k = kp & 0xffffu, p = kp >> 16;
-        d2 q;
-        const bool xr = (flu & SU_XR_ANY) != 0;
-        if (xr) q = sH[(size_t)p * L];
+        const d2 q = sH[(size_t)p * L];
         const d2 hh = sH[(size_t)k * L];
         SCHED_FENCE();
         const bool cout = (fl & S_CARRY_OUT) != 0;
-        const double p0 = cout ? x0 : (xr ? q.x : 0.0), p1 = cout ? x1 : (xr ? q.y : 0.0);
+        const double p0 = cout ? x0 : q.x, p1 = cout ? x1 : q.y;
         const double G0 = a_get(Ga[i][0], Ga[i][1]), G1 = a_get(Ga[i][2], Ga[i][3]), G2 = a_get(Ga[i][4], Ga[i][5]), G3 = a_get(Ga[i][6], Ga[i][7]);
         const double y0 = hh.x - (G0 * p0 + G1 * p1);
         const double y1 = hh.y - (G2 * p0 + G3 * p1);
