@@ -897,10 +897,9 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const uint32_t fl = ix.x, slots = ix.y;
         const uint32_t flu = uni(fl);
         const unsigned k = ix.w & 0xffffu;
-        // (1) the parent's x (ZERO slot for slack parents), this node's factors and voltage
-        d2 q;
-        const bool xr = (flu & SU_XR_ANY) != 0;
-        if (xr) q = xs[(size_t)((slots >> 20) & 1023u) * L];
+        // (1) the parent's x (ZERO slot for slack parents, carried parents and idle steps: read unconditionally, so that the request
+        // leaves with the row's other LDS reads instead of waiting in a hint branch of its own), this node's factors and voltage
+        const d2 q = xs[(size_t)((slots >> 20) & 1023u) * L];
         const d2 hh = gH ? fq[u % 4].h : sH[(size_t)k * L];
         const d2 g01 = gG ? fq[u % 4].g01 : sG[(size_t)(2 * k) * L];
         const d2 g23 = gG ? fq[u % 4].g23 : sG[(size_t)(2 * k + 1) * L];
@@ -913,7 +912,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         SCHED_FENCE();
         // (3) x_k = h_k - G_k x_parent
         const bool cout = (fl & S_CARRY_OUT) != 0;
-        const double p0 = cout ? x0 : (xr ? q.x : 0.0), p1 = cout ? x1 : (xr ? q.y : 0.0);
+        const double p0 = cout ? x0 : q.x, p1 = cout ? x1 : q.y;
         const double y0 = hh.x - (g01.x * p0 + g01.y * p1);
         const double y1 = hh.y - (g23.x * p0 + g23.y * p1);
         x0 = y0; x1 = y1;
@@ -930,9 +929,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       const uint32_t fl = ix.x, slots = ix.y;
       const uint32_t flu = uni(fl);
       const unsigned k = ix.w & 0xffffu;
-      d2 q;
-      const bool xr = (flu & SU_XR_ANY) != 0;
-      if (xr) q = xs[(size_t)((slots >> 20) & 1023u) * L];
+      const d2 q = xs[(size_t)((slots >> 20) & 1023u) * L];
       const d2 vk = sV[(size_t)k * L];
       SCHED_FENCE();
       apply_update(py0, py1, pvk, pk, pLive);
@@ -940,7 +937,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       const double hh0 = a_get(Ha[i][0], Ha[i][1]), hh1 = a_get(Ha[i][2], Ha[i][3]);
       const double G0 = a_get(Ga[i][0], Ga[i][1]), G1 = a_get(Ga[i][2], Ga[i][3]), G2 = a_get(Ga[i][4], Ga[i][5]), G3 = a_get(Ga[i][6], Ga[i][7]);
       const bool cout = (fl & S_CARRY_OUT) != 0;
-      const double p0 = cout ? x0 : (xr ? q.x : 0.0), p1 = cout ? x1 : (xr ? q.y : 0.0);
+      const double p0 = cout ? x0 : q.x, p1 = cout ? x1 : q.y;
       const double y0 = hh0 - (G0 * p0 + G1 * p1);
       const double y1 = hh1 - (G2 * p0 + G3 * p1);
       x0 = y0; x1 = y1;
