@@ -23,21 +23,36 @@ SCALE = {"case33": 0.8, "case141": 0.6, "case322": 0.8}
 LIMIT = 12
 
 
-def _args(case):
-    return dict(episode_limit=LIMIT, action_scale=SCALE[case], action_bias=0.0, voltage_barrier_type="bowl", seed=3)
+TIES = {"case141": ([5, 40, 77, 100, 20], [77, 120, 130, 12, 66]), "case322": ([5, 40, 177, 200, 300], [77, 120, 30, 12, 150])}   # as tools/general_bench.py
+
+
+def _args(case, barrier="bowl"):
+    return dict(episode_limit=LIMIT, action_scale=SCALE[case], action_bias=0.0, voltage_barrier_type=barrier, seed=3)
+
+
+def _net(case, ties):
+    """the case's feeder, or (ties > 0) the same net with tie lines closed: meshed -> the general sparse solver"""
+    from mapdn_amd.netspec import add_lines, case33_meshed, make_case
+    net, prof = make_case(case)
+    if ties:
+        if case == "case33":
+            net = case33_meshed(net, ties)
+        else:
+            f, t = TIES[case]
+            net = add_lines(net, f[:ties], t[:ties], 0.3, 0.2)
+    return net, prof
 
 
 def _replay(job):
-    case, envs, acts, rew, term, info, obs, vm, mask = job
+    case, envs, acts, rew, term, info, obs, vm, mask, barrier, ties = job
     os.environ.setdefault("OMP_NUM_THREADS", "1")
-    from mapdn_amd.netspec import make_case
     from oracle.env_restated import INFO_KEYS, VoltageControlOracle
-    net, prof = make_case(case)
+    net, prof = _net(case, ties)
     worst = dict(reward=0.0, info=0.0, obs=0.0, vm=0.0)
     where = dict(vm=None, info=None)                                      # (env id, call, oracle iterations, which info key) of the largest differences
     bad_flags, n_steps, n_resets, n_fail, n_edge = 0, 0, 0, 0, 0
     for i, e in enumerate(envs):
-        o = VoltageControlOracle(net, prof, _args(case), env_id=int(e), do_reset=False)
+        o = VoltageControlOracle(net, prof, _args(case, barrier), env_id=int(e), do_reset=False)
         oo, _ = o.reset()
         worst["obs"] = max(worst["obs"], float(np.abs(np.array(oo) - obs[0, i]).max()))
         pending = False
@@ -72,13 +87,14 @@ def main():
     ap.add_argument("--case", default="case141"); ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--watch", type=int, default=1024); ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--procs", type=int, default=0)
+    ap.add_argument("--barrier", default="bowl", help="voltage_barrier_type: l1 | l2 | courant_beltrami | bowl | bump")
+    ap.add_argument("--ties", type=int, default=0, help="close this many tie lines (meshed net: the general sparse solver)")
     a = ap.parse_args()
     import torch
     from mapdn_amd.env import VoltageControlBatch
-    from mapdn_amd.netspec import make_case
-    net, prof = make_case(a.case)
+    net, prof = _net(a.case, a.ties)
     B, W, T = a.envs, min(a.watch, a.envs), a.steps
-    env = VoltageControlBatch(net, prof, dict(_args(a.case), auto_reset=True), n_envs=B, device="cuda:0", obs_dtype=torch.float64)
+    env = VoltageControlBatch(net, prof, dict(_args(a.case, a.barrier), auto_reset=True), n_envs=B, device="cuda:0", obs_dtype=torch.float64)
     watch = np.unique(np.linspace(0, B - 1, W).astype(np.int64))
     W = len(watch)
     wt = torch.as_tensor(watch, device="cuda:0")
@@ -101,7 +117,7 @@ def main():
     env.close()
     procs = a.procs or min(len(os.sched_getaffinity(0)), 16)
     chunks = np.array_split(np.arange(W), procs * 4)
-    jobs = [(a.case, watch[c], acts[:, c], rew[:, c], term[:, c], info[:, c], obs[:, c], vm[:, c], mask[:, c]) for c in chunks if len(c)]
+    jobs = [(a.case, watch[c], acts[:, c], rew[:, c], term[:, c], info[:, c], obs[:, c], vm[:, c], mask[:, c], a.barrier, a.ties) for c in chunks if len(c)]
     import multiprocessing as mp
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(procs) as pool:
@@ -126,7 +142,7 @@ def main():
             dx = -ppr.spla.spsolve(ppr.jacobian(ybus, v, pq, pq), f)
             va[pq] += dx[:len(pq)]; vmag[pq] += dx[len(pq):]
             v = vmag * np.exp(1j * va); vmag = np.abs(v); va = np.angle(v)
-        e2 = VoltageControlBatch(net, prof, _args(a.case), n_envs=64, device="cuda:0")
+        e2 = VoltageControlBatch(net, prof, _args(a.case, a.barrier), n_envs=64, device="cuda:0")
         gvm, gva, git, gcv = e2.solve(np.tile(pl, (64, 1)), np.tile(ql, (64, 1)), np.tile(pv, (64, 1)), np.tile(qs, (64, 1)))
         e2.close()
         probe = (f"; probe of that power flow: oracle iterations {ref['iterations']}, ||F||inf of its iterates {['%.6e' % h for h in hist]} (tol {1e-8 / net.sn_mva:.1e}; the noise floor of evaluating F is the level of the last entries), "
@@ -135,7 +151,7 @@ def main():
     # bars: voltages / obs 1e-9 (north_star: 1e-6), reward / info 1e-8 — an env-step whose mismatch norm lands within the evaluation
     # noise of the tolerance (||F|| ~ 1e-9 +- 1e-12) may take one Newton step more or fewer than the oracle: both are converged
     ok = flags == 0 and max(worst['vm'], worst['obs']) < 1e-9 and max(worst['reward'], worst['info']) < 1e-8
-    print(f"{a.case} x {B} envs (waves {geo['waves']}, envs/workgroup {geo['lanes']}, lean {geo['lean']}): {W} envs x {T} calls replayed on the oracle "
+    print(f"{a.case}{' + %d tie lines' % a.ties if a.ties else ''} x {B} envs, barrier {a.barrier} (solver {geo['solver']}, waves {geo['waves']}, envs/workgroup {geo['lanes']}, lean {geo['lean']}): {W} envs x {T} calls replayed on the oracle "
           f"({n_steps} env-steps, {n_resets} auto-resets, {n_fail} unsolvable steps; {dt:.0f} s on {procs} processes): max |d reward| {worst['reward']:.2e}, "
           f"|d info| {worst['info']:.2e}, |d obs| {worst['obs']:.2e}, |d vm_pu| {worst['vm']:.2e}, flag mismatches {flags}, env-steps with |d vm_pu| > 1e-12 (a different number of Newton steps at the tolerance edge): {n_edge}; "
           f"GPU mean / max NR iterations {st['mean_nr_iters']:.2f} / {st['max_nr_iters']}; largest vm difference at (env, call, oracle iterations, min vm) = {wv}, "
