@@ -446,7 +446,9 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
   // mismatch bookkeeping of one step (deferred into the next row's shadow)
   auto note_mismatch = [&](double Fp, double Fq, bool live) {
-    allok = allok && (!live || ((fabs(Fp) < tol) && (fabs(Fq) < tol)));
+    // (bitwise on purpose: the short-circuit form compiled to two exec-mask branches per row; same booleans)
+    const bool okp = fabs(Fp) < tol, okq = fabs(Fq) < tol;
+    allok = allok & (!live | (okp & okq));
     fmx = fmax(fmx, live ? fmax(fabs(Fp), fabs(Fq)) : 0.0);
   };
   auto clist_ptr = [&](uint32_t fl, uint32_t slots, uint32_t chs) { return (fl >> 24) | ((slots >> 30) << 8) | ((chs >> 30) << 10); };
