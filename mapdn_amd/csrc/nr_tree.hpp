@@ -691,7 +691,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     for (int i = 0; i < UPN; ++i) {
       dxm = fmax(dxm, lv[i] ? fmax(fabs(xx[i].x), fabs(xx[i].y)) : 0.0);
       sincos_small(-xx[i].x, &s[i], &c[i]);
-      big = big || (lv[i] && !(fabs(xx[i].x) <= 0.5));
+      big = big | (lv[i] & !(fabs(xx[i].x) <= 0.5));
     }
     if (__any(big)) {
 #pragma unroll
@@ -974,14 +974,15 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         s_dx[(size_t)w * L] = fmx;               // (free here: the step sizes it holds were consumed before this sweep)
         lds_barrier();
 #pragma unroll
-        for (unsigned ww = 0; ww < (unsigned)W; ++ww) { allok = allok && (s_ok[ww * L + el] != 0); fmx = fmax(fmx, s_dx[(size_t)ww * L]); }
+        // (& not &&: the short-circuit form put every s_ok read behind an exec-mask branch with its own lgkmcnt(0) — W serialised LDS round trips)
+        for (unsigned ww = 0; ww < (unsigned)W; ++ww) { allok = allok & (s_ok[ww * L + el] != 0); fmx = fmax(fmx, s_dx[(size_t)ww * L]); }
       }
     } else {
       s_ok[t * L + el] = allok ? 1 : 0;
       s_dx[(size_t)t * L] = fmx;                 // (free here: the step sizes it holds were consumed before this sweep)
       if (W > 1) lds_barrier();
       fmx = 0.0;
-      for (unsigned tt = 0; tt < Wt; ++tt) { allok = allok && (s_ok[tt * L + el] != 0); fmx = fmax(fmx, s_dx[(size_t)tt * L]); }
+      for (unsigned tt = 0; tt < Wt; ++tt) { allok = allok & (s_ok[tt * L + el] != 0); fmx = fmax(fmx, s_dx[(size_t)tt * L]); }
     }
     if (light) {
       light = false;
