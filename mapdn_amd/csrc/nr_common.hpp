@@ -84,6 +84,27 @@ __device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
   *c = fma(pc, z, 1.0);
 }
 
+// cos/sin of a LARGE Newton angle step (|x| > 0.5: a diverging or badly conditioned iterate; rare).  libm's sincos is ~200
+// instructions with its Payne-Hanek branch, and it was inlined into every (unrolled / peeled) backward row of the layouts that
+// update inside the rows — the rare path made the hot loops ~40 KB larger than the instruction cache likes (case141 x 8192:
+// solver launch 111 -> 100 us without it).  This form is ~35 instructions: Cody-Waite reduction by pi/2 in three FMAs (fdlibm's
+// pio2_1 / pio2_2 / pio2_3: exact products for |x| up to ~1e5 rad), the same Taylor pair on [-pi/4, pi/4] (remainders 8e-20 /
+// 2e-18), quadrant fix-up.  Within 1-2 ulp there; beyond ~1e5 rad it loses accuracy gracefully (finite values) — such an iterate is
+// diverging and ends in the non-convergence branch whatever its digits.  Every solver path uses THIS function for large steps, so
+// results stay bit-identical across launch geometries.
+__device__ __forceinline__ void sincos_mid(double x, double* s, double* c) {
+  const double k = rint(x * 6.36619772367581382433e-01);       // 2 / pi
+  double r = fma(-k, 1.57079632673412561417e+00, x);
+  r = fma(-k, 6.07710050630396597660e-11, r);
+  r = fma(-k, 2.02226624871116645580e-21, r);
+  double sr, cr;
+  sincos_small(r, &sr, &cr);
+  const int n = (int)k;
+  const double ss = (n & 1) ? cr : sr, cc = (n & 1) ? sr : cr;
+  *s = (n & 2) ? -ss : ss;
+  *c = ((n + 1) & 2) ? -cc : cc;
+}
+
 // =================================================================== fused epilogue
 // The workgroup still holds the solution of its L envs in LDS (sV[k * L] = (e, f) of elimination position k, already
 // offset by the env's lane; position n = slack), so the rest of the env step happens here, spread over the workgroup's

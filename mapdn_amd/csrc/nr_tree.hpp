@@ -677,7 +677,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     const double dth = -y0;
     sincos_small(dth, &s, &c);
 #if !(MAPDN_EXP & 1)
-    if (__any(live && !(fabs(dth) <= 0.5))) sincos(dth, &s, &c);   // wave-uniform, only when a lane diverges
+    if (__any(live && !(fabs(dth) <= 0.5))) sincos_mid(dth, &s, &c);   // wave-uniform, only when a lane takes a large step (nr_common.hpp)
 #endif
     sV[(size_t)k * L] = done ? vk : nr_rotate(vk, s, c, y1);   // converged envs keep their state; idle steps hit the trash node
   };
@@ -695,7 +695,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     }
     if (__any(big)) {
 #pragma unroll
-      for (int i = 0; i < UPN; ++i) if (__any(lv[i] && !(fabs(xx[i].x) <= 0.5))) sincos(-xx[i].x, &s[i], &c[i]);   // as apply_update decides, node by node
+      for (int i = 0; i < UPN; ++i) if (__any(lv[i] && !(fabs(xx[i].x) <= 0.5))) sincos_mid(-xx[i].x, &s[i], &c[i]);   // as apply_update decides, node by node
     }
 #pragma unroll
     for (int i = 0; i < UPN; ++i) sV[(size_t)kk[i] * L] = done ? vv[i] : nr_rotate(vv[i], s[i], c[i], xx[i].y);
