@@ -186,8 +186,8 @@ static int settle_tree_geometry(mapdn_handle* h, int Bp, int n_cu) {
   };
   int W = knob_int(c.nr_waves, "MAPDN_NR_WAVES"), L = knob_int(c.nr_lanes, "MAPDN_NR_LANES");
   const int lean_k = knob_tri(c.nr_lean, "MAPDN_NR_LEAN");          // 0 auto, 1 lean, 2 fat
-  if ((W != 0 && W != 1 && W != 2 && W != 4 && W != 8) || (L != 0 && L != 8 && L != 16 && L != 32)) {
-    h->err = "nr_waves (MAPDN_NR_WAVES) must be 1/2/4/8 and nr_lanes (MAPDN_NR_LANES) 8/16/32 (0 = automatic)"; return MAPDN_E_INVALID; }
+  if ((W != 0 && W != 1 && W != 2 && W != 4 && W != 8) || (L != 0 && L != 4 && L != 8 && L != 16 && L != 32)) {
+    h->err = "nr_waves (MAPDN_NR_WAVES) must be 1/2/4/8 and nr_lanes (MAPDN_NR_LANES) 4/8/16/32 (0 = automatic)"; return MAPDN_E_INVALID; }
   mapdn_handle::Geo best; Schedule bestS; bool have = false;
   const bool forced = W != 0 && L != 0 && lean_k != 0;
   // automatic candidates: the pairs the model was fitted on; the other compiled pairs (nr_inst_list.hpp) only when pinned

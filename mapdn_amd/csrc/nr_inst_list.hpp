@@ -23,7 +23,10 @@
 #define NR_INSTS_3(X) \
   X(1, 8, true, true, 0) X(1, 8, true, false, 0) X(1, 8, false, false, 0) \
   X(2, 8, true, true, 0) X(2, 8, true, false, 0) X(2, 8, false, false, 0) \
-  X(1, 32, false, false, 0) X(1, 32, true, false, 0) X(1, 32, true, true, 0)
+  X(1, 32, false, false, 0) X(1, 32, true, false, 0) X(1, 32, true, true, 0) \
+  X(4, 4, true, false, 0) X(4, 4, true, true, 0) X(4, 4, false, false, 0) \
+  X(2, 4, true, false, 0) X(2, 4, true, true, 0) X(2, 4, false, false, 0) \
+  X(1, 4, true, false, 0) X(1, 4, true, true, 0)
 
 namespace mapdn {
 struct NrInst { int W, L, HL, GL, RES; const void* fn; };

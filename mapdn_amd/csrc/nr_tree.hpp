@@ -97,14 +97,29 @@ __device__ __forceinline__ void bst2(d2 x, __amdgpu_buffer_rsrc_t r, unsigned vo
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), r, voff, soff, 0);
 }
 
-// max over the four 16-lane rows of a wavefront, per column (lane & 15), every lane receiving the result: with 16 envs per
-// workgroup the rows are the wave's four workers, so this is the per-env reduction over them — two gfx950 row swaps
-// (v_permlane16_swap / v_permlane32_swap, VALU rate) per dword instead of an LDS round trip
-__device__ __forceinline__ double rows_max(double v) {
+// Per-env max over the S = 64 / L workers of a wavefront (lane = worker * L + env), every lane receiving the result — VALU-rate
+// lane exchanges instead of an LDS round trip.  The four 16-lane rows of the wave are combined by two gfx950 row swaps
+// (v_permlane16_swap / v_permlane32_swap); with fewer than 16 envs per workgroup a row holds 16 / L workers, combined first by DPP
+// rotations within the row (row_ror:L, row_ror:2L ...).  max is exact, so the order of the combination does not matter.
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int L>
+__device__ __forceinline__ double grp_max(double v) {
+  static_assert(L == 4 || L == 8 || L == 16 || L == 32, "envs per workgroup");
+  constexpr int ROW_ROR = 0x120;                   // DPP control: rotate right within each row of 16 lanes
+  if constexpr (L == 4) v = fmax(v, dpp_row_f64<ROW_ROR + 4>(v));
+  if constexpr (L <= 8) v = fmax(v, dpp_row_f64<ROW_ROR + 8>(v));
   unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-  u32x2 a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  const double m = fmax(__hiloint2double((int)b.x, (int)a.x), __hiloint2double((int)b.y, (int)a.y));
-  lo = (unsigned)__double2loint(m); hi = (unsigned)__double2hiint(m);
+  u32x2 a, b;
+  if constexpr (L <= 16) {
+    a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false); b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = fmax(__hiloint2double((int)b.x, (int)a.x), __hiloint2double((int)b.y, (int)a.y));
+    lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v);
+  }
   a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false); b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
   return fmax(__hiloint2double((int)b.x, (int)a.x), __hiloint2double((int)b.y, (int)a.y));
 }
@@ -966,9 +981,9 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     if (first) { fwd_sweep_flat(); a_define(); }
     else if (light) { if (HL && d.nr_mm_pass) mismatch_pass(); else fwd_sweep(std::integral_constant<int, 1>{}); a_define(); }
     else fwd_sweep(std::integral_constant<int, 0>{});
-    if constexpr (L == 16) {                     // AND of the workers' verdicts, per env: in the wave by row swaps, across
-      fmx = rows_max(fmx);                       // the W waves through W LDS entries (instead of Wt)
-      allok = rows_max(allok ? 0.0 : 1.0) == 0.0;
+    {                                            // AND of the workers' verdicts, per env: in the wave by lane exchanges, across
+      fmx = grp_max<L>(fmx);                     // the W waves through W LDS entries (instead of Wt)
+      allok = grp_max<L>(allok ? 0.0 : 1.0) == 0.0;
       if (W > 1) {
         s_ok[w * L + el] = allok ? 1 : 0;
         s_dx[(size_t)w * L] = fmx;               // (free here: the step sizes it holds were consumed before this sweep)
@@ -977,12 +992,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         // (& not &&: the short-circuit form put every s_ok read behind an exec-mask branch with its own lgkmcnt(0) — W serialised LDS round trips)
         for (unsigned ww = 0; ww < (unsigned)W; ++ww) { allok = allok & (s_ok[ww * L + el] != 0); fmx = fmax(fmx, s_dx[(size_t)ww * L]); }
       }
-    } else {
-      s_ok[t * L + el] = allok ? 1 : 0;
-      s_dx[(size_t)t * L] = fmx;                 // (free here: the step sizes it holds were consumed before this sweep)
-      if (W > 1) lds_barrier();
-      fmx = 0.0;
-      for (unsigned tt = 0; tt < Wt; ++tt) { allok = allok & (s_ok[tt * L + el] != 0); fmx = fmax(fmx, s_dx[(size_t)tt * L]); }
     }
     if (light) {
       light = false;
@@ -1007,19 +1016,12 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     first = false;
     if (!done) ++it;
     {                                            // size of the step just taken, per env: max over the workers
-      double dxe = 0.0;
-      if constexpr (L == 16) {
-        dxe = rows_max(dxm);
-        if (W > 1) {
-          s_dx[(size_t)w * L] = dxe;
-          lds_barrier();
+      double dxe = grp_max<L>(dxm);
+      if (W > 1) {
+        s_dx[(size_t)w * L] = dxe;
+        lds_barrier();
 #pragma unroll
-          for (unsigned ww = 0; ww < (unsigned)W; ++ww) dxe = fmax(dxe, s_dx[(size_t)ww * L]);
-        }
-      } else {
-        s_dx[(size_t)t * L] = dxm;
-        if (W > 1) lds_barrier();
-        for (unsigned tt = 0; tt < Wt; ++tt) dxe = fmax(dxe, s_dx[(size_t)tt * L]);
+        for (unsigned ww = 0; ww < (unsigned)W; ++ww) dxe = fmax(dxe, s_dx[(size_t)ww * L]);
       }
       // convergence is predicted from a tiny step, or — scale-free — from quadratic convergence of the mismatch:
       // ||F_next|| ~ ||F||^3 / ||F_prev||^2 (two sweeps of history needed)

@@ -142,13 +142,19 @@ def trafo_to_pi(trafo, bus_vn_kv: np.ndarray, net_sn_mva: float, calculate_volta
                 br_g_pu=-y.imag, br_ratio=ratio, br_shift_deg=shift)
 
 
-def from_pandapower(net) -> NetSpec:
+def from_pandapower(net, hv_init: str = "refuse") -> NetSpec:
     """pandapowerNet (`pp.from_pickle(model.p)`, voltage_control_env.py:400-405) -> NetSpec: what pd2ppc would build for
     runpp's defaults.  Converted: buses (0..n-1, all in service), lines (an open line / trafo switch takes the branch out
     when that is exact — no shunt terms, or open at both ends — and is refused otherwise), two-winding transformers (trafo_to_pi), loads / sgens with `scaling` and `in_service`,
     non-consecutive bus indices (mapped to the positions of the sorted index, pd2ppc's bus lookup),
     shunts (step, in_service), one ext_grid, closed bus-bus switches (bus fusion -> NetSpec.bus_alias).  Refused loudly, never guessed: voltage-dependent loads
-    (const_z_percent / const_i_percent: the constant-Z share would be a time-varying shunt), generators, three-winding transformers, impedances, wards, dc lines, storage."""
+    (const_z_percent / const_i_percent: the constant-Z share would be a time-varying shunt), generators, three-winding transformers, impedances, wards, dc lines, storage,
+    closed bus-bus switches with z_ohm > 0 (pandapower models them as impedance branches, not as fused buses), fused buses of different vn_kv, and
+    — unless hv_init="flat" — nets with a line at a bus above 70 kV: runpp's defaults then turn calculate_voltage_angles on AND start the
+    Newton iteration from a DC power flow's angles (init="auto" -> "dc"), while every solver here starts flat; the converged answer is the
+    same, the iteration count (and with it the 10-iteration verdict of voltage_control_env.py:188-196) need not be."""
+    if hv_init not in ("refuse", "flat"):
+        raise ValueError("hv_init must be 'refuse' or 'flat'")
     def table(name):
         t = net[name] if name in net else None
         return t if t is not None and len(t) else None
@@ -186,6 +192,9 @@ def from_pandapower(net) -> NetSpec:
         # the representative of a group is the ext_grid's bus if the group holds it, else the smallest bus (any choice gives
         # the same result tables)
         bb = (et == "b") & closed
+        if np.any(bb) and "z_ohm" in sw and np.any(np.nan_to_num(_col(sw, "z_ohm", 0.0)[bb]) > 0.0):
+            raise NotImplementedError("a closed bus-bus switch has z_ohm > 0: pandapower 2.x models it as an impedance branch between the two "
+                                      "buses, not as one fused bus; not converted")
         if np.any(bb):
             parent_ = np.arange(len(bus_index))
 
@@ -202,6 +211,12 @@ def from_pandapower(net) -> NetSpec:
             eg = int(rb([net.ext_grid["bus"].iloc[0]])[0])
             grp = fused_alias == fused_alias[eg]
             fused_alias[grp] = eg
+            vn_rep = vn[fused_alias]
+            if np.any(vn_rep != vn):
+                bad = int(np.nonzero(vn_rep != vn)[0][0])
+                raise NotImplementedError(f"bus {int(bus_index[bad])} (vn_kv {vn[bad]}) is fused by a closed bus-bus switch with bus "
+                                          f"{int(bus_index[fused_alias[bad]])} (vn_kv {vn_rep[bad]}): the per-unit base of the merged node would be "
+                                          "ambiguous; not converted")
         # An OPEN line / trafo switch: runpp's default (neglect_open_switch_branches=False, build_branch._switch_branches)
         # re-terminates the open end on an auxiliary bus, so the branch stays energised from its closed end and still draws
         # its charging / magnetising current.  That is the same as taking the branch out ONLY if it has no shunt terms, or
@@ -248,14 +263,21 @@ def from_pandapower(net) -> NetSpec:
         sn_mva=float(net.sn_mva), f_hz=float(net.f_hz))
     if fused_alias is not None:
         kw["bus_alias"] = fused_alias
+    # runpp calculate_voltage_angles="auto": True only if a line touches a bus above 70 kV — and then init="auto" means init_va_degree="dc"
+    hv_buses = set(np.nonzero(vn > 70.0)[0].tolist())
+    touched = set(rb(line["from_bus"].to_numpy()).tolist()) | set(rb(line["to_bus"].to_numpy()).tolist())
+    calc_va = bool(hv_buses & touched)
+    if calc_va and hv_init == "refuse":
+        raise NotImplementedError("a line touches a bus above 70 kV: pp.runpp's defaults (voltage_control_env.py:557) switch calculate_voltage_angles on "
+                                  "and initialise the voltage angles from a DC power flow (init='auto' -> 'dc'); the solvers here start flat, so the "
+                                  "Newton iteration count — and the 10-iteration non-convergence verdict — could differ from pandapower's.  Pass "
+                                  "hv_init='flat' to convert anyway (transformer phase shifts applied; same converged voltages where the flat start "
+                                  "converges — with a vector-group shift such as 150 degrees it does not, see tests/test_data_ingestion.py)")
     if trafo is not None:
         t = trafo.sort_index().copy()
         t["in_service"] = trafo_on
         t["hv_bus"] = rb(t["hv_bus"].to_numpy()); t["lv_bus"] = rb(t["lv_bus"].to_numpy())
-        # runpp calculate_voltage_angles="auto": True only if a line touches a bus above 70 kV
-        hv_buses = set(np.nonzero(vn > 70.0)[0].tolist())
-        touched = set(rb(line["from_bus"].to_numpy()).tolist()) | set(rb(line["to_bus"].to_numpy()).tolist())
-        kw.update(trafo_to_pi(t, vn, float(net.sn_mva), calculate_voltage_angles=bool(hv_buses & touched)))
+        kw.update(trafo_to_pi(t, vn, float(net.sn_mva), calculate_voltage_angles=calc_va))
     sh = table("shunt")
     if sh is not None:
         # build_bus._calc_shunts_and_add_on_ppc: p, q per step, referred from the shunt's vn_kv to the bus voltage

@@ -189,8 +189,34 @@ def _cached_ybus(net):
     return hit[1], hit[2], hit[3], hit[4]
 
 
+def dc_angles(net, pd_):
+    """pandapower/pf/run_dc_pf.py::_run_dc_pf + pypower makeBdc / dcpf — the angles runpp starts from when init="auto" resolves to
+    init_va_degree="dc" (calculate_voltage_angles=True: a line at a bus above 70 kV).  [PP-recalled.]
+      b = 1 / x / tap_ratio per in-service branch;  Bbus = (Cf - Ct)' diag(b) (Cf - Ct);  Pfinj = b * (-shift_rad);
+      Pbusinj = (Cf - Ct)' Pfinj;  Pbus = Re(Sbus) - Pbusinj - GS / baseMVA;  Va[pvpq] = Bbus[pvpq, pvpq]^-1 (Pbus[pvpq] - Bbus[pvpq, ref] Va0[ref])
+    with Va0[ref] = 0 (ext_grid.va_degree is taken as given: 0 in every MAPDN net)."""
+    f, t, _, x, _, tap, _ = build_branches(net)
+    nb, nl = net.n_bus, f.shape[0]
+    ratio = np.abs(tap)
+    shift = np.angle(tap)
+    b = 1.0 / x / ratio
+    i = np.arange(nl)
+    cft = sp.csr_matrix((np.r_[np.ones(nl), -np.ones(nl)], (np.r_[i, i], np.r_[f, t])), (nl, nb))
+    bbus = sp.csr_matrix(cft.T @ sp.diags(b) @ cft)
+    pbusinj = cft.T @ (b * -shift)
+    gs = np.zeros(nb)
+    if net.shunt_bus.shape[0]:
+        np.add.at(gs, net.shunt_bus, net.shunt_p_mw)
+    pbus = -pd_ / net.sn_mva - pbusinj - gs / net.sn_mva
+    ref = int(net.ext_grid_bus)
+    pvpq = np.setdiff1d(np.arange(nb), [ref])
+    va = np.zeros(nb)
+    va[pvpq] = spla.spsolve(sp.csc_matrix(bbus[pvpq][:, pvpq]), pbus[pvpq])
+    return va
+
+
 def runpp_restated(net, p_load, q_load, p_sgen, q_sgen, raise_on_fail=False, cache=True, tolerance_mva=TOLERANCE_MVA,
-                   tolerance_is_pu=False):
+                   tolerance_is_pu=False, init="flat"):
     """``pp.runpp(net)`` for a net whose load/sgen columns hold the given MW / MVAr values.
 
     Returns res_bus (vm_pu, va_degree, p_mw, q_mvar sorted by bus index), res_line.pl_mw,
@@ -200,8 +226,15 @@ def runpp_restated(net, p_load, q_load, p_sgen, q_sgen, raise_on_fail=False, cac
     Stopping rule: ||F||inf < tolerance_mva / sn_mva with F in per unit — as recalled from pandapower 2.7.0 (UNPINNED: pandapower is
     not installable here; tests/test_pandapower_pin.py::test_tolerance_rule_on_sn_mva_not_one decides it wherever pandapower is).
     `tolerance_is_pu=True` is the other reading (||F||inf < tolerance_mva, no division) — mapdn_env_config.tolerance_is_pu.
+
+    `init`: "flat" (runpp's init="auto" below 70 kV) or "dc" (what init="auto" resolves to when calculate_voltage_angles is on: angles
+    from a DC power flow, magnitudes flat).  The product solvers only start flat; mapdn_amd.data.from_pandapower refuses HV nets.
     """
+    if init not in ("flat", "dc"):
+        raise ValueError("init must be 'flat' or 'dc'")
     if getattr(net, "has_fused_buses", False):
+        if init != "flat":
+            raise NotImplementedError("init='dc' on a net with fused buses")
         return _runpp_fused(net, p_load, q_load, p_sgen, q_sgen, raise_on_fail, cache, tolerance_mva, tolerance_is_pu)
     if cache:
         ybus, yf, yt, br = _cached_ybus(net)
@@ -217,6 +250,8 @@ def runpp_restated(net, p_load, q_load, p_sgen, q_sgen, raise_on_fail=False, cac
     sbus = make_sbus(net, pd_, qd)
     # init="auto" -> flat start at mean vm set-point of voltage-controlled elements (one ext_grid)
     v0 = np.full(nb, net.ext_grid_vm_pu, dtype=np.complex128)
+    if init == "dc":
+        v0 = v0 * np.exp(1j * dc_angles(net, pd_))
     tol = tolerance_mva / (1.0 if tolerance_is_pu else net.sn_mva)
     v, converged, it = newtonpf(ybus, sbus, v0, ref, pv, pq, tol)
     if not converged and raise_on_fail:

@@ -861,9 +861,10 @@ def test_fused_step_obs_equals_step_then_get_obs(case, obs_dtype):
 
 
 @pytest.mark.parametrize("case,geoms", [
-    ("case141", [(4, 16, 0), (2, 16, 1), (2, 16, 2), (1, 8, 1), (4, 8, 0), (1, 32, 1), (2, 8, 2), (1, 16, 2), (4, 16, 1)]),
-    ("case33", [(1, 16, 0), (2, 16, 0), (1, 8, 0), (4, 16, 0), (2, 8, 1)]),
-    ("case322", [(4, 8, 0), (2, 8, 1), (4, 16, 1), (4, 16, 2), (2, 16, 1)]),
+    ("case141", [(4, 16, 0), (2, 16, 1), (2, 16, 2), (1, 8, 1), (4, 8, 0), (1, 32, 1), (2, 8, 2), (1, 16, 2), (4, 16, 1),
+                 (4, 4, 0), (2, 4, 2), (4, 4, 1), (1, 4, 2)]),
+    ("case33", [(1, 16, 0), (2, 16, 0), (1, 8, 0), (4, 16, 0), (2, 8, 1), (4, 4, 0), (1, 4, 0)]),
+    ("case322", [(4, 8, 0), (2, 8, 1), (4, 16, 1), (4, 16, 2), (2, 16, 1), (4, 4, 0), (2, 4, 0), (4, 4, 1)]),
 ])
 def test_every_nr_launch_geometry_gives_the_same_bits(case, geoms):
     """mapdn_env_config.nr_waves / nr_lanes / nr_lean (0 auto, 1 lean, 2 fat): every (waves, envs per workgroup, LDS residency)

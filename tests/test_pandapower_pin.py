@@ -113,3 +113,32 @@ def test_tolerance_rule_on_sn_mva_not_one():
     assert decided is not None, "no tolerance in the sweep separates the two readings on this net"
     assert decided == "divide", ("pandapower uses ||F||inf < tolerance_mva WITHOUT dividing by sn_mva: set tolerance_is_pu = 1 "
                                  "(mapdn_env_config / oracle.runpp_restated) — see this test's docstring")
+
+
+def test_hv_net_dc_initialisation():
+    """VERDICT r4 missing item 3: on a net with a line at a bus above 70 kV runpp's defaults switch calculate_voltage_angles on and
+    start Newton from a DC power flow's angles (init='auto' -> init_va_degree='dc').  The oracle's init='dc' restates that start;
+    the product solvers start flat and from_pandapower refuses such nets unless hv_init='flat' is passed (with this net's 150 degree
+    vector group a flat start does not converge at all: tests/test_data_ingestion.py).  Decides: the voltages and the iteration
+    count pandapower reports equal the oracle's with init='dc'."""
+    n = pp.create_empty_network(sn_mva=10.0)
+    hv = [pp.create_bus(n, vn_kv=110.0, zone="main") for _ in range(2)]
+    b = [pp.create_bus(n, vn_kv=20.0, zone=z) for z in ("main", "zone1", "zone1")]
+    pp.create_line_from_parameters(n, hv[0], hv[1], length_km=30.0, r_ohm_per_km=0.06, x_ohm_per_km=0.4, c_nf_per_km=9.0, max_i_ka=0.6)
+    pp.create_transformer_from_parameters(n, hv[1], b[0], sn_mva=25.0, vn_hv_kv=110.0, vn_lv_kv=20.0, vk_percent=12.0, vkr_percent=0.41,
+                                          pfe_kw=14.0, i0_percent=0.07, shift_degree=150.0)
+    pp.create_line_from_parameters(n, b[0], b[1], length_km=2.0, r_ohm_per_km=0.2, x_ohm_per_km=0.12, c_nf_per_km=250.0, max_i_ka=0.4)
+    pp.create_line_from_parameters(n, b[1], b[2], length_km=1.5, r_ohm_per_km=0.3, x_ohm_per_km=0.1, c_nf_per_km=200.0, max_i_ka=0.4)
+    pp.create_load(n, b[1], p_mw=4.0, q_mvar=1.0)
+    pp.create_load(n, b[2], p_mw=3.0, q_mvar=0.8)
+    pp.create_sgen(n, b[2], p_mw=1.5, q_mvar=0.2, name="zone1")
+    pp.create_ext_grid(n, hv[0], vm_pu=1.02)
+    pp.runpp(n)
+    with pytest.raises(NotImplementedError, match="DC power flow"):
+        from_pandapower(n)
+    net = from_pandapower(n, hv_init="flat")
+    args = (n.load.p_mw.to_numpy(), n.load.q_mvar.to_numpy(), n.sgen.p_mw.to_numpy(), n.sgen.q_mvar.to_numpy())
+    dc = runpp_restated(net, *args, init="dc")
+    rb = n.res_bus.sort_index()
+    assert np.abs(rb.vm_pu.to_numpy() - dc.vm_pu).max() < 1e-9 and np.abs(rb.va_degree.to_numpy() - dc.va_degree).max() < 1e-7
+    assert dc.converged and int(n._ppc["iterations"]) == dc.iterations
