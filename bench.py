@@ -236,8 +236,14 @@ def _free_port():
     return p
 
 
-def self_launch(n):
+def self_launch(n, backend="nccl"):
     """--gpus N without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`."""
+    if backend == "nccl":                                    # one rank per GPU over RCCL: fail here, with a sentence, not in N ranks' init
+        import torch
+        have = torch.cuda.device_count()
+        if n > have:
+            raise SystemExit(f"bench.py --gpus {n}: this node exposes {have} GPU(s) and the nccl (RCCL) backend needs one per rank; "
+                             f"run with --gpus <= {have}, or --backend gloo to exercise the {n}-rank path with ranks sharing GPUs")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
@@ -264,12 +270,14 @@ def main():
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the short case33 / case322 measurements appended to the default line")
     ap.add_argument("--env-id-offset", type=int, default=0, help="global id of this run's first env (a 1-rank run that covers the ids "
                                                                    "of rank r of an N-rank run: r x envs); ranks add rank x envs")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and run the end-of-rollout gather, the max-over-ranks "
+                                                              "all_reduce and the barriers) even at --gpus 1: first contact with RCCL on one GPU")
     ap.add_argument("--dump-returns", default=None, help="rank 0 writes the gathered per-env episode returns of the LAST timed block "
                                                          "to this .npy file (pre-flight checks of the N > 1 path)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(a.gpus)
+        self_launch(a.gpus, a.backend)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -291,8 +299,11 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:                  # --force-dist without a launcher: a one-rank rendezvous on the loopback
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -344,7 +355,7 @@ def main():
                 one_step()
             if dist is not None:                              # end-of-rollout RCCL gather, inside the timed region
                 ret = env.episode_returns()
-                allret = gather_rollout(ret if a.backend == "nccl" else ret.cpu())
+                allret = gather_rollout(ret if a.backend == "nccl" else ret.cpu(), force=True)
                 assert allret.shape[0] == world * B
                 last_returns[0] = allret
             elif a.dump_returns:
@@ -460,7 +471,8 @@ def main():
                        "resets_in_timed_region": resets_in_region,
                        "envs_per_gpu": B, "global_envs": n_gpus * B, "obs_size": head["obs_size"],
                        "parallelism": f"env-batch sharded x{n_gpus}, no data-path collective; one all_gather of episode "
-                                      f"returns ({a.backend}) at the end of the rollout, inside the timed region"},
+                                      f"returns ({a.backend}) at the end of the rollout, inside the timed region"
+                                      + ("" if dist is not None else " (N = 1: torch.distributed not initialised; --force-dist runs the same collectives on one rank)")},
             "nr_iterations": {"mean": stats["mean_nr_iters"], "max": stats["max_nr_iters"]},
             # `bound`: what the SQ counters say limits the kernel (profiles/*_nr_sq_counters.txt) — per-row latency of the
             # tree sweeps, neither roof.  The fraction is against the HBM roof as the contract prescribes (SURVEY 8(d):
@@ -481,6 +493,11 @@ def main():
                         "note": "f64 vector (no MFMA on the radial path: the Jacobian is eliminated without fill, there is no "
                                 "dense contraction)"},
         }
+        if dist is not None:
+            maps = open("/proc/self/maps").read()
+            out["dist"] = {"backend": a.backend, "world_size": world, "forced_at_one_rank": bool(a.force_dist and world == 1),
+                           "rccl_loaded": "librccl" in maps, "collectives_in_timed_region": ["all_gather_into_tensor(episode returns)",
+                           "all_reduce(MAX, block time)", "barrier x2"], "gathered_rows_last_block": int(m["returns"].shape[0]) if m["returns"] is not None else None}
         if shapes:
             out["other_shapes"] = shapes
         if cpu is not None:

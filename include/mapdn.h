@@ -353,6 +353,10 @@ int mapdn_layernorm64_backward(const float* dy, const float* x, const float* gam
  * against a known byte count.  Bp a multiple of 256, rows x Bp x 16 < 4 GiB. */
 int mapdn_debug_stream(const double* src, double* dst, int32_t rows, int32_t Bp, int32_t pattern, void* stream);
 
+/* "MAPDN_SRC_HASH=<hex>": sha256 of the sources + flags the library was built from (mapdn_amd/build.py::source_hash).  The Python
+ * loader refuses (or rebuilds) a library whose hash differs from the sources beside it.  No reference counterpart: build hygiene. */
+const char* mapdn_build_info(void);
+
 /* counters (host, synchronises the given stream): number of envs whose last reset exhausted
  * max_tries; mean / max NR iterations of the last solve */
 int mapdn_stats(mapdn_handle* h, int64_t* reset_failures, double* mean_iters, int32_t* max_iters,

@@ -32,7 +32,7 @@ EXPORTS = (
     "mapdn_solve_only", "mapdn_get_ybus_dense", "mapdn_get_obs_index", "mapdn_get_schedule", "mapdn_get_flat_factors", "mapdn_stats", "mapdn_nr_timing",
     "mapdn_nr_time_ms", "mapdn_get_auto_reset_mask", "mapdn_dense_solve", "mapdn_step_obs", "mapdn_get_sparse_program", "mapdn_policy_forward",
     "mapdn_policy_forward_fits", "mapdn_layernorm64_forward", "mapdn_layernorm64_backward", "mapdn_layernorm64_backward_blocks",
-    "mapdn_get_nr_geometry", "mapdn_debug_stream",
+    "mapdn_get_nr_geometry", "mapdn_debug_stream", "mapdn_build_info",
 )
 
 _pd = C.POINTER(C.c_double)
@@ -107,16 +107,19 @@ def load():
     # process, shared streams and device pointers.  (Loading ours first drags in /opt/rocm's copy
     # and the second runtime then fails with "no ROCm-capable device".)
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
-        # not a fallback: compile the same HIP sources in-tree (hipcc cross-compiles gfx950), once,
+    if "MAPDN_LIB_PATH" not in os.environ:
+        # not a fallback: a missing library — or one whose embedded source hash differs from the sources beside it (a prebuilt
+        # .so shipped with edited sources) — is compiled from the same HIP sources in-tree (hipcc cross-compiles gfx950), once,
         # race-free when several ranks start together; raise if that is impossible
         from . import build as _build
-        try:
-            _build.build_locked()
-        except Exception as exc:
-            raise ImportError(
-                f"{LIB_PATH} not found and could not be built ({exc}); build it with "
-                "`python -m mapdn_amd.build` (hipcc --offload-arch=gfx950); there is no CPU fallback") from exc
+        if _build.stale():
+            try:
+                _build.build_locked()
+            except Exception as exc:
+                raise ImportError(
+                    f"{LIB_PATH} is missing or was built from other sources than mapdn_amd/csrc (hash {_build.library_hash()} vs "
+                    f"{_build.source_hash()}) and could not be rebuilt ({exc}); build it with `python -m mapdn_amd.build` "
+                    "(hipcc --offload-arch=gfx950); there is no CPU fallback") from exc
     lib = C.CDLL(os.environ.get("MAPDN_LIB_PATH", LIB_PATH))      # override: A/B experiments with debug builds only
     if "MAPDN_LIB_PATH" in os.environ:                              # an OLDER build for a same-box A/B may lack the newest exports
         for name in EXPORTS:
@@ -127,6 +130,8 @@ def load():
     vp = C.c_void_p
     lib.mapdn_last_error.restype = C.c_char_p
     lib.mapdn_last_error.argtypes = [vp]
+    lib.mapdn_build_info.restype = C.c_char_p
+    lib.mapdn_build_info.argtypes = []
     lib.mapdn_create.argtypes = [C.POINTER(CNetSpec), C.POINTER(CEnvConfig), C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.mapdn_destroy.argtypes = [vp]
     lib.mapdn_destroy.restype = None
@@ -160,7 +165,7 @@ def load():
     lib.mapdn_nr_timing.argtypes = [vp, C.c_int32]
     lib.mapdn_nr_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
-        if name not in ("mapdn_last_error", "mapdn_destroy"):
+        if name not in ("mapdn_last_error", "mapdn_destroy", "mapdn_build_info"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib

@@ -1,6 +1,7 @@
 """Build libmapdn_hip.so in-tree with hipcc for gfx950 (no torch, no cmake)."""
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -14,25 +15,61 @@ NR_INST_SOURCE, NR_PARTS = "nr_inst.hip", 4
 HEADERS = ["plan.hpp", "kernels.hpp", "philox.hpp", "nrmath.hpp", "nr_common.hpp", "nr_tree.hpp", "nr_inst_list.hpp", NR_INST_SOURCE,
            os.path.join("..", "..", "include", "mapdn.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+HASH_TAG = b"MAPDN_SRC_HASH="
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+def _extra_flags():
+    return os.environ.get("MAPDN_EXTRA_FLAGS", "").split()        # debug builds only (e.g. -DMAPDN_NR_STAMPS)
+
+
+def source_hash() -> str:
+    """sha256 over the CONTENT of every source / header (by name, sorted) and the compiler flags: what the library on disk must
+    have been built from.  Content, not mtimes: a checkout, a copy to another box or `touch` do not change it; an edit does."""
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        h.update(os.path.basename(name).encode() + b"\0")
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(" ".join(FLAGS + _extra_flags()).encode())
+    return h.hexdigest()
+
+
+def library_hash(path: str | None = None) -> str | None:
+    """the source hash embedded in a built library (mapdn_build_info(), capi.hip), read from the file without loading it"""
+    path = path or LIB
+    try:
+        with open(path, "rb") as f:
+            data = f.read()
+    except OSError:
+        return None
+    i = data.find(HASH_TAG)
+    while i >= 0:
+        digest = data[i + len(HASH_TAG): i + len(HASH_TAG) + 64]
+        if len(digest) == 64 and all(c in b"0123456789abcdef" for c in digest):
+            return digest.decode()
+        i = data.find(HASH_TAG, i + 1)
+    return None
+
+
+def stale() -> bool:
+    """True when the library is missing or was built from other sources / flags than the ones on disk"""
+    return library_hash() != source_hash()
+
+
+_stale = stale          # (older name)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc -c every translation unit (in parallel: the NR instantiations dominate), then link the shared library."""
-    if not force and not _stale():
+    if not force and not stale():
         return LIB
     import shutil
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("MAPDN_EXTRA_FLAGS", "").split()        # debug builds only (e.g. -DMAPDN_NR_STAMPS)
+    extra = _extra_flags()
+    digest = source_hash()
     objdir = tempfile.mkdtemp(prefix="mapdn_build_")
     jobs = []                                                      # (command, object)
     for p in range(NR_PARTS):                                      # longest first
@@ -40,7 +77,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         jobs.append(([hipcc] + FLAGS + extra + [f"-DNR_INST_PART={p}", "-c", os.path.join(CSRC, NR_INST_SOURCE), "-o", o], o))
     for s in SOURCES:                                              # .cpp host files are compiled as plain C++ by hipcc; .hip as HIP
         o = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
-        jobs.append(([hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, s), "-o", o], o))
+        more = [f'-DMAPDN_SRC_HASH="{digest}"'] if s == "capi.hip" else []
+        jobs.append(([hipcc] + FLAGS + extra + more + ["-c", os.path.join(CSRC, s), "-o", o], o))
 
     def run(job):
         if verbose:
@@ -55,37 +93,39 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(link), file=sys.stderr)
         subprocess.run(link, check=True)
+        if library_hash(tmp) != digest:
+            raise RuntimeError("the linked library does not carry the source hash it was built with")
         os.replace(tmp, LIB)      # atomic: a concurrent loader never sees a half-written library
     finally:
         shutil.rmtree(objdir, ignore_errors=True)
     return LIB
 
 
-def build_locked(timeout: float = 600.0) -> str:
-    """build() guarded by a lock file, for several processes (ranks) that find the library missing."""
+def build_locked(timeout: float = 900.0) -> str:
+    """build() guarded by a lock file, for several processes (ranks) that find the library missing or stale at the same time:
+    exactly one of them compiles, the others wait for it and then use its result."""
     import time
     lock = LIB + ".lock"
     t0 = time.time()
     while True:
         try:
             fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
-            break
         except FileExistsError:
-            if os.path.exists(LIB) and not os.path.exists(lock):
-                return LIB
             if time.time() - t0 > timeout:
-                raise TimeoutError(f"waiting for {lock}")
-            time.sleep(0.5)
-            if os.path.exists(LIB) and not os.path.exists(lock):
+                raise TimeoutError(f"waiting for {lock} (left behind by a killed build? remove it)")
+            time.sleep(0.25)
+            if not os.path.exists(lock) and not stale():
                 return LIB
-    try:
-        os.close(fd)
-        return build() if _stale() else LIB
-    finally:
+            continue
         try:
-            os.remove(lock)
-        except OSError:
-            pass
+            os.write(fd, str(os.getpid()).encode())
+            os.close(fd)
+            return build() if stale() else LIB
+        finally:
+            try:
+                os.remove(lock)
+            except OSError:
+                pass
 
 
 if __name__ == "__main__":

@@ -13,10 +13,6 @@
 #include "plan.hpp"
 
 using namespace mapdn;
-#ifdef MAPDN_EXP_MERGED_POST
-namespace mapdn { void launch_post_merged(const Dev& d, int add_noise, uint32_t sb_write_off, const double* base, const int32_t* rows, const double* scales,
-                                          const int32_t* x_ptr, const int32_t* x_row, void* out, int C, hipStream_t st); }
-#endif
 
 struct mapdn_handle {
   Plan plan;
@@ -229,6 +225,13 @@ static int settle_tree_geometry(mapdn_handle* h, int Bp, int n_cu) {
 extern "C" {
 
 const char* mapdn_last_error(const mapdn_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+#ifndef MAPDN_SRC_HASH
+#define MAPDN_SRC_HASH "unknown"
+#endif
+// "MAPDN_SRC_HASH=<sha256 of the sources and flags this library was built from>" (mapdn_amd/build.py): the loader compares it with the
+// sources on disk, so that a prebuilt library can never silently disagree with them
+const char* mapdn_build_info(void) { return "MAPDN_SRC_HASH=" MAPDN_SRC_HASH; }
 
 static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_env_config* cfg, int32_t B, int32_t device) {
   if (!net || !cfg) { h->err = "null netspec/config"; return MAPDN_E_INVALID; }
@@ -734,16 +737,6 @@ int mapdn_step_obs(mapdn_handle* h, const void* actions, int32_t actions_dtype, 
   hipStream_t st = (hipStream_t)stream;
   const Dev& d = h->d;
   const int C = h->plan.n_agents * h->plan.obs_size;
-#ifdef MAPDN_EXP_MERGED_POST
-  if (getenv("MAPDN_EXP_MERGED") && obs_dtype == MAPDN_F32) {   // timing experiment (wrong obs): advance + gather as one launch
-    const bool fused = h->fuse_inject && h->solver == 0 && !h->sbus_stale;
-    if (!fused) inject_launch(h, MODE_STEP, actions, actions_dtype, add_noise, st);
-    nr_launch(h, MODE_STEP, reward, terminated, info, st, fused ? actions : nullptr, actions_dtype);
-    launch_post_merged(d, add_noise, d.sb_off_alt, d.gbuf, h->obs_rows, h->obs_scale, h->obs_xptr, h->obs_xrow, obs, C, st);
-    std::swap(h->d.sb_off, h->d.sb_off_alt);
-    return MAPDN_OK;
-  }
-#endif
   { const int rc = step_launches(h, actions, actions_dtype, add_noise, reward, terminated, info, st); if (rc) return rc; }
   launch_gather(d, d.gbuf, h->obs_rows, h->obs_scale, 1.0, h->obs_xptr, h->obs_xrow, obs, obs_dtype, C, st);
   HIPCHK(h, hipGetLastError());

@@ -73,13 +73,10 @@ static __device__ unsigned long long g_stamps[4096];   // one copy per translati
 #endif
 
 
-#ifndef MAPDN_EXP
-#define MAPDN_EXP 0      // debug experiments only (timing A/B builds); 0 in the product
+#if defined(MAPDN_EXP) || defined(MAPDN_NO_FUSE_PROLOGUE)
+#error "MAPDN_EXP / MAPDN_NO_FUSE_PROLOGUE were timing-experiment switches of rounds 3-4 (results under profiles/); they produced wrong results by design and are gone"
 #endif
 __device__ __forceinline__ void lds_barrier() {
-#if (MAPDN_EXP & 4)
-  return;
-#endif
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -181,7 +178,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // bookkeeping its first row does.  One item per (PV bus, env), env fastest; a launch of its own cost 6.8 us for 90 k such
   // items (launch + a chain of dependent loads); here the chain runs once per workgroup beside the LDS initialisation.  The
   // Sbus entries are read back by this workgroup only, after the barrier that ends the prologue.
-#ifndef MAPDN_NO_FUSE_PROLOGUE      // (A/B builds only: the kernel without the prologue, to separate its register-allocation side effects)
   if (d.fi_actions) {
     // Items are taken IT at a time per thread with ALL loads of a level issued before any is used (record + flags, then the
     // values): the chain is paid once per batch, not once per item.  Loads are unconditional with clamped indices, only the
@@ -285,7 +281,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       }
     }
   }
-#endif
   // LDS map, in pair rows (L x 16 bytes: one d2 per env; a worker's 16 lanes read 256 contiguous bytes with one
   // conflict-free ds_read_b128):  V [n+2] | h [n+2] if HL | G [2(n+2)] if GL | contribution slots x 4 | x slots x 1
   //   then verdict bytes [64 W], step sizes [64 W doubles], overflow child list, net.line constants (when they fit)
@@ -685,15 +680,10 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   //   =>  V <- V (1 - y1) e^{-j y0}   (rotation by the small step; |V|, angle are formed at the end)
   auto apply_update = [&](double y0, double y1, d2 vk, unsigned k, bool live) {
     dxm = fmax(dxm, live ? fmax(fabs(y0), fabs(y1)) : 0.0);
-#if (MAPDN_EXP & 2)
-    return;
-#endif
     double s, c;
     const double dth = -y0;
     sincos_small(dth, &s, &c);
-#if !(MAPDN_EXP & 1)
     if (__any(live && !(fabs(dth) <= 0.5))) sincos_mid(dth, &s, &c);   // wave-uniform, only when a lane takes a large step (nr_common.hpp)
-#endif
     sV[(size_t)k * L] = done ? vk : nr_rotate(vk, s, c, y1);   // converged envs keep their state; idle steps hit the trash node
   };
   // ... of three nodes at once: ONE wave-uniform check for the rare large-angle case instead of one per node, so that the three

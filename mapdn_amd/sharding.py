@@ -28,11 +28,12 @@ def make_sharded_env(net, profiles, args, total_envs: int, rank: int, world_size
     return VoltageControlBatch(net, profiles, args, n_envs=hi - lo, device=device, env_id_offset=lo, **kw)
 
 
-def gather_rollout(x: torch.Tensor, sizes=None):
+def gather_rollout(x: torch.Tensor, sizes=None, force: bool = False):
     """End-of-rollout gather: concatenates each rank's [B_local, ...] tensor along dim 0 on every
-    rank, in global env-id order.  `sizes` = per-rank B_local when shards are uneven."""
+    rank, in global env-id order.  `sizes` = per-rank B_local when shards are uneven.  `force`: run the
+    collective on a one-rank group too (bench.py --force-dist: first contact with RCCL on one GPU)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return x
     world = dist.get_world_size()
     x = x.contiguous()

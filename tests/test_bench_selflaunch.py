@@ -25,6 +25,8 @@ def test_self_launch_builds_a_torchrun_command(monkeypatch):
         seen["cmd"], seen["env"] = cmd, env
         return 0
     monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    import torch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)                  # an 8-GPU node
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     with pytest.raises(SystemExit) as e:
@@ -34,6 +36,25 @@ def test_self_launch_builds_a_torchrun_command(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_self_launch_fails_fast_when_the_node_has_fewer_gpus_than_ranks(monkeypatch):
+    """`--gpus N` under nccl (one rank per GPU over RCCL) on a node with fewer GPUs says so in one sentence before
+    any rank starts; gloo (ranks may share a GPU: the pre-flight tests) is still launched"""
+    import torch
+    bench = _bench_module()
+    called = []
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: called.append(cmd) or 0)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "exposes 1 GPU" in str(e.value.code) and "--backend gloo" in str(e.value.code) and not called
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--backend", "gloo"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(called) == 1
 
 
 @pytest.mark.gpu
@@ -107,3 +128,22 @@ def test_bench_single_gpu_line_has_live_traffic_and_cpu_baseline():
     ro = j["roofline"]
     assert ro["bound"] == "hbm" and "latency" in ro["limited_by"] and abs(ro["frac"] - ro["achieved"] / 8000.0) < 1e-12
     assert ro["traffic_detail"] is not None and (ro["traffic_detail"].get("bytes") or ro["traffic_detail"].get("error"))
+
+
+@pytest.mark.gpu
+def test_bench_force_dist_rccl_first_contact():
+    """the nccl (RCCL) code path of bench.py — init_process_group("nccl", device_id=...), all_gather_into_tensor on a
+    DEVICE tensor, all_reduce(MAX) of the block time, the barriers of fence() — on ONE rank, so that an RCCL initialisation / IPC failure
+    shows up here and not in the driver's first real SCALE run.  librccl must be mapped into the process."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--envs", "256", "--steps", "6", "--warmup", "2",
+                        "--no-traffic", "--no-cpu-baseline", "--no-other-shapes"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    d = j["dist"]
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and d["forced_at_one_rank"] and d["rccl_loaded"] is True
+    assert d["gathered_rows_last_block"] == 256 and j["n_gpus"] == 1 and j["value"] > 0

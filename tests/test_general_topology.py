@@ -9,6 +9,7 @@ import pytest
 
 from mapdn_amd import _lib
 from mapdn_amd.netspec import NetSpec, Profiles, add_lines, case33_meshed, make_case
+from tests.edge_rule import same_newton_count
 from oracle.pp_restated import make_ybus, residual_inf, runpp_restated
 
 
@@ -211,7 +212,7 @@ def test_meshed_solve_matches_oracle(solver, which, monkeypatch):
     worst = 0.0
     for e in range(B):
         r = runpp_restated(net, pl[e], ql[e], pv[e], qs[e])
-        assert r.converged and r.iterations == it[e]
+        assert r.converged and same_newton_count(net, (pl[e], ql[e], pv[e], qs[e]), it[e], True, r)
         worst = max(worst, np.abs(vm[e] - r.vm_pu).max(), np.abs(va[e] - r.va_degree).max() * np.pi / 180)
         v = vm[e] * np.exp(1j * va[e] * np.pi / 180)
         assert residual_inf(net, v, pl[e], ql[e], pv[e], qs[e]) < 1e-8 / net.sn_mva
