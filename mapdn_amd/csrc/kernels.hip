@@ -12,7 +12,6 @@
 // voltage_control_env.py:557) and MAPDN's VoltageControl methods cited at each kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -457,8 +456,8 @@ __global__ void __launch_bounds__(256) k_commit_fused(Dev d) {
 //                both the env-minor reads and the env-major writes are coalesced.
 // =================================================================================================
 #define GATHER_HAS_EXTRA 0x40000000   // flag bit in a row descriptor: the column has add-back rows (x_ptr/x_row)
-template <typename T, bool XM, typename SRC = double>
-__device__ __forceinline__ void gather_body(const SRC* __restrict__ base, const int32_t* rows_g, const double* scales_g,
+template <typename T, bool XM>
+__device__ __forceinline__ void gather_body(const double* __restrict__ base, const int32_t* rows_g, const double* scales_g,
                                             double scale_all, const int32_t* x_ptr_g, const int32_t* x_row_g,
                                             T* __restrict__ out, int C, int B, int Bp, unsigned blk_x, unsigned blk_y, unsigned grd_x, unsigned grd_y, int xl) {
   __shared__ T tile[64][65];                      // output-typed tile: 16.6 KB for f32 -> 8 workgroups per CU
@@ -491,12 +490,12 @@ __device__ __forceinline__ void gather_body(const SRC* __restrict__ base, const 
   double v[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i)
-    v[i] = (rw[i] >= 0) ? (double)base[(size_t)(rw[i] & ~GATHER_HAS_EXTRA) * Bp + etx] * sc[i] : 0.0;
+    v[i] = (rw[i] >= 0) ? base[(size_t)(rw[i] & ~GATHER_HAS_EXTRA) * Bp + etx] * sc[i] : 0.0;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     if (rw[i] >= 0 && (rw[i] & GATHER_HAS_EXTRA)) {   // wave-uniform, only the PV-bus columns
       const int c = c0 + ty + 4 * i;
-      for (int q = x_ptr[c]; q < x_ptr[c + 1]; ++q) v[i] += (double)base[(size_t)x_row[q] * Bp + etx];
+      for (int q = x_ptr[c]; q < x_ptr[c + 1]; ++q) v[i] += base[(size_t)x_row[q] * Bp + etx];
     }
     tile[ty + 4 * i][tx] = (T)v[i];
   }
@@ -527,42 +526,6 @@ k_gather(const double* __restrict__ base, const int32_t* rows_g, const double* s
          T* __restrict__ out, int C, int B, int Bp, int xl) {
   gather_body<T, XM>(base, rows_g, scales_g, scale_all, x_ptr_g, x_row_g, out, C, B, Bp, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, xl);
 }
-
-#ifdef MAPDN_AB_F32MIRROR
-#ifndef MAPDN_DEBUG_BUILD
-#error "MAPDN_AB_F32MIRROR is a timing experiment (wrong obs): it needs -DMAPDN_DEBUG_BUILD"
-#endif
-// TIMING EXPERIMENT ONLY (profiles/r05_f32_obs_mirror_ab.txt): what would an f32 mirror of the gatherable state block buy?
-//   MAPDN_AB_GATHER32=1: the f32 obs gather reads 4-byte columns from a float block of the same shape (its CONTENT is not maintained)
-//   MAPDN_AB_MIRROR=1:   the commit rows of k_advance additionally write the four floats per bus that would maintain it
-static float* g_ab32 = nullptr;
-static float* ab32(const Dev& d) {
-  if (!g_ab32) { (void)hipMalloc((void**)&g_ab32, (size_t)(2 * d.ns + 4 * d.nbo) * d.Bp * sizeof(float)); (void)hipMemset(g_ab32, 0, (size_t)(2 * d.ns + 4 * d.nbo) * d.Bp * sizeof(float)); }
-  return g_ab32;
-}
-__global__ void __launch_bounds__(256)
-k_gather_ab(const float* __restrict__ base, const int32_t* rows_g, const double* scales_g, double scale_all, const int32_t* x_ptr_g,
-            const int32_t* x_row_g, float* __restrict__ out, int C, int B, int Bp) {
-  gather_body<float, false, float>(base, rows_g, scales_g, scale_all, x_ptr_g, x_row_g, out, C, B, Bp, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, 0);
-}
-__global__ void __launch_bounds__(256) k_advance_ab(Dev d, int add_noise, int do_profiles, int do_commit, uint32_t sb_write_off, float* m32) {
-  const int e = (int)(blockIdx.x * 256u + threadIdx.x);
-  if (e >= d.B) return;
-  const int npv = (d.ns + 1) >> 1, npl = (d.nl + 1) >> 1;
-  const int npairs = do_profiles ? npv + npl : 0;
-  const size_t S = (size_t)d.Bp;
-  if ((int)blockIdx.y >= npairs) {
-    const int b_ = (int)blockIdx.y - npairs;
-    double v, va, P, Q;
-    commit_bus<true>(d, b_, e, S, v, va, P, Q);
-    float* o = m32 + (size_t)(2 * d.ns + b_) * S + e;
-    o[0] = (float)v; o[(size_t)d.nbo * S] = (float)va; o[(size_t)2 * d.nbo * S] = (float)P; o[(size_t)3 * d.nbo * S] = (float)Q;
-    return;
-  }
-  if ((int)blockIdx.y < npv) { double v0, v1; advance_pv_pair<false>(d, e, (int)blockIdx.y, add_noise, S, v0, v1); }
-  else advance_load_pair(d, e, (int)blockIdx.y - npv, add_noise, S, sb_write_off);
-}
-#endif
 
 // env-major [B, n] -> env-minor [n][Bp] (zero-fills the pad lanes)
 __global__ void __launch_bounds__(256)
@@ -689,7 +652,7 @@ void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* in
   if (d.dense) { launch_nr_dense(d, mode, reward, term, info, st); return; }
   if (d.sparse) { launch_nr_sparse(d, mode, reward, term, info, st); return; }
   const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.n, d.nr_cslots, d.nr_xslots, d.nr_nclist, d.nr_h_lds, d.nr_g_lds,
-                                  d.nr_line_lds ? d.n_line : 0, d.nr_rec_lds ? d.nr_rows : 0, d.nr_flat_lds ? d.nr_rows : 0);
+                                  d.nr_line_lds ? d.n_line : 0, d.nr_rec_lds ? d.nr_rows : 0, d.nr_flat_lds ? d.nr_rows : 0, d.nr_pairs, d.nr_ytop_lds);
   const NrInst* I = nr_pick(d.nr_waves, d.nr_lanes, d.nr_h_lds, d.nr_g_lds, d.nr_rec_lds, d.nr_flat_lds);
   if (!I) return;                                   // (mapdn_create refuses such a geometry: nr_set_lds_limit)
 #ifdef MAPDN_NR_STAMPS
@@ -723,9 +686,6 @@ void launch_advance(const Dev& d, int add_noise, int do_profiles, int do_commit,
   const int rows = (do_profiles ? ((d.ns + 1) >> 1) + ((d.nl + 1) >> 1) : 0) + (do_commit ? d.nbo : 0);
   if (rows == 0) return;
   const unsigned gx = d.xcd_lanes ? xcd_blocks((unsigned)d.Bp, 256u, (unsigned)d.xcd_lanes) : (unsigned)((d.B + 255) / 256);
-#ifdef MAPDN_AB_F32MIRROR
-  if (getenv("MAPDN_AB_MIRROR") && do_commit) { hipLaunchKernelGGL(k_advance_ab, dim3(gx, rows), dim3(256), 0, st, d, add_noise, do_profiles, do_commit, sb_write_off, ab32(d)); return; }
-#endif
   hipLaunchKernelGGL(k_advance, dim3(gx, rows), dim3(256), 0, st, d, add_noise, do_profiles, do_commit, sb_write_off);
 }
 void launch_commit_fused(const Dev& d, hipStream_t st) {
@@ -740,10 +700,6 @@ void launch_gather(const Dev& d, const double* base, const int32_t* rows, const 
                    const int32_t* x_ptr, const int32_t* x_row, void* out, int dtype, int C, hipStream_t st) {
   const int xl = d.xcd_lanes;
   dim3 grid((C + 63) / 64, xl ? xcd_blocks((unsigned)d.Bp, 64u, (unsigned)xl) : (unsigned)(d.Bp / 64));
-#ifdef MAPDN_AB_F32MIRROR
-  if (getenv("MAPDN_AB_GATHER32") && dtype == MAPDN_F32 && base == d.gbuf && !xl) {
-    hipLaunchKernelGGL(k_gather_ab, grid, dim3(256), 0, st, ab32(d), rows, scales, scale_all, x_ptr, x_row, (float*)out, C, d.B, d.Bp); return; }
-#endif
   if (dtype == MAPDN_F32) {
     if (xl) hipLaunchKernelGGL((k_gather<float, true>), grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (float*)out, C, d.B, d.Bp, xl);
     else hipLaunchKernelGGL((k_gather<float, false>), grid, dim3(256), 0, st, base, rows, scales, scale_all, x_ptr, x_row, (float*)out, C, d.B, d.Bp, 0);

@@ -13,7 +13,7 @@
   X(4, 16, true, false, 1) X(4, 16, true, false, 3) X(4, 16, true, false, 0) X(4, 16, true, true, 0) X(4, 16, false, false, 0)
 // part 1: small feeders (n < 48: one wave) and the lean layout of the 141-bus class
 #define NR_INSTS_1(X) \
-  X(1, 16, true, true, 1) X(1, 16, true, true, 0) X(1, 16, true, false, 0) X(1, 16, false, false, 0) \
+  X(1, 16, true, true, 1) X(1, 16, true, true, 3) X(1, 16, true, true, 0) X(1, 16, true, false, 0) X(1, 16, false, false, 0) \
   X(2, 16, false, false, 2) X(2, 16, false, false, 0) X(2, 16, true, false, 0) X(2, 16, true, true, 0)
 // part 2: the 322-bus class: 8 envs per workgroup (32 workers), 16 beyond one round of workgroups
 #define NR_INSTS_2(X) \
