@@ -173,17 +173,18 @@ static int settle_tree_geometry(mapdn_handle* h, int Bp, int n_cu) {
       g.lds = lds_for(g.h_lds, g.g_lds, g.line_lds, g.rec_lds, g.flat_lds);
       g.pairs = np;
       if (g.lds > LDS_MAX) { fits = false; break; }
-      const int need = g.g_lds ? 0 : (g.h_lds ? NR_G_REG_ROWS : NR_HG_REG_ROWS);
+      const int need = (np || g.g_lds) ? 0 : (g.h_lds ? NR_G_REG_ROWS : NR_HG_REG_ROWS);   // (the pair bodies peel no rows)
       if (R_ >= need) { min_rows = -1; break; }
       min_rows = need;
     }
-    if (with_pairs && (!fits || !g.h_lds || S.pairs == 0)) continue;        // this layout cannot run pairs (or the feeder has none): plain schedule
+    if (with_pairs && (!fits || !g.h_lds || S.pairs == 0 || !nr_geometry_compiled(W, L, g.h_lds, g.g_lds, g.rec_lds, g.flat_lds, 1))) continue;   // this layout cannot
+                                                              // run pairs, the feeder has none, or no pair body is compiled for it: plain schedule
     if (!fits) return 1;
     if (min_rows >= 0) { h->err = "NR schedule: could not settle the number of peeled rows"; return MAPDN_E_INVALID; }
     break;
     }
-    if (f_pairs == 1 && g.pairs == 0 && !lean) { h->err = "nr_pairs = 1 (MAPDN_NR_PAIRS): this layout cannot run the chain-pair schedule (it needs the h factors in LDS and the mismatch pass) or the feeder has no chain to fuse"; return MAPDN_E_INVALID; }
-    const int compiled = nr_geometry_compiled(W, L, g.h_lds, g.g_lds, g.rec_lds, g.flat_lds);
+    if (f_pairs == 1 && g.pairs == 0) return 1;   // pinned on: only layouts that run the chain-pair schedule are candidates
+    int compiled = nr_geometry_compiled(W, L, g.h_lds, g.g_lds, g.rec_lds, g.flat_lds, g.pairs);
     if (!compiled) return 1;
     g.W = W; g.L = L; g.lean = lean; g.rows = S.R;
     g.wgs = Bp / L;
@@ -222,6 +223,10 @@ static int settle_tree_geometry(mapdn_handle* h, int Bp, int n_cu) {
     if (r == 0) { best = g; bestS = std::move(S); have = true; }
     else if (g.lds > LDS_MAX) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (nr_lanes / MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
   }
+  if (!have && f_pairs == 1) {
+    h->err = "nr_pairs = 1 (MAPDN_NR_PAIRS): no compiled layout runs the chain-pair schedule on this feeder (it needs the h factors in LDS, the "
+             "mismatch pass, a pair body for the (waves, lanes) pair — csrc/nr_inst_list.hpp — and a feeder with chains)";
+    return MAPDN_E_INVALID; }
   if (!have) {
     h->err = (W || L) ? "this (nr_waves, nr_lanes) combination is not compiled in or does not fit the 160 KB LDS of a CU (csrc/nr_inst_list.hpp)"
                       : "no compiled k_nr_tree geometry fits this network into the 160 KB LDS of a CU";
@@ -534,7 +539,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   {
     // the attribute is per kernel function, not per handle: always raise it to the full 160 KB so that
     // handles with different LDS needs can share an instantiation
-    const int lr = nr_set_lds_limit(G_.W, G_.L, G_.h_lds, G_.g_lds, G_.rec_lds, G_.flat_lds, 160 * 1024);
+    const int lr = nr_set_lds_limit(G_.W, G_.L, G_.h_lds, G_.g_lds, G_.rec_lds, G_.flat_lds, 160 * 1024, G_.pairs);
     if (lr == -2) { h->err = "this (nr_waves, nr_lanes) combination is not compiled in (csrc/nr_inst_list.hpp)"; return MAPDN_E_INVALID; }
     if (lr != 0) { (void)hipGetLastError(); h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return MAPDN_E_HIP; }
   }

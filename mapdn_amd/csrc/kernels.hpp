@@ -111,8 +111,8 @@ void launch_inject_sgen(const Dev& d, int mode, const void* actions, int dtype, 
 // fused_actions != nullptr (MODE_STEP only): k_nr_tree's prologue performs the PV-bus injection itself (no k_inject_sgen launch)
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st,
                const void* fused_actions = nullptr, int fused_dtype = 0);
-int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds, size_t bytes);   // -2: geometry not instantiated
-int nr_geometry_compiled(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds);
+int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds, size_t bytes, int pairs = 0);   // -2: geometry not instantiated
+int nr_geometry_compiled(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds, int pairs = 0);
 // dynamic LDS of k_nr_tree (W waves, L envs per workgroup => Wt = W*64/L workers), in pair rows of L x 16 bytes:
 // node voltages (n+2: nodes, slack, trash), h (n+2) and G (2(n+2)) when resident, contribution slots (4 rows each),
 // x slots (1 row each); then verdict bytes, step-size partials (64*W doubles), overflow child list (padded to

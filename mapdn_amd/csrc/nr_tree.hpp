@@ -142,7 +142,10 @@ struct BwdF { d2 h, g01, g23; };                        // factors of one step w
 // HL / GL: the h / G factors live in LDS (when they fit) instead of global scratch.  RES: 1 = step records and flat-start
 // constants are LDS-resident (compile-time: the "fat" geometry), 2 = neither is (the "lean" one), 3 = the records are, the
 // flat-start constants are not (the 322-bus feeder: W = 4, L = 8), 0 = per handle (d.nr_*_lds)
-template <int W, int L, bool HL, bool GL, int RES = 0>
+// PAIRS: the instantiation runs chain-pair schedules (HL only).  Its step bodies carry the pair algebra, so it keeps NO peeled rows
+// (every copy of a row is instruction-cache footprint): all G factors go through LDS or the factor blocks.  The others are the
+// round-4 bodies, untouched.
+template <int W, int L, bool HL, bool GL, int RES = 0, bool PAIRS = false>
 __global__ void __launch_bounds__(64 * W)
 k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ terminated, double* __restrict__ info) {
   extern __shared__ d2 lds2[];
@@ -165,7 +168,8 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // chain pairs: the Y constants of a pair's TOP node come from a table by NODE (Schedule::ytop: 64 bytes per node; the node numbers
   // of a pair step are in its first record), LDS-resident when it fits
   const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(d.ytop), 0, d.ytop_bytes, 0x00020000);
-  const bool pairsOn = HL && d.nr_pairs != 0;    // (uniform over the launch)
+  static_assert(!PAIRS || HL, "chain pairs need the h factors in LDS");
+  constexpr bool pairsOn = PAIRS;               // (the host launches a PAIRS instantiation iff the handle's schedule has pairs)
   const unsigned pb = (unsigned)d.Bp * 16u;      // bytes per pair row (one d2 per env)
   constexpr unsigned TB = (unsigned)sizeof(StepRec);        // bytes per step record
   constexpr unsigned FB = (unsigned)FLAT_N * 8u;            // bytes per flat-start step
@@ -394,12 +398,12 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // instruction-cache footprint (its first execution in a launch is cold), which is what limits KR.
   // When h lives in global scratch too (!HL: the lean layouts, the 322-bus feeder at 16 envs per workgroup), the peeled rows keep
   // h AND G in registers (12 AGPRs per row) and there are NR_HG_REG_ROWS of them.
-  constexpr int KR = GL ? 0 : (HL ? NR_G_REG_ROWS : NR_HG_REG_ROWS);
+  constexpr int KR = (GL || PAIRS) ? 0 : (HL ? NR_G_REG_ROWS : NR_HG_REG_ROWS);
   constexpr bool RH = !HL;                         // the peeled rows' h is in registers as well
   uint32_t Ga[KR > 0 ? KR : 1][8];                 // AGPR-class values: written / read only by the two helpers below
   uint32_t Ha[(KR > 0 && RH) ? KR : 1][4];
-  constexpr bool PA = HL && KR > 0;                // chain pairs in the peeled rows: G_kp and G_kb of the top node, 16 more AGPRs per row
-  uint32_t Gk[PA ? KR : 1][16];
+  constexpr bool PA = false;                       // (pairs in peeled rows were measured: 16 more AGPRs per row and nine copies of the pair
+  uint32_t Gk[1][16];                              //  algebra cost more than the rows they saved — PAIRS instantiations do not peel)
   auto a_put = [](double v, uint32_t& lo, uint32_t& hi) {
     asm("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(__double2loint(v)));
     asm("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(__double2hiint(v)));
@@ -525,7 +529,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
           for (int i = 0; i < NP; ++i) g1[i] = c1[i * L];
         }
         // chain pairs (wave-uniform): the top node's record, its parent's voltage and its injection
-        const bool pairU = (K == 0) && HL && (flu & SU_PAIR_ANY) != 0u;
+        const bool pairU = PAIRS && (K == 0) && (flu & SU_PAIR_ANY) != 0u;
         Rec T2; d2 vp2 = {0.0, 0.0};
         if (pairU) {
           load_top((fl & S_PAIR) ? (kp >> 16) : n + 1u, T2);
@@ -563,7 +567,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         double oS0 = apk_r, oS1 = apk_i;                                        // the S term the parent receives
         double hk0 = 0.0, hk1 = 0.0, P0 = 0.0, P1 = 0.0, P2 = 0.0, P3 = 0.0, B0 = 0.0, B1 = 0.0, B2 = 0.0, B3 = 0.0;   // h_k, G_kp, G_kb
         unsigned kt = n + 1u;                                                   // the top node (single steps: the trash node)
-        if constexpr (K == 0 && HL) {
+        if constexpr (K == 0 && PAIRS) {
           if (pairU) {
             // The top node k of a pair (b = this step's node, its only child; p = k's parent): every term of its pivot is its own,
             //   S_k = A_kk + A_ks + A_kp + A_kb,  so it is eliminated here, beside the LDS reads of b's children.
@@ -653,20 +657,36 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const double Fp = sr - T.sb.x, Fq = si - T.sb.y;
         pFp = Fp; pFq = Fq; pLive = (fl & S_LIVE) != 0;
         if constexpr (K == 0) {
-          // (every product-sum below is spelled out as one fma + one product: single steps must round alike whether or not a pair
-          //  shares their wave — which depends on the launch geometry)
-          const double D0 = (-(si - akk_i) - aD0) - q0, D1 = ((sr + akk_r) - aD1) - q1;
-          const double D2 = ((sr - akk_r) - aD2) - q2, D3 = ((si + akk_i) - aD3) - q3;
-          const double r0 = (Fp - aR0) - w0, r1 = (Fq - aR1) - w1;
-          const double idet = rcp_nr(fma(D0, D3, -(D1 * D2)));
-          const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
-          const double h0 = fma(I0, r0, I1 * r1), h1 = fma(I2, r0, I3 * r1);
-          // G = D^-1 U,  contribution to the parent: S (the parent's own A term), D = L G (+ the top node's), R = L h (+ the top node's)
-          const double G0 = fma(I0, u0, I1 * u2), G1 = fma(I0, u1, I1 * u3);
-          const double G2 = fma(I2, u0, I3 * u2), G3 = fma(I2, u1, I3 * u3);
-          const double s0 = fma(l0, G0, l1 * G2) + m0, s1 = fma(l0, G1, l1 * G3) + m1;
-          const double s2 = fma(l2, G0, l3 * G2) + m2, s3 = fma(l2, G1, l3 * G3) + m3;
-          const double t0 = fma(l0, h0, l1 * h1) + z0, t1 = fma(l2, h0, l3 * h1) + z1;
+          double h0, h1, G0, G1, G2, G3, s0, s1, s2, s3, t0, t1;
+          if constexpr (PAIRS) {
+            // (every product-sum is spelled out as one fma + one product: a single step must round alike whether or not a pair
+            //  shares its wave — which depends on the launch geometry)
+            const double D0 = (-(si - akk_i) - aD0) - q0, D1 = ((sr + akk_r) - aD1) - q1;
+            const double D2 = ((sr - akk_r) - aD2) - q2, D3 = ((si + akk_i) - aD3) - q3;
+            const double r0 = (Fp - aR0) - w0, r1 = (Fq - aR1) - w1;
+            const double idet = rcp_nr(fma(D0, D3, -(D1 * D2)));
+            const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
+            h0 = fma(I0, r0, I1 * r1); h1 = fma(I2, r0, I3 * r1);
+            // G = D^-1 U,  contribution to the parent: S (the parent's own A term), D = L G (+ the top node's), R = L h (+ the top node's)
+            G0 = fma(I0, u0, I1 * u2); G1 = fma(I0, u1, I1 * u3);
+            G2 = fma(I2, u0, I3 * u2); G3 = fma(I2, u1, I3 * u3);
+            s0 = fma(l0, G0, l1 * G2) + m0; s1 = fma(l0, G1, l1 * G3) + m1;
+            s2 = fma(l2, G0, l3 * G2) + m2; s3 = fma(l2, G1, l3 * G3) + m3;
+            t0 = fma(l0, h0, l1 * h1) + z0; t1 = fma(l2, h0, l3 * h1) + z1;
+          } else {
+            const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) - aD1;
+            const double D2 = (sr - akk_r) - aD2, D3 = (si + akk_i) - aD3;
+            const double r0 = Fp - aR0, r1 = Fq - aR1;
+            const double idet = rcp_nr(D0 * D3 - D1 * D2);
+            const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
+            h0 = I0 * r0 + I1 * r1; h1 = I2 * r0 + I3 * r1;
+            // U = J'(k,p) = [[Im A_kp, Re A_kp], [-Re A_kp, Im A_kp]],  L = J'(p,k) likewise from A_pk
+            G0 = I0 * akp_i - I1 * akp_r; G1 = I0 * akp_r + I1 * akp_i;
+            G2 = I2 * akp_i - I3 * akp_r; G3 = I2 * akp_r + I3 * akp_i;
+            s0 = apk_i * G0 + apk_r * G2; s1 = apk_i * G1 + apk_r * G3;
+            s2 = apk_i * G2 - apk_r * G0; s3 = apk_i * G3 - apk_r * G1;
+            t0 = apk_i * h0 + apk_r * h1; t1 = apk_i * h1 - apk_r * h0;
+          }
           // contribution to the parent: registers (consumed only if the next step has S_CARRY_IN) and the
           // LDS slot (TRASH unless S_SCRATCH_OUT; skipped when no worker of the wave has a real slot)
           cS0 = oS0; cS1 = oS1; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
@@ -684,7 +704,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
             a_put(G0, Ga[RS][0], Ga[RS][1]); a_put(G1, Ga[RS][2], Ga[RS][3]); a_put(G2, Ga[RS][4], Ga[RS][5]); a_put(G3, Ga[RS][6], Ga[RS][7]);
           }
           else { bst2(d2{G0, G1}, rs, voN, sF_G01); bst2(d2{G2, G3}, rs, voN, sF_G23); }
-          if constexpr (HL) {
+          if constexpr (PAIRS) {
             if (pairU) {                           // the top node's factors: h_k beside the others (single steps: 0 into the trash entry), G_kp / G_kb
               sH[(size_t)kt * L] = d2{hk0, hk1};
               if (GL) {
@@ -850,7 +870,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     // one row of the x recurrence.  pk01 .. : the top node's factors when the wave holds a pair (else unused)
     auto xrow = [&](const u32x4& ix, d2 g01, d2 g23, d2 pk01, d2 pk23, d2 bk01, d2 bk23) {
       const uint32_t fl = ix.x, kp = ix.w;
-      const bool pairU = pairsOn && (uni(fl) & SU_PAIR_ANY) != 0u;
+      const bool pairU = PAIRS && (uni(fl) & SU_PAIR_ANY) != 0u;
       const bool pr = pairU && (fl & S_PAIR) != 0;
       const unsigned k = kp & 0xffffu, p = pr ? ((ix.y >> 10) & 0xffffu) : (kp >> 16), kt = pr ? (kp >> 16) : n + 1u;
       // (1) the parent's x (its h slot, already overwritten; the slack entry holds the 0 that elimination roots read), this node's
@@ -870,8 +890,9 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       // (2) x_b = h_b - G_b x_parent  [, x_k = h_k - G_kp x_p - G_kb x_b ]
       const bool cout = (fl & S_CARRY_OUT) != 0;
       const double p0 = cout ? x0 : q.x, p1 = cout ? x1 : q.y;
-      const double y0 = hh.x - fma(g01.x, p0, g01.y * p1);
-      const double y1 = hh.y - fma(g23.x, p0, g23.y * p1);
+      double y0, y1;
+      if constexpr (PAIRS) { y0 = hh.x - fma(g01.x, p0, g01.y * p1); y1 = hh.y - fma(g23.x, p0, g23.y * p1); }
+      else { y0 = hh.x - (g01.x * p0 + g01.y * p1); y1 = hh.y - (g23.x * p0 + g23.y * p1); }
       x0 = y0; x1 = y1;
       sH[(size_t)k * L] = d2{y0, y1};              // (idle steps: the trash node)
       if (pairU) {
