@@ -191,12 +191,6 @@ typedef struct mapdn_env_config {
                                        env on the XCD its solver workgroup runs on (env e of an L-env workgroup i = e / L: XCD i % 8), so
                                        that what one launch writes the next reads from that XCD's L2; 0 (default) / 2: plain order.
                                        Same results; measured a wash (solver -1 us, gather +1 us), so it is opt-in.   env: MAPDN_XCD_MAP */
-  int32_t nr_pairs;                 /* k_nr_tree, chain-pair fusion (round 5): a bus whose only child is b is eliminated together with b in ONE
-                                       schedule step — first, off the critical path (its pivot needs nothing from below) — which takes a row
-                                       off every chain of the feeder (141-bus: 17 -> 11 rows per sweep).  Same linear system, another exact
-                                       elimination order: voltages differ from the plain schedule by rounding (<= 1e-13 p.u.).  0 auto (on for
-                                       the layouts whose h factors are LDS-resident with the mismatch pass), 1 on (refused when the layout
-                                       cannot), 2 off.                                              env: MAPDN_NR_PAIRS=1/0 */
 } mapdn_env_config;
 
 typedef struct mapdn_dims_t {
@@ -358,12 +352,6 @@ int mapdn_layernorm64_backward(const float* dy, const float* x, const float* gam
  * 16-lane worker (pattern 0) — or with whole waves on one row (pattern 1), so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be read
  * against a known byte count.  Bp a multiple of 256, rows x Bp x 16 < 4 GiB. */
 int mapdn_debug_stream(const double* src, double* dst, int32_t rows, int32_t Bp, int32_t pattern, void* stream);
-
-/* the chain-pair schedule a handle with `nr_pairs` on would run on W workers (host; tests replay its flat-start substitution):
- * dims[0] = rows R, dims[1] = pairs; rows_bottom / rows_top [W * R] = the node a step eliminates and the top node fused with it (-1:
- * none / idle); flat [W * R * 12], flat2 [W * R * 24] = the host-factorised flat-start constants (plan.hpp FL_* / F2_*).  Any output
- * pointer may be NULL. */
-int mapdn_get_pair_schedule(const mapdn_handle* h, int32_t W, int32_t* dims, int32_t* rows_bottom, int32_t* rows_top, double* flat, double* flat2);
 
 /* "MAPDN_SRC_HASH=<hex>": sha256 of the sources + flags the library was built from (mapdn_amd/build.py::source_hash).  The Python
  * loader refuses (or rebuilds) a library whose hash differs from the sources beside it.  No reference counterpart: build hygiene. */

@@ -32,7 +32,7 @@ EXPORTS = (
     "mapdn_solve_only", "mapdn_get_ybus_dense", "mapdn_get_obs_index", "mapdn_get_schedule", "mapdn_get_flat_factors", "mapdn_stats", "mapdn_nr_timing",
     "mapdn_nr_time_ms", "mapdn_get_auto_reset_mask", "mapdn_dense_solve", "mapdn_step_obs", "mapdn_get_sparse_program", "mapdn_policy_forward",
     "mapdn_policy_forward_fits", "mapdn_layernorm64_forward", "mapdn_layernorm64_backward", "mapdn_layernorm64_backward_blocks",
-    "mapdn_get_nr_geometry", "mapdn_debug_stream", "mapdn_build_info", "mapdn_get_pair_schedule",
+    "mapdn_get_nr_geometry", "mapdn_debug_stream", "mapdn_build_info",
 )
 
 _pd = C.POINTER(C.c_double)
@@ -69,17 +69,17 @@ class CEnvConfig(C.Structure):
         ("nr_mm_pass", C.c_int32), ("sp_lanes", C.c_int32), ("inject_full", C.c_int32),
         ("nr_check_dx", C.c_double), ("nr_check_quad", C.c_double), ("debug_geometry", C.c_int32),
         ("tolerance_mva", C.c_double), ("tolerance_is_pu", C.c_int32), ("nr_init", C.c_int32),
-        ("fuse_inject", C.c_int32), ("overlap_advance", C.c_int32), ("xcd_map", C.c_int32), ("nr_pairs", C.c_int32),
+        ("fuse_inject", C.c_int32), ("overlap_advance", C.c_int32), ("xcd_map", C.c_int32),
     ]
 
 
 # keys of the `tuning` dict of VoltageControlBatch (== the appended fields of mapdn_env_config)
 TUNING_INT = ("nr_solver", "nr_waves", "nr_lanes", "nr_lean", "nr_h_lds", "nr_g_lds", "nr_rec_lds", "nr_flat_lds", "nr_line_lds",
-              "nr_mm_pass", "sp_lanes", "inject_full", "debug_geometry", "tolerance_is_pu", "nr_init", "fuse_inject", "overlap_advance", "xcd_map", "nr_pairs")
+              "nr_mm_pass", "sp_lanes", "inject_full", "debug_geometry", "tolerance_is_pu", "nr_init", "fuse_inject", "overlap_advance", "xcd_map")
 TUNING_F64 = ("nr_check_dx", "nr_check_quad", "tolerance_mva")
 NR_SOLVERS = dict(auto=0, tree=0, sparse=1, dense=2)
 GEOMETRY_KEYS = ("solver", "waves", "lanes", "lean", "rows", "h_lds", "g_lds", "rec_lds", "flat_lds", "line_lds", "mm_pass",
-                 "lds_bytes", "workgroups", "resident_per_cu", "rounds", "model_ns", "fuse_inject", "n_fused_buses", "n_nodes", "pairs")
+                 "lds_bytes", "workgroups", "resident_per_cu", "rounds", "model_ns", "fuse_inject", "n_fused_buses", "n_nodes", "reserved")
 
 
 class CDims(C.Structure):
@@ -152,7 +152,6 @@ def load():
     lib.mapdn_get_obs_index.argtypes = [vp, _pi, _pi]
     lib.mapdn_get_schedule.argtypes = [vp, C.c_int32, _pi, _pi, _pi]
     lib.mapdn_get_flat_factors.argtypes = [vp, _pd, _pi]
-    lib.mapdn_get_pair_schedule.argtypes = [vp, C.c_int32, _pi, _pi, _pi, _pd, _pd]
     lib.mapdn_get_nr_geometry.argtypes = [vp, _pi]
     lib.mapdn_debug_stream.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.mapdn_get_sparse_program.argtypes = [vp, C.c_int32, _pi, _pi, _pi, _pi]

@@ -36,7 +36,7 @@ struct mapdn_handle {
   std::vector<int32_t> ld_dest_host;
   size_t lds_bytes = 0;
   // what mapdn_create settled on (mapdn_get_nr_geometry); tree solver only: W .. mm_pass
-  struct Geo { int W = 0, L = 0, lean = 0, rows = 0, h_lds = 0, g_lds = 0, rec_lds = 0, flat_lds = 0, line_lds = 0, mm_pass = 0, ncl = 0, pairs = 0, ytop_lds = 0;
+  struct Geo { int W = 0, L = 0, lean = 0, rows = 0, h_lds = 0, g_lds = 0, rec_lds = 0, flat_lds = 0, line_lds = 0, mm_pass = 0, ncl = 0;
                size_t lds = 0; long wgs = 0; int resident = 0, rounds = 0; double model_ns = 0.0; } geo;
   int32_t *obs_rows = nullptr, *state_rows = nullptr, *iota_idx = nullptr, *vm_row = nullptr, *va_row = nullptr;
   int32_t *obs_xptr = nullptr, *obs_xrow = nullptr;
@@ -143,48 +143,31 @@ static int settle_tree_geometry(mapdn_handle* h, int Bp, int n_cu) {
   // slots are resident, so that several workgroups share a CU.
   // The kernel peels the first rows of its full sweeps (their G — and h, when h is not in LDS — stay in registers): a schedule
   // shorter than that is rebuilt with idle rows appended; one that needs no peeled rows (G in LDS) is left alone.
-  // Chain-pair fusion (plan.hpp): the schedule is first built with pairs; it is kept when the layout can run it — h LDS-resident
-  // (the x-propagation backward sweep) and the mismatch pass on (the mismatch-only sweep form has no pair step) — else rebuilt without.
-  const int f_pairs = knob_tri(c.nr_pairs, "MAPDN_NR_PAIRS"), f_mm = knob_tri(c.nr_mm_pass, "MAPDN_NR_MM_PASS");
   auto settle = [&](int W, int L, int lean, Schedule& S, mapdn_handle::Geo& g) -> int {   // 0 ok, 1 does not fit / not compiled, <0 error
     const int Wt = W * (64 / L);
-    for (int with_pairs = (f_pairs != 2 && !lean && f_mm != 2 && f_h != 2) ? 1 : 0; with_pairs >= 0; --with_pairs) {
     int min_rows = 0;
-    bool fits = true;
     for (int pass = 0; pass < 4; ++pass) {
-      build_schedule(P, Wt, S, nr_min_cslots(W, L), 64 / L, min_rows, with_pairs != 0);
+      build_schedule(P, Wt, S, nr_min_cslots(W, L), 64 / L, min_rows);
       if (S.n_cslots > 1023 || S.n_xslots > 1023) { h->err = "NR schedule needs more than 1023 LDS slots"; return MAPDN_E_INVALID; }
       g.ncl = (int)S.clist.size();
       if (g.ncl > 4095) { h->err = "NR schedule: more than 4095 overflow children (junctions with > 3 non-chain children)"; return MAPDN_E_INVALID; }
       if ((long)S.R * Wt > 0xffff) { h->err = "NR schedule has more than 65535 steps"; return MAPDN_E_INVALID; }
       const int R_ = S.R;
-      const int np = with_pairs ? S.pairs : 0;
-      g.ytop_lds = 0;
       auto lds_for = [&](int hl, int gl, int ll, int rl, int fl) {
-        return nr_lds_bytes(W, L, P.n, S.n_cslots, S.n_xslots, g.ncl, hl, gl, ll ? P.n_line : 0, rl ? R_ : 0, fl ? R_ : 0, np, g.ytop_lds); };
+        return nr_lds_bytes(W, L, P.n, S.n_cslots, S.n_xslots, g.ncl, hl, gl, ll ? P.n_line : 0, rl ? R_ : 0, fl ? R_ : 0); };
       g.h_lds = tri(f_h, !lean && lds_for(1, 0, 0, 0, 0) <= LDS_MAX);
-      // chain pairs: the top nodes' Y constants are read inside their row (the step records are prefetched two rows ahead, also from
-      // global memory): resident ahead of the records.  And no flat-start tables: a handle with pairs starts with a full sweep.
-      if (np && g.h_lds) { g.ytop_lds = 1; if (lds_for(1, 0, 0, 0, 0) > LDS_MAX) g.ytop_lds = 0; }
       g.rec_lds = tri(f_rec, !lean && lds_for(g.h_lds, 0, 0, 1, 0) <= LDS_MAX);
-      g.flat_lds = np ? 0 : tri(f_flat, !lean && lds_for(g.h_lds, 0, 0, g.rec_lds, 1) <= LDS_MAX);
+      g.flat_lds = tri(f_flat, !lean && lds_for(g.h_lds, 0, 0, g.rec_lds, 1) <= LDS_MAX);
       g.line_lds = (tri(f_line, !lean && P.n_line > 0 && lds_for(g.h_lds, 0, 1, g.rec_lds, g.flat_lds) <= LDS_MAX) && P.n_line > 0) ? 1 : 0;
       g.g_lds = (tri(f_g, !lean && g.h_lds && lds_for(1, 1, g.line_lds, g.rec_lds, g.flat_lds) <= LDS_MAX) && g.h_lds) ? 1 : 0;
       g.lds = lds_for(g.h_lds, g.g_lds, g.line_lds, g.rec_lds, g.flat_lds);
-      g.pairs = np;
-      if (g.lds > LDS_MAX) { fits = false; break; }
-      const int need = (np || g.g_lds) ? 0 : (g.h_lds ? NR_G_REG_ROWS : NR_HG_REG_ROWS);   // (the pair bodies peel no rows)
+      if (g.lds > LDS_MAX) return 1;
+      const int need = g.g_lds ? 0 : (g.h_lds ? NR_G_REG_ROWS : NR_HG_REG_ROWS);
       if (R_ >= need) { min_rows = -1; break; }
       min_rows = need;
     }
-    if (with_pairs && (!fits || !g.h_lds || S.pairs == 0 || !nr_geometry_compiled(W, L, g.h_lds, g.g_lds, g.rec_lds, g.flat_lds, 1))) continue;   // this layout cannot
-                                                              // run pairs, the feeder has none, or no pair body is compiled for it: plain schedule
-    if (!fits) return 1;
     if (min_rows >= 0) { h->err = "NR schedule: could not settle the number of peeled rows"; return MAPDN_E_INVALID; }
-    break;
-    }
-    if (f_pairs == 1 && g.pairs == 0) return 1;   // pinned on: only layouts that run the chain-pair schedule are candidates
-    int compiled = nr_geometry_compiled(W, L, g.h_lds, g.g_lds, g.rec_lds, g.flat_lds, g.pairs);
+    const int compiled = nr_geometry_compiled(W, L, g.h_lds, g.g_lds, g.rec_lds, g.flat_lds);
     if (!compiled) return 1;
     g.W = W; g.L = L; g.lean = lean; g.rows = S.R;
     g.wgs = Bp / L;
@@ -223,10 +206,6 @@ static int settle_tree_geometry(mapdn_handle* h, int Bp, int n_cu) {
     if (r == 0) { best = g; bestS = std::move(S); have = true; }
     else if (g.lds > LDS_MAX) { h->err = "NR schedule needs more LDS than one CU has (160 KB); use fewer envs per workgroup (nr_lanes / MAPDN_NR_LANES) or fewer waves"; return MAPDN_E_INVALID; }
   }
-  if (!have && f_pairs == 1) {
-    h->err = "nr_pairs = 1 (MAPDN_NR_PAIRS): no compiled layout runs the chain-pair schedule on this feeder (it needs the h factors in LDS, the "
-             "mismatch pass, a pair body for the (waves, lanes) pair — csrc/nr_inst_list.hpp — and a feeder with chains)";
-    return MAPDN_E_INVALID; }
   if (!have) {
     h->err = (W || L) ? "this (nr_waves, nr_lanes) combination is not compiled in or does not fit the 160 KB LDS of a CU (csrc/nr_inst_list.hpp)"
                       : "no compiled k_nr_tree geometry fits this network into the 160 KB LDS of a CU";
@@ -234,12 +213,11 @@ static int settle_tree_geometry(mapdn_handle* h, int Bp, int n_cu) {
   if (forced) best.model_ns = 0.0;
   const int mm = knob_tri(c.nr_mm_pass, "MAPDN_NR_MM_PASS");
   best.mm_pass = (best.h_lds && mm != 2) ? 1 : 0;    // the pass needs the h array in LDS
-  if (best.pairs && !best.mm_pass) { h->err = "internal: chain-pair schedule without the mismatch pass"; return MAPDN_E_INVALID; }
   h->geo = best; h->sched = std::move(bestS); h->lds_bytes = best.lds;
   if (knob_int(c.debug_geometry, "MAPDN_DEBUG_GEOMETRY"))
-    fprintf(stderr, "[mapdn] k_nr_tree geometry: W %d L %d lean %d rows %d (fused chain pairs %d) cslots %d | LDS: h %d rec %d flat %d line %d G %d = %zu B | "
+    fprintf(stderr, "[mapdn] k_nr_tree geometry: W %d L %d lean %d rows %d cslots %d | LDS: h %d rec %d flat %d line %d G %d = %zu B | "
                     "%ld workgroups, %d per CU, %d round(s), model %.1f us\n",
-            best.W, best.L, best.lean, best.rows, best.pairs, h->sched.n_cslots, best.h_lds, best.rec_lds, best.flat_lds, best.line_lds, best.g_lds,
+            best.W, best.L, best.lean, best.rows, h->sched.n_cslots, best.h_lds, best.rec_lds, best.flat_lds, best.line_lds, best.g_lds,
             best.lds, best.wgs, best.resident, best.rounds, best.model_ns * 1e-3);
   return MAPDN_OK;
 }
@@ -539,7 +517,7 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   {
     // the attribute is per kernel function, not per handle: always raise it to the full 160 KB so that
     // handles with different LDS needs can share an instantiation
-    const int lr = nr_set_lds_limit(G_.W, G_.L, G_.h_lds, G_.g_lds, G_.rec_lds, G_.flat_lds, 160 * 1024, G_.pairs);
+    const int lr = nr_set_lds_limit(G_.W, G_.L, G_.h_lds, G_.g_lds, G_.rec_lds, G_.flat_lds, 160 * 1024);
     if (lr == -2) { h->err = "this (nr_waves, nr_lanes) combination is not compiled in (csrc/nr_inst_list.hpp)"; return MAPDN_E_INVALID; }
     if (lr != 0) { (void)hipGetLastError(); h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return MAPDN_E_HIP; }
   }
@@ -549,11 +527,9 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
   UP(mm_recs, h->sched.mm_recs); d.mm_recs_bytes = (uint32_t)(h->sched.mm_recs.size() * sizeof(StepRec)); d.mm_np = h->sched.mm_np;
   d.nr_mm_pass = G_.mm_pass;   // the predicted-final mismatch evaluation as a barrier-free pass over all nodes instead of a tree sweep
   UP(flat, h->sched.flat); d.flat_bytes = (uint32_t)(h->sched.flat.size() * sizeof(double));
-  d.nr_pairs = G_.pairs; d.nr_nbp = G_.pairs ? NBP_PAIRS : NBP; d.nr_ytop_lds = G_.ytop_lds;
-  UP(ytop, h->sched.ytop); d.ytop_bytes = (uint32_t)(h->sched.ytop.size() * sizeof(double));
   {  // NR scratch: factor blocks (one per node) | 2 x Sbus (one entry per node) | Vout
     const size_t nblk = (size_t)P.n + 2;           // Sbus by node position (+ slack, + the trash node of idle steps: stays 0)
-    const size_t fb_rows = (h_lds && g_lds) ? 0 : (size_t)(P.n + 2) * d.nr_nbp;   // pair rows of Bp x 16 bytes: one block per node (+ slack, trash)
+    const size_t fb_rows = (h_lds && g_lds) ? 0 : (size_t)(P.n + 2) * NBP;   // pair rows of Bp x 16 bytes: one block per node (+ slack, trash)
     std::vector<int32_t> sbi(P.n);
     for (int k = 0; k < P.n; ++k) sbi[k] = k;
     rc = alloc_nrbuf(fb_rows, nblk, sbi); if (rc) return rc;
@@ -894,7 +870,7 @@ int mapdn_get_nr_geometry(const mapdn_handle* h, int32_t* out) {
                              knob_tri(h->cfg.fuse_inject, "MAPDN_FUSE_INJECT") != 2;
   const int32_t v[20] = {h->solver, g.W, g.L, g.lean, g.rows, g.h_lds, g.g_lds, g.rec_lds, g.flat_lds, g.line_lds, g.mm_pass,
                          (int32_t)h->lds_bytes, (int32_t)g.wgs, g.resident, g.rounds, (int32_t)std::min(g.model_ns, 2.0e9),
-                         (h->host_only ? fuse_possible : h->fuse_inject) ? 1 : 0, (int32_t)h->plan.fused_obus.size(), h->plan.nb, g.pairs};
+                         (h->host_only ? fuse_possible : h->fuse_inject) ? 1 : 0, (int32_t)h->plan.fused_obus.size(), h->plan.nb, 0};
   std::memcpy(out, v, sizeof(v));
   if (h->solver == 1) out[2] = h->sp_lanes;
   return MAPDN_OK;
@@ -911,22 +887,6 @@ int mapdn_get_flat_factors(const mapdn_handle* h, double* factors, int32_t* bus_
     if (T.flags & S_LIVE) std::memcpy(factors + (size_t)(T.kp & 0xffffu) * FLAT_N, &S.flat[(size_t)r * FLAT_N], FLAT_N * sizeof(double));
   }
   if (bus_of_pos) std::memcpy(bus_of_pos, h->plan.bus_of_pos.data(), (size_t)(n + 1) * sizeof(int32_t));
-  return MAPDN_OK;
-}
-
-int mapdn_get_pair_schedule(const mapdn_handle* h, int32_t W, int32_t* dims, int32_t* rows_bottom, int32_t* rows_top, double* flat, double* flat2) {
-  if (!h || !dims || W < 1 || W > 64) return MAPDN_E_INVALID;
-  if (!h->plan.radial) return MAPDN_E_TOPOLOGY;
-  Schedule S;
-  build_schedule(h->plan, W, S, 0, 1, 0, true);
-  dims[0] = S.R; dims[1] = S.pairs;
-  for (size_t i = 0; i < S.steps.size(); ++i) {
-    const bool live = (S.steps[i].flags & S_LIVE) != 0, pair = (S.steps[i].flags & S_PAIR) != 0;
-    if (rows_bottom) rows_bottom[i] = live ? (int32_t)(S.steps[i].kp & 0xffffu) : -1;
-    if (rows_top) rows_top[i] = (live && pair) ? (int32_t)(S.steps2[i].kp & 0xffffu) : -1;
-  }
-  if (flat) std::memcpy(flat, S.flat.data(), S.flat.size() * sizeof(double));
-  if (flat2) std::memcpy(flat2, S.flat2.data(), S.flat2.size() * sizeof(double));
   return MAPDN_OK;
 }
 

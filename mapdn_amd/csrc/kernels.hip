@@ -618,23 +618,23 @@ void launch_inject(const Dev& d, int mode, const void* actions, int dtype, const
 }
 // k_nr_tree instantiations: tables exported by the parts of nr_inst.hip (nr_inst_list.hpp).  RES is the residency of the step
 // records / flat-start constants as a compile-time fact (1 both, 2 neither, 3 records only); 0 = the generic body.
-static const NrInst* nr_find(int W, int L, bool hl, bool gl, int res, int pairs) {
+static const NrInst* nr_find(int W, int L, bool hl, bool gl, int res) {
   const NrInst* tabs[NR_INST_PARTS] = {nr_insts_0, nr_insts_1, nr_insts_2, nr_insts_3};
   const int cnt[NR_INST_PARTS] = {nr_n_insts_0, nr_n_insts_1, nr_n_insts_2, nr_n_insts_3};
   for (int p = 0; p < NR_INST_PARTS; ++p)
     for (int i = 0; i < cnt[p]; ++i) {
       const NrInst& I = tabs[p][i];
-      if (I.W == W && I.L == L && (I.HL != 0) == hl && (I.GL != 0) == gl && I.RES == res && (I.PAIRS != 0) == (pairs != 0)) return &I;
+      if (I.W == W && I.L == L && (I.HL != 0) == hl && (I.GL != 0) == gl && I.RES == res) return &I;
     }
   return nullptr;
 }
 static int nr_res_of(int rec_lds, int flat_lds) { return (rec_lds && flat_lds) ? 1 : (!rec_lds && !flat_lds) ? 2 : (rec_lds && !flat_lds) ? 3 : 0; }
 // the instantiation a handle with this geometry / residency runs: the specialised one when compiled in, else the generic body
-static const NrInst* nr_pick(int W, int L, int h_lds, int g_lds, int rec_lds, int flat_lds, int pairs) {
+static const NrInst* nr_pick(int W, int L, int h_lds, int g_lds, int rec_lds, int flat_lds) {
   const bool hl = h_lds != 0, gl = hl && g_lds != 0;
   const int res = nr_res_of(rec_lds, flat_lds);
-  const NrInst* I = res ? nr_find(W, L, hl, gl, res, pairs) : nullptr;
-  return I ? I : nr_find(W, L, hl, gl, 0, pairs);
+  const NrInst* I = res ? nr_find(W, L, hl, gl, res) : nullptr;
+  return I ? I : nr_find(W, L, hl, gl, 0);
 }
 #ifdef MAPDN_NR_STAMPS
 int nr_debug_stamps_0(unsigned long long*, int); int nr_debug_stamps_1(unsigned long long*, int);
@@ -652,8 +652,8 @@ void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* in
   if (d.dense) { launch_nr_dense(d, mode, reward, term, info, st); return; }
   if (d.sparse) { launch_nr_sparse(d, mode, reward, term, info, st); return; }
   const size_t lds = nr_lds_bytes(d.nr_waves, d.nr_lanes, d.n, d.nr_cslots, d.nr_xslots, d.nr_nclist, d.nr_h_lds, d.nr_g_lds,
-                                  d.nr_line_lds ? d.n_line : 0, d.nr_rec_lds ? d.nr_rows : 0, d.nr_flat_lds ? d.nr_rows : 0, d.nr_pairs, d.nr_ytop_lds);
-  const NrInst* I = nr_pick(d.nr_waves, d.nr_lanes, d.nr_h_lds, d.nr_g_lds, d.nr_rec_lds, d.nr_flat_lds, d.nr_pairs);
+                                  d.nr_line_lds ? d.n_line : 0, d.nr_rec_lds ? d.nr_rows : 0, d.nr_flat_lds ? d.nr_rows : 0);
+  const NrInst* I = nr_pick(d.nr_waves, d.nr_lanes, d.nr_h_lds, d.nr_g_lds, d.nr_rec_lds, d.nr_flat_lds);
   if (!I) return;                                   // (mapdn_create refuses such a geometry: nr_set_lds_limit)
 #ifdef MAPDN_NR_STAMPS
   { const NrInst* tabs[NR_INST_PARTS] = {nr_insts_0, nr_insts_1, nr_insts_2, nr_insts_3};
@@ -666,15 +666,15 @@ void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* in
   (void)hipLaunchKernel(I->fn, dim3(d.Bp / d.nr_lanes), dim3(64 * d.nr_waves), args, lds, st);
 }
 // raises the dynamic-LDS limit of the instantiation this geometry runs; -2: the geometry is not compiled in
-int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds, size_t bytes, int pairs) {
-  const NrInst* I = nr_pick(waves, lanes, h_lds, g_lds, rec_lds, flat_lds, pairs);
+int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds, size_t bytes) {
+  const NrInst* I = nr_pick(waves, lanes, h_lds, g_lds, rec_lds, flat_lds);
   if (!I) return -2;
   return hipFuncSetAttribute(I->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
 }
 // 1 when some instantiation serves (waves, lanes) at all (host-side check, no device call)
 // ... and 2 when that instantiation is a specialised one (residency known at compile time: ~6 % faster than the generic body)
-int nr_geometry_compiled(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds, int pairs) {
-  const NrInst* I = nr_pick(waves, lanes, h_lds, g_lds, rec_lds, flat_lds, pairs);
+int nr_geometry_compiled(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds) {
+  const NrInst* I = nr_pick(waves, lanes, h_lds, g_lds, rec_lds, flat_lds);
   return I ? (I->RES ? 2 : 1) : 0;
 }
 void launch_reset_begin(const Dev& d, const int64_t* start_rows, int first_try, hipStream_t st) {

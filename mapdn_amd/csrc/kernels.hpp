@@ -20,8 +20,7 @@ enum { STREAM_PV = 0, STREAM_LOAD_P = 1, STREAM_LOAD_Q = 2, STREAM_ACTION = 3, S
 //                                two buffers, flipped by the host after every step (k_advance fills the next one)
 //   Vout           [n+1][4] rows of Bp doubles   per position (n == slack): e f |V| angle — the solution (k_nr_tree)
 // Voltages and everything that crosses workers live in LDS during the solve.
-enum { NB_G01 = 0, NB_G23, NB_H, NBP, NB_K01 = NBP, NB_K23, NBP_PAIRS };   // NB_K*: G_kb of the top node of a fused pair (its G_kp uses NB_G*); blocks have
-                                                                          // NBP pair rows, NBP_PAIRS in handles with fused pairs (Dev::nr_nbp)
+enum { NB_G01 = 0, NB_G23, NB_H, NBP };
 enum { VO_E = 0, VO_F, VO_VM, VO_VA, VOF };
 
 // Everything a kernel needs, passed by value (kernarg segment -> scalar loads).
@@ -70,8 +69,6 @@ struct Dev {
   int32_t nr_waves, nr_lanes, nr_rows, nr_cslots, nr_xslots, nr_nclist, nr_h_lds, nr_g_lds, nr_line_lds, nr_rec_lds, nr_flat_lds;
   const StepRec* sched; uint32_t sched_bytes; const int32_t* clist;
   const double* flat; uint32_t flat_bytes;   // Schedule::flat, [Wt][R][FLAT_N]
-  // chain-pair fusion (plan.hpp Schedule::pairs; only in layouts with nr_h_lds && nr_mm_pass): second record / flat-start constants per step
-  int32_t nr_pairs, nr_nbp, nr_ytop_lds; const double* ytop; uint32_t ytop_bytes;   // nr_nbp: pair rows per factor block; ytop: Schedule::ytop
   // mismatch pass (k_nr_tree): per (worker, turn) a record with the node, its parent, its first three children in canonical
   // order, its Sbus entry and its Y constants (Schedule::mm_recs); further children of a junction from mm_ptr / mm_child
   const int32_t *mm_ptr, *mm_child; int32_t nr_mm_pass, mm_np;
@@ -111,8 +108,8 @@ void launch_inject_sgen(const Dev& d, int mode, const void* actions, int dtype, 
 // fused_actions != nullptr (MODE_STEP only): k_nr_tree's prologue performs the PV-bus injection itself (no k_inject_sgen launch)
 void launch_nr(const Dev& d, int mode, double* reward, uint8_t* term, double* info, hipStream_t st,
                const void* fused_actions = nullptr, int fused_dtype = 0);
-int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds, size_t bytes, int pairs = 0);   // -2: geometry not instantiated
-int nr_geometry_compiled(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds, int pairs = 0);
+int nr_set_lds_limit(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds, size_t bytes);   // -2: geometry not instantiated
+int nr_geometry_compiled(int waves, int lanes, int h_lds, int g_lds, int rec_lds, int flat_lds);
 // dynamic LDS of k_nr_tree (W waves, L envs per workgroup => Wt = W*64/L workers), in pair rows of L x 16 bytes:
 // node voltages (n+2: nodes, slack, trash), h (n+2) and G (2(n+2)) when resident, contribution slots (4 rows each),
 // x slots (1 row each); then verdict bytes, step-size partials (64*W doubles), overflow child list (padded to
@@ -121,15 +118,12 @@ __host__ __device__ static inline size_t nr_line_bytes(int n_line) { return ((si
 // The epilogue's partial sums (10 x 64*W doubles) re-use the contribution slots, so cslots >= nr_min_cslots(W, L).
 static inline int nr_min_cslots(int W, int L) { return (10 * 64 * W + 8 * L - 1) / (8 * L); }
 // rec_rows / flat_rows: R when the step records / flat-start constants of all Wt workers are staged in LDS, else 0
-// pairs != 0 (chain-pair fusion): G in LDS takes two more planes (G_kb of the top nodes); ytop_lds: the Y constants of the top nodes
-// by node ((n + 2) x 64 bytes) are resident
 static inline size_t nr_lds_bytes(int W, int L, int n, int cslots, int xslots, int nclist, int h_lds, int g_lds, int n_line_lds,
-                                  int rec_rows, int flat_rows, int pairs = 0, int ytop_lds = 0) {
-  const size_t rows = (size_t)(n + 2) * (1 + (h_lds ? 1 : 0) + (g_lds ? (pairs ? 4 : 2) : 0)) + (size_t)cslots * 4 + (size_t)xslots;
+                                  int rec_rows, int flat_rows) {
+  const size_t rows = (size_t)(n + 2) * (1 + (h_lds ? 1 : 0) + (g_lds ? 2 : 0)) + (size_t)cslots * 4 + (size_t)xslots;
   const size_t Wt = (size_t)W * (64 / L);
   return rows * (size_t)L * 16 + (size_t)W * 64 + (size_t)64 * W * sizeof(double) + (size_t)((nclist + 3) & ~3) * sizeof(int32_t) +
-         nr_line_bytes(n_line_lds) + Wt * rec_rows * sizeof(StepRec) + Wt * flat_rows * FLAT_N * sizeof(double) +
-         ((pairs && ytop_lds) ? (size_t)(n + 2) * 64 : 0);
+         nr_line_bytes(n_line_lds) + Wt * rec_rows * sizeof(StepRec) + Wt * flat_rows * FLAT_N * sizeof(double);
 }
 // general sparse kernel (sparse.hip): L envs per one-wave workgroup; prepare returns -2 for an L that is not instantiated
 size_t nr_sparse_lds_bytes(int n, int n_blocks, int L);

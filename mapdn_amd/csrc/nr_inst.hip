@@ -11,10 +11,9 @@ namespace mapdn {
 
 #define NR_CAT_(a, b) a##b
 #define NR_CAT(a, b) NR_CAT_(a, b)
-#define NR_ENTRY(w, l, hl, gl, res) {w, l, hl, gl, res, 0, (const void*)k_nr_tree<w, l, hl, gl, res, false>},
-#define NR_ENTRY_P(w, l, hl, gl, res) {w, l, hl, gl, res, 1, (const void*)k_nr_tree<w, l, hl, gl, res, true>},
+#define NR_ENTRY(w, l, hl, gl, res) {w, l, hl, gl, res, (const void*)k_nr_tree<w, l, hl, gl, res>},
 
-extern const NrInst NR_CAT(nr_insts_, NR_INST_PART)[] = { NR_CAT(NR_INSTS_, NR_INST_PART)(NR_ENTRY, NR_ENTRY_P) };
+extern const NrInst NR_CAT(nr_insts_, NR_INST_PART)[] = { NR_CAT(NR_INSTS_, NR_INST_PART)(NR_ENTRY) };
 extern const int NR_CAT(nr_n_insts_, NR_INST_PART) = (int)(sizeof(NR_CAT(nr_insts_, NR_INST_PART)) / sizeof(NrInst));
 
 #ifdef MAPDN_NR_STAMPS

@@ -8,33 +8,28 @@
 // A geometry that is not in the list is refused at mapdn_create ("not compiled in"), never silently replaced.
 #pragma once
 
-// P(...) entries: the chain-pair bodies (PAIRS = true; h LDS-resident; no flat-start tables: RES is 3 = records in LDS, 2 = not, 0 generic)
 // part 0: the 141-bus class (48 <= n < 200), fat layouts: 16 workers on four waves
-#define NR_INSTS_0(X, P) \
-  X(4, 16, true, false, 1) X(4, 16, true, false, 3) X(4, 16, true, false, 0) X(4, 16, true, true, 0) X(4, 16, false, false, 0) \
-  P(4, 16, true, false, 3) P(4, 16, true, false, 0) P(4, 16, true, true, 0)
+#define NR_INSTS_0(X) \
+  X(4, 16, true, false, 1) X(4, 16, true, false, 3) X(4, 16, true, false, 0) X(4, 16, true, true, 0) X(4, 16, false, false, 0)
 // part 1: small feeders (n < 48: one wave) and the lean layout of the 141-bus class
-#define NR_INSTS_1(X, P) \
+#define NR_INSTS_1(X) \
   X(1, 16, true, true, 1) X(1, 16, true, true, 0) X(1, 16, true, false, 0) X(1, 16, false, false, 0) \
-  X(2, 16, false, false, 2) X(2, 16, false, false, 0) X(2, 16, true, false, 0) X(2, 16, true, true, 0) \
-  P(1, 16, true, true, 3) P(1, 16, true, true, 0) P(1, 16, true, false, 0) P(2, 16, true, false, 0) P(2, 16, true, true, 0)
+  X(2, 16, false, false, 2) X(2, 16, false, false, 0) X(2, 16, true, false, 0) X(2, 16, true, true, 0)
 // part 2: the 322-bus class: 8 envs per workgroup (32 workers), 16 beyond one round of workgroups
-#define NR_INSTS_2(X, P) \
+#define NR_INSTS_2(X) \
   X(4, 8, true, false, 3) X(4, 8, true, false, 2) X(4, 8, true, false, 0) X(4, 8, true, true, 0) X(4, 8, false, false, 0) \
-  X(4, 16, false, false, 2) \
-  P(4, 8, true, false, 3) P(4, 8, true, false, 2) P(4, 8, true, false, 0) P(4, 8, true, true, 0)
+  X(4, 16, false, false, 2)
 // part 3: further pairs a caller may force (tests: every geometry gives the same bits)
-#define NR_INSTS_3(X, P) \
+#define NR_INSTS_3(X) \
   X(1, 8, true, true, 0) X(1, 8, true, false, 0) X(1, 8, false, false, 0) \
   X(2, 8, true, true, 0) X(2, 8, true, false, 0) X(2, 8, false, false, 0) \
   X(1, 32, false, false, 0) X(1, 32, true, false, 0) X(1, 32, true, true, 0) \
   X(4, 4, true, false, 0) X(4, 4, true, true, 0) X(4, 4, false, false, 0) \
   X(2, 4, true, false, 0) X(2, 4, true, true, 0) X(2, 4, false, false, 0) \
-  X(1, 4, true, false, 0) X(1, 4, true, true, 0) \
-  P(1, 8, true, true, 0) P(2, 8, true, true, 0) P(2, 8, true, false, 0) P(4, 4, true, false, 0) P(4, 4, true, true, 0) P(2, 4, true, true, 0)
+  X(1, 4, true, false, 0) X(1, 4, true, true, 0)
 
 namespace mapdn {
-struct NrInst { int W, L, HL, GL, RES, PAIRS; const void* fn; };
+struct NrInst { int W, L, HL, GL, RES; const void* fn; };
 enum { NR_INST_PARTS = 4 };
 extern const NrInst nr_insts_0[]; extern const int nr_n_insts_0;
 extern const NrInst nr_insts_1[]; extern const int nr_n_insts_1;

@@ -56,9 +56,6 @@ namespace mapdn {
 //  1/det uses v_rcp_f64 + two Newton steps; the update rotates V by the small step angle
 //  (polynomial sin/cos, full sincos only when a lane diverges).  Children are summed in a canonical
 //  order, so results are bit-identical for every W and L.
-//  Chain-pair fusion (plan.hpp Schedule::pairs; layouts with h in LDS): a step may eliminate TWO nodes, b and its parent k whose only
-//  child is b.  k goes first — its pivot needs nothing from below, so its elimination runs in the shadow of the LDS reads of b's
-//  children — then b against the Schur-complement coupling to k's parent.  One row per pair: every fused pair shortens its chain.
 // =================================================================================================
 
 #ifdef MAPDN_NR_STAMPS
@@ -135,17 +132,14 @@ __device__ __forceinline__ void static_for_down(F&& f) {
   if constexpr (N > 0) { f(std::integral_constant<int, N - 1>{}); static_for_down<N - 1>(f); }
 }
 
-struct Rec { u32x4 ix; d2 ykk, ykp, ypk, cks, sb, sb2; };   // per-(worker,row) constants + the env's scheduled injection (sb2: of the top node of a pair)
-struct RecF { u32x4 ix; d2 s, i01, i23, ap, sb, sb2; }; // flat-start form: host-factorised constants (Schedule::flat)
+struct Rec { u32x4 ix; d2 ykk, ykp, ypk, cks, sb; };    // per-(worker,row) constants + the env's scheduled injection
+struct RecF { u32x4 ix; d2 s, i01, i23, ap, sb; };      // flat-start form: host-factorised constants (Schedule::flat)
 struct BwdF { d2 h, g01, g23; };                        // factors of one step when they come from global memory
 
 // HL / GL: the h / G factors live in LDS (when they fit) instead of global scratch.  RES: 1 = step records and flat-start
 // constants are LDS-resident (compile-time: the "fat" geometry), 2 = neither is (the "lean" one), 3 = the records are, the
 // flat-start constants are not (the 322-bus feeder: W = 4, L = 8), 0 = per handle (d.nr_*_lds)
-// PAIRS: the instantiation runs chain-pair schedules (HL only).  Its step bodies carry the pair algebra, so it keeps NO peeled rows
-// (every copy of a row is instruction-cache footprint): all G factors go through LDS or the factor blocks.  The others are the
-// round-4 bodies, untouched.
-template <int W, int L, bool HL, bool GL, int RES = 0, bool PAIRS = false>
+template <int W, int L, bool HL, bool GL, int RES = 0>
 __global__ void __launch_bounds__(64 * W)
 k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ terminated, double* __restrict__ info) {
   extern __shared__ d2 lds2[];
@@ -165,23 +159,17 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(d.nrbuf, 0, d.nrbuf_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(d.flat), 0, d.flat_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<StepRec*>(d.sched), 0, d.sched_bytes, 0x00020000);
-  // chain pairs: the Y constants of a pair's TOP node come from a table by NODE (Schedule::ytop: 64 bytes per node; the node numbers
-  // of a pair step are in its first record), LDS-resident when it fits
-  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(d.ytop), 0, d.ytop_bytes, 0x00020000);
-  static_assert(!PAIRS || HL, "chain pairs need the h factors in LDS");
-  constexpr bool pairsOn = PAIRS;               // (the host launches a PAIRS instantiation iff the handle's schedule has pairs)
   const unsigned pb = (unsigned)d.Bp * 16u;      // bytes per pair row (one d2 per env)
   constexpr unsigned TB = (unsigned)sizeof(StepRec);        // bytes per step record
   constexpr unsigned FB = (unsigned)FLAT_N * 8u;            // bytes per flat-start step
-  const unsigned bb = (unsigned)d.nr_nbp * pb;   // bytes per factor block
+  const unsigned bb = (unsigned)NBP * pb;        // bytes per factor block
   const unsigned voT = t * (unsigned)R * TB;     // this worker's records (same address for its L lanes)
   const unsigned voF = t * (unsigned)R * FB;     // this worker's flat-start steps
   // factor blocks are addressed by NODE (block k of env e at e*16 + k*bb, field offset on the scalar side): the idle steps of
   // all workers share the trash node's block, so a sweep moves n blocks per env, not workers x rows
   const unsigned voE = e * 16u;
   const unsigned sF_H = __builtin_amdgcn_readfirstlane(NB_H * pb), sF_G01 = __builtin_amdgcn_readfirstlane(NB_G01 * pb),
-                 sF_G23 = __builtin_amdgcn_readfirstlane(NB_G23 * pb), sF_K01 = __builtin_amdgcn_readfirstlane(NB_K01 * pb),
-                 sF_K23 = __builtin_amdgcn_readfirstlane(NB_K23 * pb);
+                 sF_G23 = __builtin_amdgcn_readfirstlane(NB_G23 * pb);
   const unsigned voS = d.sb_off + e * 16u;       // the injection Sbus, one (re, im) pair row per NODE (entry n + 1, the trash node idle steps work on, stays 0)
   // ---- fused PV-bus injection (step() of a handle without auto_reset; otherwise k_inject_sgen ran as a launch of its own).
   // _clip_reactive_power (voltage_control_env.py:568-572): q = a sqrt(s_max^2 - p^2) of the sgens of every PV bus of this workgroup's
@@ -300,8 +288,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   d2* sV = lds2 + el;                                        // sV[k*L] = (e, f)
   d2* sH = sV + (size_t)(n + 2) * L;                         // sH[k*L] = (h0, h1)
   d2* sG = sH + (HL ? (size_t)(n + 2) * L : 0);              // sG[(2k+j)*L] = (G0,G1), (G2,G3)
-  d2* sG2 = sG + (GL ? (size_t)2 * (n + 2) * L : 0);         // chain pairs with G in LDS: G_kb of a top node k (its G_kp sits in sG)
-  d2* cs = sG2 + ((GL && pairsOn) ? (size_t)2 * (n + 2) * L : 0);   // cs[(slot*4 + j)*L] = (S0,S1) (D0,D1) (D2,D3) (R0,R1)
+  d2* cs = sG + (GL ? (size_t)2 * (n + 2) * L : 0);          // cs[(slot*4 + j)*L] = (S0,S1) (D0,D1) (D2,D3) (R0,R1)
   d2* xs = cs + (size_t)d.nr_cslots * 4 * L;                 // xs[slot*L] = (x0, x1)
   uint8_t* s_ok = (uint8_t*)(xs - el + (size_t)d.nr_xslots * L);   // [Wt][L], Wt*L = 64*W
   double* s_dx = (double*)(s_ok + 64 * W) + el;              // step-size partials: s_dx[worker*L], 64*W doubles
@@ -313,7 +300,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // worker's 16 lanes read the same 16 bytes (LDS broadcast)
   char* s_rec = (char*)s_lines + (d.nr_line_lds ? nr_line_bytes(d.n_line) : 0);
   char* s_flat = s_rec + (d.nr_rec_lds ? (size_t)Wt * R * sizeof(StepRec) : 0);
-  char* s_ytop = s_flat + (d.nr_flat_lds ? (size_t)Wt * R * FB : 0);         // (chain pairs) Y constants by node, [n + 2][64 bytes], when d.nr_ytop_lds
   {  // LDS init: flat start (runpp init="auto": every bus at the slack set-point), ZERO slots, small tables
     const d2 v0 = {vroot, 0.0}, z2 = {0.0, 0.0};
     for (unsigned k = t; k < n + 2; k += Wt) sV[(size_t)k * L] = v0;
@@ -359,10 +345,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     };
     if (d.nr_rec_lds) stage(d.sched, s_rec, Wt * (unsigned)R * (unsigned)(sizeof(StepRec) / 16));
     if (d.nr_flat_lds) stage(d.flat, s_flat, Wt * (unsigned)R * (unsigned)(FLAT_N * 8 / 16));
-    if (pairsOn) {
-      if (d.nr_ytop_lds) stage(d.ytop, s_ytop, (n + 2u) * 4u);
-      if (t == 0) sH[(size_t)(n + 1) * L] = z2;   // the trash entry of the h / x array: what single steps write as "their top node's" h stays finite
-    }
   }
 #ifdef MAPDN_NR_STAMPS
   const bool stamp_on = blockIdx.x == 0 && threadIdx.x == 0;
@@ -398,12 +380,10 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   // instruction-cache footprint (its first execution in a launch is cold), which is what limits KR.
   // When h lives in global scratch too (!HL: the lean layouts, the 322-bus feeder at 16 envs per workgroup), the peeled rows keep
   // h AND G in registers (12 AGPRs per row) and there are NR_HG_REG_ROWS of them.
-  constexpr int KR = (GL || PAIRS) ? 0 : (HL ? NR_G_REG_ROWS : NR_HG_REG_ROWS);
+  constexpr int KR = GL ? 0 : (HL ? NR_G_REG_ROWS : NR_HG_REG_ROWS);
   constexpr bool RH = !HL;                         // the peeled rows' h is in registers as well
   uint32_t Ga[KR > 0 ? KR : 1][8];                 // AGPR-class values: written / read only by the two helpers below
   uint32_t Ha[(KR > 0 && RH) ? KR : 1][4];
-  constexpr bool PA = false;                       // (pairs in peeled rows were measured: 16 more AGPRs per row and nine copies of the pair
-  uint32_t Gk[1][16];                              //  algebra cost more than the rows they saved — PAIRS instantiations do not peel)
   auto a_put = [](double v, uint32_t& lo, uint32_t& hi) {
     asm("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(__double2loint(v)));
     asm("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(__double2hiint(v)));
@@ -414,7 +394,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
   auto a_define = [&]() {
     static_for<KR * 8>([&](auto ic) { constexpr int q = decltype(ic)::value; a_def1(Ga[q / 8][q % 8], ic); });
     if constexpr (RH) static_for<KR * 4>([&](auto ic) { constexpr int q = decltype(ic)::value; a_def1(Ha[q / 4][q % 4], std::integral_constant<int, 1000 + q>{}); });
-    if constexpr (PA) static_for<KR * 16>([&](auto ic) { constexpr int q = decltype(ic)::value; a_def1(Gk[q / 16][q % 16], std::integral_constant<int, 2000 + q>{}); });
   };
   auto a_get = [](uint32_t lo, uint32_t hi) -> double {
     int l, h;
@@ -445,17 +424,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       const unsigned st = row_s(row, TB);
       o.ix = bldu4(rsT, voT, st);
       o.ykk = bld2(rsT, voT + 16u, st); o.ykp = bld2(rsT, voT + 32u, st); o.ypk = bld2(rsT, voT + 48u, st); o.cks = bld2(rsT, voT + 64u, st);
-    }
-  };
-  // the Y constants of the top node of a pair step (by node; a single step asks for the trash node's: an idle step's harmless values)
-  const bool ytopL = d.nr_ytop_lds != 0;
-  auto load_top = [&](unsigned node, Rec& o) {
-    if (ytopL) {
-      const char* p = s_ytop + node * 64u;
-      o.ykk = *(const d2*)p; o.ykp = *(const d2*)(p + 16); o.ypk = *(const d2*)(p + 32); o.cks = *(const d2*)(p + 48);
-    } else {
-      const unsigned vo = node * 64u;
-      o.ykk = bld2(rsY, vo, 0u); o.ykp = bld2(rsY, vo + 16u, 0u); o.ypk = bld2(rsY, vo + 32u, 0u); o.cks = bld2(rsY, vo + 48u, 0u);
     }
   };
   auto load_recf = [&](int row, RecF& o) {
@@ -503,8 +471,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     constexpr int K = decltype(kind)::value;
     Rec Tq[3]; d2 vkq[3], vpq[3];
     load_rec(0, Tq[0]); load_rec(min(1, R - 1), Tq[1]);
-    { const unsigned kp = Tq[0].ix.w; vkq[0] = sV[(size_t)(kp & 0xffffu) * L]; vpq[0] = sV[(size_t)(kp >> 16) * L]; Tq[0].sb = load_sb(kp);
-      if (pairsOn) Tq[0].sb2 = load_sb(kp >> 16); }
+    { const unsigned kp = Tq[0].ix.w; vkq[0] = sV[(size_t)(kp & 0xffffu) * L]; vpq[0] = sV[(size_t)(kp >> 16) * L]; Tq[0].sb = load_sb(kp); }
     double pFp = 0.0, pFq = 0.0; bool pLive = false;       // deferred mismatch bookkeeping of the previous row
     // one row; u = ring position (compile-time), RS = the row number when it is a compile-time constant (peeled rows), else -1
     auto fwd_row = [&](auto uc, auto rsc, int r) {
@@ -528,18 +495,10 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
 #pragma unroll
           for (int i = 0; i < NP; ++i) g1[i] = c1[i * L];
         }
-        // chain pairs (wave-uniform): the top node's record, its parent's voltage and its injection
-        const bool pairU = PAIRS && (K == 0) && (flu & SU_PAIR_ANY) != 0u;
-        Rec T2; d2 vp2 = {0.0, 0.0};
-        if (pairU) {
-          load_top((fl & S_PAIR) ? (kp >> 16) : n + 1u, T2);
-          vp2 = sV[(size_t)((fl & S_PAIR) ? ((slots >> 10) & 0xffffu) : n) * L];   // the pair's parent p (single steps: any valid entry)
-        }
         {                                          // next row's operands (LDS) and the record two rows ahead (global)
           const unsigned kpn = Tq[(u + 1) % 3].ix.w;
           vkq[(u + 1) % 3] = sV[(size_t)(kpn & 0xffffu) * L]; vpq[(u + 1) % 3] = sV[(size_t)(kpn >> 16) * L];
           Tq[(u + 1) % 3].sb = load_sb(kpn);
-          if (pairsOn) Tq[(u + 1) % 3].sb2 = load_sb(kpn >> 16);   // the injection of the top node of a pair (requested for every step: same VMEM count)
           load_rec(min(r + 2, R - 1), Tq[(u + 2) % 3]);
         }
         SCHED_FENCE();
@@ -559,63 +518,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         if (flu & SU_SLACK_ANY) { aks_r = ek * T.cks.x + fk * T.cks.y; aks_i = fk * T.cks.x - ek * T.cks.y; }
         const double base_r = (akk_r + aks_r) + akp_r, base_i = (akk_i + aks_i) + akp_i;
         const double m = (fl & S_CARRY_IN) ? 1.0 : 0.0;    // register carry (same worker, previous row) masked by a 0/1 factor
-        // The coupling blocks of the step: U = J(b, parent), L = J(parent, b) — of the electrical parent for a single node,
-        //   [[Im A, Re A], [-Re A, Im A]] of A_kp / A_pk — and what a fused top node hands down / up (zero for a single node).
-        double u0 = akp_i, u1 = akp_r, u2 = -akp_r, u3 = akp_i, l0 = apk_i, l1 = apk_r, l2 = -apk_r, l3 = apk_i;
-        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0, w0 = 0.0, w1 = 0.0;      // J(b,k) G_kb, J(b,k) h_k: off b's pivot / right-hand side
-        double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, z0 = 0.0, z1 = 0.0;      // J(p,k) G_kp, J(p,k) h_k: the top node's own contribution to p
-        double oS0 = apk_r, oS1 = apk_i;                                        // the S term the parent receives
-        double hk0 = 0.0, hk1 = 0.0, P0 = 0.0, P1 = 0.0, P2 = 0.0, P3 = 0.0, B0 = 0.0, B1 = 0.0, B2 = 0.0, B3 = 0.0;   // h_k, G_kp, G_kb
-        unsigned kt = n + 1u;                                                   // the top node (single steps: the trash node)
-        if constexpr (K == 0 && PAIRS) {
-          if (pairU) {
-            // The top node k of a pair (b = this step's node, its only child; p = k's parent): every term of its pivot is its own,
-            //   S_k = A_kk + A_ks + A_kp + A_kb,  so it is eliminated here, beside the LDS reads of b's children.
-            const bool pr = (fl & S_PAIR) != 0;
-            const double gkk2 = T2.ykk.x, bkk2 = T2.ykk.y, gkp2 = T2.ykp.x, bkp2 = T2.ykp.y, gpk2 = T2.ypk.x, bpk2 = T2.ypk.y;
-            const double ek2 = ep, fk2 = fp, ep2 = vp2.x, fp2 = vp2.y;          // V_k is this step's "parent" voltage
-            const double tr2 = gkp2 * ep2 - bkp2 * fp2, ti2 = gkp2 * fp2 + bkp2 * ep2;
-            const double akp2_r = ek2 * tr2 + fk2 * ti2, akp2_i = fk2 * tr2 - ek2 * ti2;
-            const double ur2 = gpk2 * ek2 - bpk2 * fk2, ui2 = gpk2 * fk2 + bpk2 * ek2;
-            const double apk2_r = ep2 * ur2 + fp2 * ui2, apk2_i = fp2 * ur2 - ep2 * ui2;
-            const double v22 = ek2 * ek2 + fk2 * fk2;
-            const double akk2_r = v22 * gkk2, akk2_i = -v22 * bkk2;
-            const double aks2_r = ek2 * T2.cks.x + fk2 * T2.cks.y, aks2_i = fk2 * T2.cks.x - ek2 * T2.cks.y;
-            const double sr2 = ((akk2_r + aks2_r) + akp2_r) + apk_r, si2 = ((akk2_i + aks2_i) + akp2_i) + apk_i;   // A_kb = this step's A_pk
-            const double Fp2 = sr2 - T.sb2.x, Fq2 = si2 - T.sb2.y;
-            note_mismatch(Fp2, Fq2, pr);
-            const double E0 = -(si2 - akk2_i), E1 = sr2 + akk2_r, E2 = sr2 - akk2_r, E3 = si2 + akk2_i;
-            const double idet2 = rcp_nr(fma(E0, E3, -(E1 * E2)));
-            const double K0 = E3 * idet2, K1 = -E1 * idet2, K2 = -E2 * idet2, K3 = E0 * idet2;
-            const double hq0 = fma(K0, Fp2, K1 * Fq2), hq1 = fma(K2, Fp2, K3 * Fq2);
-            // G_kp = D_k^-1 J(k,p), G_kb = D_k^-1 J(k,b)
-            const double p0 = fma(K0, akp2_i, -(K1 * akp2_r)), p1 = fma(K0, akp2_r, K1 * akp2_i);
-            const double p2 = fma(K2, akp2_i, -(K3 * akp2_r)), p3 = fma(K2, akp2_r, K3 * akp2_i);
-            const double b0 = fma(K0, apk_i, -(K1 * apk_r)), b1 = fma(K0, apk_r, K1 * apk_i);
-            const double b2 = fma(K2, apk_i, -(K3 * apk_r)), b3 = fma(K2, apk_r, K3 * apk_i);
-            // down to b: J(b,k) = [[Im A_bk, Re A_bk], [-Re A_bk, Im A_bk]], A_bk = this step's A_kp
-            const double dq0 = fma(akp_i, b0, akp_r * b2), dq1 = fma(akp_i, b1, akp_r * b3);
-            const double dq2 = fma(akp_i, b2, -(akp_r * b0)), dq3 = fma(akp_i, b3, -(akp_r * b1));
-            const double dw0 = fma(akp_i, hq0, akp_r * hq1), dw1 = fma(akp_i, hq1, -(akp_r * hq0));
-            const double du0 = -fma(akp_i, p0, akp_r * p2), du1 = -fma(akp_i, p1, akp_r * p3);      // J'(b,p) = -J(b,k) G_kp
-            const double du2 = -fma(akp_i, p2, -(akp_r * p0)), du3 = -fma(akp_i, p3, -(akp_r * p1));
-            // up to p: J(p,k) from A_pk of the top node
-            const double dm0 = fma(apk2_i, p0, apk2_r * p2), dm1 = fma(apk2_i, p1, apk2_r * p3);
-            const double dm2 = fma(apk2_i, p2, -(apk2_r * p0)), dm3 = fma(apk2_i, p3, -(apk2_r * p1));
-            const double dz0 = fma(apk2_i, hq0, apk2_r * hq1), dz1 = fma(apk2_i, hq1, -(apk2_r * hq0));
-            const double dl0 = -fma(apk2_i, b0, apk2_r * b2), dl1 = -fma(apk2_i, b1, apk2_r * b3);  // J'(p,b) = -J(p,k) G_kb
-            const double dl2 = -fma(apk2_i, b2, -(apk2_r * b0)), dl3 = -fma(apk2_i, b3, -(apk2_r * b1));
-            // single steps of this wave keep their own blocks (selects, not arithmetic masks: their top-node values are meaningless)
-            u0 = pr ? du0 : u0; u1 = pr ? du1 : u1; u2 = pr ? du2 : u2; u3 = pr ? du3 : u3;
-            l0 = pr ? dl0 : l0; l1 = pr ? dl1 : l1; l2 = pr ? dl2 : l2; l3 = pr ? dl3 : l3;
-            q0 = pr ? dq0 : 0.0; q1 = pr ? dq1 : 0.0; q2 = pr ? dq2 : 0.0; q3 = pr ? dq3 : 0.0; w0 = pr ? dw0 : 0.0; w1 = pr ? dw1 : 0.0;
-            m0 = pr ? dm0 : 0.0; m1 = pr ? dm1 : 0.0; m2 = pr ? dm2 : 0.0; m3 = pr ? dm3 : 0.0; z0 = pr ? dz0 : 0.0; z1 = pr ? dz1 : 0.0;
-            oS0 = pr ? apk2_r : apk_r; oS1 = pr ? apk2_i : apk_i;
-            hk0 = pr ? hq0 : 0.0; hk1 = pr ? hq1 : 0.0;
-            P0 = p0; P1 = p1; P2 = p2; P3 = p3; B0 = b0; B1 = b1; B2 = b2; B3 = b3;
-            kt = pr ? (kp >> 16) : n + 1u;
-          }
-        }
         SCHED_FENCE();
         STAMP2(201 + 10 * K);
         // (3) the dependent chain: children (carry + LDS slots, canonical order) -> S, mismatch -> pivot -> factors -> contribution
@@ -657,42 +559,24 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
         const double Fp = sr - T.sb.x, Fq = si - T.sb.y;
         pFp = Fp; pFq = Fq; pLive = (fl & S_LIVE) != 0;
         if constexpr (K == 0) {
-          double h0, h1, G0, G1, G2, G3, s0, s1, s2, s3, t0, t1;
-          if constexpr (PAIRS) {
-            // (every product-sum is spelled out as one fma + one product: a single step must round alike whether or not a pair
-            //  shares its wave — which depends on the launch geometry)
-            const double D0 = (-(si - akk_i) - aD0) - q0, D1 = ((sr + akk_r) - aD1) - q1;
-            const double D2 = ((sr - akk_r) - aD2) - q2, D3 = ((si + akk_i) - aD3) - q3;
-            const double r0 = (Fp - aR0) - w0, r1 = (Fq - aR1) - w1;
-            const double idet = rcp_nr(fma(D0, D3, -(D1 * D2)));
-            const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
-            h0 = fma(I0, r0, I1 * r1); h1 = fma(I2, r0, I3 * r1);
-            // G = D^-1 U,  contribution to the parent: S (the parent's own A term), D = L G (+ the top node's), R = L h (+ the top node's)
-            G0 = fma(I0, u0, I1 * u2); G1 = fma(I0, u1, I1 * u3);
-            G2 = fma(I2, u0, I3 * u2); G3 = fma(I2, u1, I3 * u3);
-            s0 = fma(l0, G0, l1 * G2) + m0; s1 = fma(l0, G1, l1 * G3) + m1;
-            s2 = fma(l2, G0, l3 * G2) + m2; s3 = fma(l2, G1, l3 * G3) + m3;
-            t0 = fma(l0, h0, l1 * h1) + z0; t1 = fma(l2, h0, l3 * h1) + z1;
-          } else {
-            const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) - aD1;
-            const double D2 = (sr - akk_r) - aD2, D3 = (si + akk_i) - aD3;
-            const double r0 = Fp - aR0, r1 = Fq - aR1;
-            const double idet = rcp_nr(D0 * D3 - D1 * D2);
-            const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
-            h0 = I0 * r0 + I1 * r1; h1 = I2 * r0 + I3 * r1;
-            // U = J'(k,p) = [[Im A_kp, Re A_kp], [-Re A_kp, Im A_kp]],  L = J'(p,k) likewise from A_pk
-            G0 = I0 * akp_i - I1 * akp_r; G1 = I0 * akp_r + I1 * akp_i;
-            G2 = I2 * akp_i - I3 * akp_r; G3 = I2 * akp_r + I3 * akp_i;
-            s0 = apk_i * G0 + apk_r * G2; s1 = apk_i * G1 + apk_r * G3;
-            s2 = apk_i * G2 - apk_r * G0; s3 = apk_i * G3 - apk_r * G1;
-            t0 = apk_i * h0 + apk_r * h1; t1 = apk_i * h1 - apk_r * h0;
-          }
+          const double D0 = -(si - akk_i) - aD0, D1 = (sr + akk_r) - aD1;
+          const double D2 = (sr - akk_r) - aD2, D3 = (si + akk_i) - aD3;
+          const double r0 = Fp - aR0, r1 = Fq - aR1;
+          const double idet = rcp_nr(D0 * D3 - D1 * D2);
+          const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
+          const double h0 = I0 * r0 + I1 * r1, h1 = I2 * r0 + I3 * r1;
+          // U = J'(k,p) = [[Im A_kp, Re A_kp], [-Re A_kp, Im A_kp]],  L = J'(p,k) likewise from A_pk
+          const double G0 = I0 * akp_i - I1 * akp_r, G1 = I0 * akp_r + I1 * akp_i;
+          const double G2 = I2 * akp_i - I3 * akp_r, G3 = I2 * akp_r + I3 * akp_i;
+          const double s0 = apk_i * G0 + apk_r * G2, s1 = apk_i * G1 + apk_r * G3;
+          const double s2 = apk_i * G2 - apk_r * G0, s3 = apk_i * G3 - apk_r * G1;
+          const double t0 = apk_i * h0 + apk_r * h1, t1 = apk_i * h1 - apk_r * h0;
           // contribution to the parent: registers (consumed only if the next step has S_CARRY_IN) and the
           // LDS slot (TRASH unless S_SCRATCH_OUT; skipped when no worker of the wave has a real slot)
-          cS0 = oS0; cS1 = oS1; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
+          cS0 = apk_r; cS1 = apk_i; cD0 = s0; cD1 = s1; cD2 = s2; cD3 = s3; cR0 = t0; cR1 = t1;
           if (flu & SU_W_ANY) {
             d2* c = cs + (size_t)(slots & 1023u) * (4 * L);
-            c[0] = d2{oS0, oS1}; c[L] = d2{s0, s1}; c[2 * L] = d2{s2, s3}; c[3 * L] = d2{t0, t1};
+            c[0] = d2{apk_r, apk_i}; c[L] = d2{s0, s1}; c[2 * L] = d2{s2, s3}; c[3 * L] = d2{t0, t1};
           }
           SCHED_FENCE();                           // the factors leave after the contribution is on its way
           const unsigned k = kp & 0xffffu, voN = voE + k * bb;
@@ -704,22 +588,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
             a_put(G0, Ga[RS][0], Ga[RS][1]); a_put(G1, Ga[RS][2], Ga[RS][3]); a_put(G2, Ga[RS][4], Ga[RS][5]); a_put(G3, Ga[RS][6], Ga[RS][7]);
           }
           else { bst2(d2{G0, G1}, rs, voN, sF_G01); bst2(d2{G2, G3}, rs, voN, sF_G23); }
-          if constexpr (PAIRS) {
-            if (pairU) {                           // the top node's factors: h_k beside the others (single steps: 0 into the trash entry), G_kp / G_kb
-              sH[(size_t)kt * L] = d2{hk0, hk1};
-              if (GL) {
-                sG[(size_t)(2 * kt) * L] = d2{P0, P1}; sG[(size_t)(2 * kt + 1) * L] = d2{P2, P3};
-                sG2[(size_t)(2 * kt) * L] = d2{B0, B1}; sG2[(size_t)(2 * kt + 1) * L] = d2{B2, B3};
-              } else if constexpr (RS >= 0 && PA) {
-                a_put(P0, Gk[RS][0], Gk[RS][1]); a_put(P1, Gk[RS][2], Gk[RS][3]); a_put(P2, Gk[RS][4], Gk[RS][5]); a_put(P3, Gk[RS][6], Gk[RS][7]);
-                a_put(B0, Gk[RS][8], Gk[RS][9]); a_put(B1, Gk[RS][10], Gk[RS][11]); a_put(B2, Gk[RS][12], Gk[RS][13]); a_put(B3, Gk[RS][14], Gk[RS][15]);
-              } else {
-                const unsigned voK = voE + kt * bb;
-                bst2(d2{P0, P1}, rs, voK, sF_G01); bst2(d2{P2, P3}, rs, voK, sF_G23);
-                bst2(d2{B0, B1}, rs, voK, sF_K01); bst2(d2{B2, B3}, rs, voK, sF_K23);
-              }
-            }
-          }
         } else {
           cS0 = apk_r; cS1 = apk_i;
           if (flu & SU_W_ANY) cs[(size_t)(slots & 1023u) * (4 * L)] = d2{apk_r, apk_i};
@@ -849,10 +717,6 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     constexpr int SRC = decltype(src)::value;
     constexpr bool gG = (SRC == 1) && !GL;         // G comes from the factor blocks in global memory
     u32x4 ixq[4]; d2 g01q[4], g23q[4];
-    // chain pairs: G_kp / G_kb of the top node k of a pair step (x_k = h_k - G_kp x_p - G_kb x_b), from the LDS planes or k's factor
-    // block — the latter two rows ahead through the same static ring (wave-uniform: only rows with a pair).  (A handle with pairs
-    // never takes the flat-start form, SRC 0: its first iteration is a full sweep.)
-    d2 p01q[4], p23q[4], b01q[4], b23q[4];
     auto load_g = [&](int row, const u32x4& ixr, int slot) {
       if constexpr (SRC == 0) {
         if (flatL) { const char* p = flatT + (unsigned)row * FB; g01q[slot] = *(const d2*)(p + FL_G0 * 8); g23q[slot] = *(const d2*)(p + FL_G2 * 8); }
@@ -860,49 +724,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
       } else if constexpr (gG) {
         const unsigned voN = voE + (ixr.w & 0xffffu) * bb;
         g01q[slot] = bld2(rs, voN, sF_G01); g23q[slot] = bld2(rs, voN, sF_G23);
-        if (pairsOn && (uni(ixr.x) & SU_PAIR_ANY)) {
-          const unsigned voK = voE + ((ixr.x & S_PAIR) ? (ixr.w >> 16) : n + 1u) * bb;
-          p01q[slot] = bld2(rs, voK, sF_G01); p23q[slot] = bld2(rs, voK, sF_G23);
-          b01q[slot] = bld2(rs, voK, sF_K01); b23q[slot] = bld2(rs, voK, sF_K23);
-        }
       }
-    };
-    // one row of the x recurrence.  pk01 .. : the top node's factors when the wave holds a pair (else unused)
-    auto xrow = [&](const u32x4& ix, d2 g01, d2 g23, d2 pk01, d2 pk23, d2 bk01, d2 bk23) {
-      const uint32_t fl = ix.x, kp = ix.w;
-      const bool pairU = PAIRS && (uni(fl) & SU_PAIR_ANY) != 0u;
-      const bool pr = pairU && (fl & S_PAIR) != 0;
-      const unsigned k = kp & 0xffffu, p = pr ? ((ix.y >> 10) & 0xffffu) : (kp >> 16), kt = pr ? (kp >> 16) : n + 1u;
-      // (1) the parent's x (its h slot, already overwritten; the slack entry holds the 0 that elimination roots read), this node's
-      // h and G.  The parent's entry is read unconditionally, together with h (round 4): behind the SU_XR_ANY hint the read sat in a
-      // scalar branch of its own and its wait came before the other requests of the row were issued — one more exposed LDS round trip
-      // in a row that consists of three.
-      const d2 q = sH[(size_t)p * L];
-      const d2 hh = sH[(size_t)k * L];
-      d2 hk = {0.0, 0.0};
-      if (pairU) hk = sH[(size_t)kt * L];
-      if constexpr (SRC == 1 && GL) {
-        g01 = sG[(size_t)(2 * k) * L]; g23 = sG[(size_t)(2 * k + 1) * L];
-        if (pairU) { pk01 = sG[(size_t)(2 * kt) * L]; pk23 = sG[(size_t)(2 * kt + 1) * L]; bk01 = sG2[(size_t)(2 * kt) * L]; bk23 = sG2[(size_t)(2 * kt + 1) * L]; }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      STAMP2(240);
-      // (2) x_b = h_b - G_b x_parent  [, x_k = h_k - G_kp x_p - G_kb x_b ]
-      const bool cout = (fl & S_CARRY_OUT) != 0;
-      const double p0 = cout ? x0 : q.x, p1 = cout ? x1 : q.y;
-      double y0, y1;
-      if constexpr (PAIRS) { y0 = hh.x - fma(g01.x, p0, g01.y * p1); y1 = hh.y - fma(g23.x, p0, g23.y * p1); }
-      else { y0 = hh.x - (g01.x * p0 + g01.y * p1); y1 = hh.y - (g23.x * p0 + g23.y * p1); }
-      x0 = y0; x1 = y1;
-      sH[(size_t)k * L] = d2{y0, y1};              // (idle steps: the trash node)
-      if (pairU) {
-        const double xk0 = (hk.x - fma(pk01.x, p0, pk01.y * p1)) - fma(bk01.x, y0, bk01.y * y1);
-        const double xk1 = (hk.y - fma(pk23.x, p0, pk23.y * p1)) - fma(bk23.x, y0, bk23.y * y1);
-        sH[(size_t)kt * L] = pr ? d2{xk0, xk1} : d2{0.0, 0.0};    // (single steps of the wave: the trash entry stays finite)
-      }
-      STAMP2(242);
-      if (W > 1) lds_barrier();
-      STAMP(110 + SRC);
     };
     // rows below KP are peeled (straight-line code, G in registers: see Gs); their index words are fetched up front
     constexpr int KP = gG ? KR : 0;
@@ -915,24 +737,52 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (r < KP) break;
-        const u32x4 ix = ixq[u % 4];
+        const uint32_t fl = ixq[u % 4].x, kp = ixq[u % 4].w;
+        const unsigned k = kp & 0xffffu, p = kp >> 16;
+        // (1) the parent's x (its h slot, already overwritten; the slack entry holds the 0 that elimination roots read), this node's
+        // h and G.  The parent's entry is read unconditionally, together with h (round 4): behind the SU_XR_ANY hint the read sat in a
+        // scalar branch of its own and its wait came before the other requests of the row were issued — one more exposed LDS round trip
+        // in a row that consists of three.
+        const d2 q = sH[(size_t)p * L];
+        const d2 hh = sH[(size_t)k * L];
+        d2 g01, g23;
+        if constexpr (SRC == 1 && GL) { g01 = sG[(size_t)(2 * k) * L]; g23 = sG[(size_t)(2 * k + 1) * L]; }
         ixq[(u + 3) % 4] = load_ix(max(r - 3, KP));
         load_g(max(r - 2, KP), ixq[(u + 2) % 4], (u + 2) % 4);
-        xrow(ix, g01q[u % 4], g23q[u % 4], p01q[u % 4], p23q[u % 4], b01q[u % 4], b23q[u % 4]);
+        SCHED_FENCE();
+        STAMP2(240);
+        if constexpr (SRC == 0 || gG) { g01 = g01q[u % 4]; g23 = g23q[u % 4]; }
+        // (2) x_k = h_k - G_k x_parent
+        const bool cout = (fl & S_CARRY_OUT) != 0;
+        const double p0 = cout ? x0 : q.x, p1 = cout ? x1 : q.y;
+        const double y0 = hh.x - (g01.x * p0 + g01.y * p1);
+        const double y1 = hh.y - (g23.x * p0 + g23.y * p1);
+        x0 = y0; x1 = y1;
+        sH[(size_t)k * L] = d2{y0, y1};            // (idle steps: the trash node)
+        STAMP2(242);
+        if (W > 1) lds_barrier();
+        STAMP(110 + SRC);
         --r;
       }
     }
     static_for_down<KP>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      const d2 g01 = {a_get(Ga[i][0], Ga[i][1]), a_get(Ga[i][2], Ga[i][3])}, g23 = {a_get(Ga[i][4], Ga[i][5]), a_get(Ga[i][6], Ga[i][7])};
-      d2 pk01 = {0.0, 0.0}, pk23 = pk01, bk01 = pk01, bk23 = pk01;
-      if constexpr (PA) {
-        if (pairsOn && (uni(ixs[i].x) & SU_PAIR_ANY)) {
-          pk01 = d2{a_get(Gk[i][0], Gk[i][1]), a_get(Gk[i][2], Gk[i][3])}; pk23 = d2{a_get(Gk[i][4], Gk[i][5]), a_get(Gk[i][6], Gk[i][7])};
-          bk01 = d2{a_get(Gk[i][8], Gk[i][9]), a_get(Gk[i][10], Gk[i][11])}; bk23 = d2{a_get(Gk[i][12], Gk[i][13]), a_get(Gk[i][14], Gk[i][15])};
-        }
+      {
+        const uint32_t fl = ixs[i].x, kp = ixs[i].w;
+        const unsigned k = kp & 0xffffu, p = kp >> 16;
+        const d2 q = sH[(size_t)p * L];
+        const d2 hh = sH[(size_t)k * L];
+        SCHED_FENCE();
+        const bool cout = (fl & S_CARRY_OUT) != 0;
+        const double p0 = cout ? x0 : q.x, p1 = cout ? x1 : q.y;
+        const double G0 = a_get(Ga[i][0], Ga[i][1]), G1 = a_get(Ga[i][2], Ga[i][3]), G2 = a_get(Ga[i][4], Ga[i][5]), G3 = a_get(Ga[i][6], Ga[i][7]);
+        const double y0 = hh.x - (G0 * p0 + G1 * p1);
+        const double y1 = hh.y - (G2 * p0 + G3 * p1);
+        x0 = y0; x1 = y1;
+        sH[(size_t)k * L] = d2{y0, y1};
+        if (W > 1) lds_barrier();
+        STAMP(110 + SRC);
       }
-      xrow(ixs[i], g01, g23, pk01, pk23, bk01, bk23);
     });
     // (3) update of every node from its x, three nodes per pass (loads first)
     for (unsigned kb = t; kb < n; kb += (unsigned)UPN * Wt) {
@@ -1118,10 +968,7 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     allok = true; fmx = 0.0;
     cS0 = cS1 = cD0 = cD1 = cD2 = cD3 = cR0 = cR1 = 0.0;
     STAMP(10);
-    // (chain pairs: no flat-start form — the pair algebra lives in the full sweep only, whose first pass costs ~0.4 rows more than the
-    //  flat form would; the LDS its tables would take goes to the records and the net.line constants instead)
-    const bool flatF = first && !pairsOn;
-    if (flatF) { fwd_sweep_flat(); a_define(); }
+    if (first) { fwd_sweep_flat(); a_define(); }
     else if (light) { if (HL && d.nr_mm_pass) mismatch_pass(); else fwd_sweep(std::integral_constant<int, 1>{}); a_define(); }
     else fwd_sweep(std::integral_constant<int, 0>{});
     {                                            // AND of the workers' verdicts, per env: in the wave by lane exchanges, across
@@ -1154,8 +1001,8 @@ k_nr_tree(Dev d, int mode, double* __restrict__ reward, uint8_t* __restrict__ te
     x0 = x1 = 0.0;
     dxm = 0.0;
     STAMP(12);
-    if constexpr (HL) { if (flatF) bwd_xprop(std::integral_constant<int, 0>{}); else bwd_xprop(std::integral_constant<int, 1>{}); }
-    else { if (flatF) bwd_sweep(std::integral_constant<int, 0>{}); else bwd_sweep(std::integral_constant<int, 1>{}); }
+    if constexpr (HL) { if (first) bwd_xprop(std::integral_constant<int, 0>{}); else bwd_xprop(std::integral_constant<int, 1>{}); }
+    else { if (first) bwd_sweep(std::integral_constant<int, 0>{}); else bwd_sweep(std::integral_constant<int, 1>{}); }
     first = false;
     if (!done) ++it;
     {                                            // size of the step just taken, per env: max over the workers

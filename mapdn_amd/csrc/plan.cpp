@@ -486,45 +486,26 @@ void sparse_program(const Plan& P, int S, SparseProg& G) {
   }
 }
 
-void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw, int min_rows, bool pairs) {
+void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw, int min_rows) {
   const int n = P.n;
   if (Sw < 1 || W % Sw) Sw = 1;
-  S.W = W; S.S = Sw; S.steps.clear(); S.steps2.clear(); S.clist.clear();
+  S.W = W; S.S = Sw; S.steps.clear(); S.clist.clear();
   std::vector<std::vector<int>> children(n + 1);
   for (int k = 0; k < n; ++k) children[P.par[k]].push_back(k);     // ascending k
-  // ---- chain pairs (plan.hpp): top_of[b] = k for a bottom node b, bot_of[k] = b for a top node k.  The ITEMS of the schedule are
-  // the single nodes and the tops (a pair is named by its top); everything below is written over items.
-  std::vector<int> top_of(n, -1), bot_of(n, -1);
-  S.pairs = 0;
-  if (pairs)
-    for (int k = 0; k < n; ++k) {
-      if (children[k].size() != 1) continue;
-      const int b = children[k][0];
-      if (bot_of[b] >= 0 || top_of[b] >= 0) continue;              // b is already the top (or, impossible here, the bottom) of a pair
-      top_of[b] = k; bot_of[k] = b; ++S.pairs;
-    }
-  S.top_of.assign(top_of.begin(), top_of.end());
-  auto is_item = [&](int k) { return top_of[k] < 0; };
-  auto sbot = [&](int t) { return bot_of[t] >= 0 ? bot_of[t] : t; };           // the node whose children feed the item
-  auto spar = [&](int t) { const int p = P.par[t]; return p >= n ? n : (top_of[p] >= 0 ? top_of[p] : p); };   // parent ITEM (n: none)
-  std::vector<int> items;
-  for (int k = 0; k < n; ++k) if (is_item(k)) items.push_back(k);
-  const int ni = (int)items.size();
   std::vector<int> depth(n + 1, 0);
-  for (int i = ni - 1; i >= 0; --i) depth[items[i]] = depth[spar(items[i])] + 1;   // parent items have larger positions
-  // canonical chain child of an item: the node right below its bottom node in the plan's order, when that node is its child
-  auto chain_child = [&](int t) { const int b = sbot(t); return (b > 0 && (P.flags[b - 1] & F_PARENT_NEXT)) ? b - 1 : -1; };
+  for (int k = n - 1; k >= 0; --k) depth[k] = depth[P.par[k]] + 1;  // parents have larger positions
+  auto chain_child = [&](int k) { return (k > 0 && (P.flags[k - 1] & F_PARENT_NEXT)) ? k - 1 : -1; };
   std::vector<int> pending(n, 0), row_of(n, -1), wave_of(n, -1);
-  for (int t : items) pending[t] = (int)children[sbot(t)].size();   // (children of a bottom / single node are items)
+  for (int k = 0; k < n; ++k) pending[k] = (int)children[k].size();
   std::vector<int> ready;
-  for (int t : items) if (!pending[t]) ready.push_back(t);
-  std::vector<std::vector<int>> rows;   // rows[r][w] = item or -1
+  for (int k = 0; k < n; ++k) if (!pending[k]) ready.push_back(k);
+  std::vector<std::vector<int>> rows;   // rows[r][w] = node or -1
   int scheduled = 0;
   if (W == 1) {   // one worker: the plan's own order keeps the feeder chains contiguous
-    for (int t : items) { row_of[t] = (int)rows.size(); wave_of[t] = 0; rows.push_back({t}); }
-    scheduled = ni;
+    for (int k = 0; k < n; ++k) { rows.push_back({k}); row_of[k] = k; wave_of[k] = 0; }
+    scheduled = n;
   }
-  while (scheduled < ni) {
+  while (scheduled < n) {
     const int r = (int)rows.size();
     // highest level first; among equals prefer nodes that continue a chain from the previous row
     auto continues = [&](int k) { int c = chain_child(k); return c >= 0 && row_of[c] == r - 1; };
@@ -550,7 +531,7 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw, i
     for (int ww = 0; ww < W; ++ww) {
       int k = row[ww];
       if (k < 0) continue;
-      int p = spar(k);
+      int p = P.par[k];
       if (p < n && --pending[p] == 0) ready.push_back(p);
     }
   }
@@ -558,10 +539,9 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw, i
   const int R = (int)rows.size();
   S.R = R;
   S.steps.assign((size_t)W * R, StepRec{});
-  S.steps2.assign((size_t)W * R, StepRec{});
   std::vector<char> carry_out(n, 0);
-  for (int k : items) {
-    int p = spar(k);
+  for (int k = 0; k < n; ++k) {
+    int p = P.par[k];
     if (p < n && chain_child(p) == k && row_of[p] == row_of[k] + 1 && wave_of[p] == wave_of[k]) carry_out[k] = 1;
   }
   // ---- LDS slot allocation by interval colouring.
@@ -570,7 +550,7 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw, i
   std::vector<int> oslot(n, -1), xslot(n, -1);
   {
     std::vector<std::vector<int>> writers(R), release(R + 1);
-    for (int k : items) if (spar(k) < n && !carry_out[k]) writers[row_of[k]].push_back(k);
+    for (int k = 0; k < n; ++k) if (P.par[k] < n && !carry_out[k]) writers[row_of[k]].push_back(k);
     std::vector<int> freelist; int next = 0;
     for (int r = 0; r < R; ++r) {
       for (int sl : release[r]) freelist.push_back(sl);
@@ -578,19 +558,18 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw, i
       for (int k : writers[r]) {
         int sl; if (!freelist.empty()) { sl = freelist.back(); freelist.pop_back(); } else sl = next++;
         oslot[k] = sl;
-        release[row_of[spar(k)] + 1].push_back(sl);
+        release[row_of[P.par[k]] + 1].push_back(sl);
       }
     }
     S.n_cslots = std::max(std::max(next, 1), min_cslots - 2);   // two more (ZERO, TRASH) are appended below
   }
   // x slot of parent p: written in backward row row_of[p], read by its non-carried children at
   // rows < row_of[p]; reusable by writers at rows strictly below the lowest reader row.
-  // (Layouts whose h factors are not in LDS only: they are scheduled WITHOUT pairs, so items == nodes there.)
   {
     std::vector<int> low(n, -1);   // lowest reader row
-    for (int k : items) { int p = spar(k); if (p < n && !carry_out[k]) low[p] = (low[p] < 0) ? row_of[k] : std::min(low[p], row_of[k]); }
+    for (int k = 0; k < n; ++k) { int p = P.par[k]; if (p < n && !carry_out[k]) low[p] = (low[p] < 0) ? row_of[k] : std::min(low[p], row_of[k]); }
     std::vector<std::vector<int>> writers(R), release(R + 1);
-    for (int k : items) if (low[k] >= 0) writers[row_of[k]].push_back(k);
+    for (int k = 0; k < n; ++k) if (low[k] >= 0) writers[row_of[k]].push_back(k);
     std::vector<int> freelist; int next = 0;
     for (int r = R - 1; r >= 0; --r) {
       for (int sl : release[r]) freelist.push_back(sl);      // released for writers at row r: readers all at rows > r
@@ -610,8 +589,7 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw, i
   for (int w = 0; w < W; ++w)
     for (int r = 0; r < R; ++r) {
       StepRec& T = S.steps[(size_t)w * R + r];
-      StepRec& T2 = S.steps2[(size_t)w * R + r];
-      const int t = rows[r][w];
+      const int k = rows[r][w];
       T = StepRec{};
       T.kp = (uint32_t)(n + 1) | ((uint32_t)n << 16);   // idle: trash node, slack parent
       T.slots = c_trash | (x_trash << 10) | (x_zero << 20);
@@ -620,41 +598,27 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw, i
       // mismatch exactly 0, a regular 2x2 pivot, Newton step exactly 0 — every value it leaves in the carry registers
       // is finite (the kernel masks carries by a 0/1 factor, and 0 * NaN would poison the next live step)
       T.ykk[0] = 1.0; T.ykk[1] = -1.0; T.ykp[0] = -1.0; T.ykp[1] = 1.0; T.ypk[0] = -1.0; T.ypk[1] = 1.0;
-      T2 = T;                                            // the top-node record of a step that is not a pair: the same harmless node
-      if (t < 0) continue;
-      const int k = sbot(t);                             // the node whose record this is (the bottom node of a pair)
-      const bool pair = bot_of[t] >= 0;
+      if (k < 0) continue;
       S.step_of_node[k] = w * R + r;
-      if (pair) S.step_of_node[t] = w * R + r;
       const double* c = &P.yc[(size_t)k * 8];
       T.ykk[0] = c[0]; T.ykk[1] = c[1]; T.ykp[0] = c[2]; T.ykp[1] = c[3]; T.ypk[0] = c[4]; T.ypk[1] = c[5];
       T.cks[0] = c[6]; T.cks[1] = c[7];
-      T.kp = (uint32_t)k | ((uint32_t)P.par[k] << 16);   // (a bottom node's electrical parent is the pair's top)
-      if (pair) {
-        const double* c2 = &P.yc[(size_t)t * 8];
-        T2.ykk[0] = c2[0]; T2.ykk[1] = c2[1]; T2.ykp[0] = c2[2]; T2.ykp[1] = c2[3]; T2.ypk[0] = c2[4]; T2.ypk[1] = c2[5];
-        T2.cks[0] = c2[6]; T2.cks[1] = c2[7];
-        T2.kp = (uint32_t)t | ((uint32_t)P.par[t] << 16);
-        T2.flags = S_LIVE | S_PAIR;
-      }
-      const int p = spar(t);
-      uint32_t f = S_LIVE | (pair ? (uint32_t)S_PAIR : 0u), os = c_trash, xsl = x_trash, pxs = x_zero;
+      const int p = P.par[k];
+      T.kp = (uint32_t)k | ((uint32_t)p << 16);
+      uint32_t f = S_LIVE, os = c_trash, xsl = x_trash, pxs = x_zero;
       if (p == n) f |= S_PARENT_ROOT;
-      else if (carry_out[t]) f |= S_CARRY_OUT;
-      else { f |= S_SCRATCH_OUT; os = (uint32_t)oslot[t]; pxs = (uint32_t)xslot[p]; }
+      else if (carry_out[k]) f |= S_CARRY_OUT;
+      else { f |= S_SCRATCH_OUT; os = (uint32_t)oslot[k]; pxs = (uint32_t)xslot[p]; }
       std::vector<int> kids;
-      const int cc = chain_child(t);
+      const int cc = chain_child(k);
       if (cc >= 0) { if (carry_out[cc]) f |= S_CARRY_IN; else kids.push_back(oslot[cc]); }
       for (int ch : children[k]) if (ch != cc) kids.push_back(oslot[ch]);
       uint32_t ch3[3] = {c_zero, c_zero, c_zero};
       for (size_t j = 0; j < kids.size() && j < 3; ++j) ch3[j] = (uint32_t)kids[j];
       const uint32_t cptr = (uint32_t)S.clist.size();
       for (size_t j = 3; j < kids.size(); ++j) S.clist.push_back(kids[j]);
-      if (xslot[t] >= 0) { f |= S_X_OUT; xsl = (uint32_t)xslot[t]; }
+      if (xslot[k] >= 0) { f |= S_X_OUT; xsl = (uint32_t)xslot[k]; }
       T.slots = os | (xsl << 10) | (pxs << 20) | (((cptr >> 8) & 3u) << 30);
-      // a pair step runs only in layouts whose backward sweep goes through the h array (no x slots): bits 10-25 carry the position
-      // of the pair's parent p instead (kp holds b | k << 16), so that no second index word has to be fetched
-      if (pair) T.slots = os | ((uint32_t)P.par[t] << 10) | (((cptr >> 8) & 3u) << 30);
       T.chs = ch3[0] | (ch3[1] << 10) | (ch3[2] << 20) | (((cptr >> 10) & 3u) << 30);
       T.flags = f | ((uint32_t)std::min<size_t>(kids.size(), 255) << 16) | ((cptr & 255u) << 24);
     }
@@ -664,29 +628,20 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw, i
       uint32_t gmax = 0, any = 0;
       for (int w = w0; w < w0 + Sw; ++w) {
         const StepRec& T = S.steps[(size_t)w * R + r];
-        const StepRec& T2 = S.steps2[(size_t)w * R + r];
         if (!(T.flags & S_LIVE)) continue;
         gmax = std::max(gmax, std::min<uint32_t>((T.flags >> 16) & 255u, 3u));
         if (T.flags & S_SCRATCH_OUT) any |= SU_W_ANY;
         if (T.flags & S_X_OUT) any |= SU_XW_ANY;
         if ((T.flags & S_SCRATCH_OUT)) any |= SU_XR_ANY;       // a non-carried child of a real parent reads the parent's x slot
         if (T.cks[0] != 0.0 || T.cks[1] != 0.0) any |= SU_SLACK_ANY;
-        if (T.flags & S_PAIR) { any |= SU_PAIR_ANY; if (T2.cks[0] != 0.0 || T2.cks[1] != 0.0) any |= SU_SLACK_ANY; }
       }
       for (int w = w0; w < w0 + Sw; ++w) S.steps[(size_t)w * R + r].flags |= (gmax << SU_GMAX_SHIFT) | any;
     }
   if (S.clist.empty()) S.clist.push_back(0);
-  S.ytop.assign((size_t)(n + 2) * 8, 0.0);
-  for (int k = 0; k < n + 2; ++k) {
-    double* o = &S.ytop[(size_t)k * 8];
-    if (k < n) std::copy_n(&P.yc[(size_t)k * 8], 8, o);
-    else { o[0] = 1.0; o[1] = -1.0; o[2] = -1.0; o[3] = 1.0; o[4] = -1.0; o[5] = 1.0; }     // (as an idle step)
-  }
-  // ---- canonical child lists by NODE (independent of W and of the pairs: the mismatch pass works node by node)
-  auto node_chain_child = [&](int k) { return (k > 0 && (P.flags[k - 1] & F_PARENT_NEXT)) ? k - 1 : -1; };
+  // ---- canonical child lists (independent of W: the same order the records above encode)
   S.mm_ptr.assign(1, 0); S.mm_child.clear();
   for (int k = 0; k < n; ++k) {
-    const int cc = node_chain_child(k);
+    const int cc = chain_child(k);
     if (cc >= 0) S.mm_child.push_back(cc);
     for (int ch : children[k]) if (ch != cc) S.mm_child.push_back(ch);
     S.mm_ptr.push_back((int32_t)S.mm_child.size());
@@ -709,66 +664,37 @@ void build_schedule(const Plan& P, int W, Schedule& S, int min_cslots, int Sw, i
       const double* c = &P.yc[(size_t)k * 8];
       T.ykk[0] = c[0]; T.ykk[1] = c[1]; T.ykp[0] = c[2]; T.ykp[1] = c[3]; T.ypk[0] = c[4]; T.ypk[1] = c[5]; T.cks[0] = c[6]; T.cks[1] = c[7];
     }
-  // ---- flat-start factorisation (same formulas as k_nr_tree's forward step with V == vroot everywhere; pairs: plan.hpp)
+  // ---- flat-start factorisation (same formulas as k_nr_tree's forward step with V == vroot everywhere)
   {
     const double v = P.vroot, v2 = v * v;
-    std::vector<double> aS((size_t)(n + 1) * 2, 0.0), aD((size_t)(n + 1) * 4, 0.0), node((size_t)n * FLAT_N, 0.0), node2((size_t)n * FLAT2_N, 0.0);
-    struct M2 { double a, b, c, d; };                                  // [[a, b], [c, d]]
-    auto mul = [](const M2& x, const M2& y) { return M2{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; };
-    auto inv = [](const M2& x) { const double id = 1.0 / (x.a * x.d - x.b * x.c); return M2{x.d * id, -x.b * id, -x.c * id, x.a * id}; };
-    auto jac = [](double ar, double ai) { return M2{ai, ar, -ar, ai}; };   // off-diagonal Jacobian block of A = ar + j ai (U and L alike)
-    for (int t : items) {                         // children have smaller positions than their parents
-      const int k = sbot(t);
+    std::vector<double> aS((size_t)n * 2, 0.0), aD((size_t)n * 4, 0.0), node((size_t)n * FLAT_N, 0.0);
+    for (int k = 0; k < n; ++k) {                 // children have smaller positions than their parents
       const double* c = &P.yc[(size_t)k * 8];
       const double gkk = c[0], bkk = c[1], gkp = c[2], bkp = c[3], gpk = c[4], bpk = c[5];
       const double akp_r = v2 * gkp, akp_i = -v2 * bkp, apk_r = v2 * gpk, apk_i = -v2 * bpk;
       const double akk_r = v2 * gkk, akk_i = -v2 * bkk, aks_r = v * c[6], aks_i = -v * c[7];
       const double sr = (akk_r + aks_r) + akp_r + aS[2 * k], si = (akk_i + aks_i) + akp_i + aS[2 * k + 1];
-      M2 D{-(si - akk_i) - aD[4 * k], (sr + akk_r) - aD[4 * k + 1], (sr - akk_r) - aD[4 * k + 2], (si + akk_i) - aD[4 * k + 3]};
+      const double D0 = -(si - akk_i) - aD[4 * k], D1 = (sr + akk_r) - aD[4 * k + 1];
+      const double D2 = (sr - akk_r) - aD[4 * k + 2], D3 = (si + akk_i) - aD[4 * k + 3];
+      const double idet = 1.0 / (D0 * D3 - D1 * D2);
+      const double I0 = D3 * idet, I1 = -D1 * idet, I2 = -D2 * idet, I3 = D0 * idet;
+      const double G0 = I0 * akp_i - I1 * akp_r, G1 = I0 * akp_r + I1 * akp_i;
+      const double G2 = I2 * akp_i - I3 * akp_r, G3 = I2 * akp_r + I3 * akp_i;
       double* o = &node[(size_t)k * FLAT_N];
-      o[FL_SR] = sr; o[FL_SI] = si;
-      const int p = P.par[t];                    // where the item's contribution goes (a single / bottom node, or n)
-      if (bot_of[t] < 0) {                       // single node: U = J(k,p), L = J(p,k)
-        const M2 I = inv(D), G = mul(I, jac(akp_r, akp_i)), s = mul(jac(apk_r, apk_i), G);
-        o[FL_I0] = I.a; o[FL_I1] = I.b; o[FL_I2] = I.c; o[FL_I3] = I.d; o[FL_APR] = apk_r; o[FL_API] = apk_i;
-        o[FL_G0] = G.a; o[FL_G1] = G.b; o[FL_G2] = G.c; o[FL_G3] = G.d;
+      o[FL_SR] = sr; o[FL_SI] = si; o[FL_I0] = I0; o[FL_I1] = I1; o[FL_I2] = I2; o[FL_I3] = I3;
+      o[FL_APR] = apk_r; o[FL_API] = apk_i; o[FL_G0] = G0; o[FL_G1] = G1; o[FL_G2] = G2; o[FL_G3] = G3;
+      const int p = P.par[k];
+      if (p < n) {
         aS[2 * p] += apk_r; aS[2 * p + 1] += apk_i;
-        aD[4 * p] += s.a; aD[4 * p + 1] += s.b; aD[4 * p + 2] += s.c; aD[4 * p + 3] += s.d;
-        continue;
+        aD[4 * p] += apk_i * G0 + apk_r * G2; aD[4 * p + 1] += apk_i * G1 + apk_r * G3;
+        aD[4 * p + 2] += apk_i * G2 - apk_r * G0; aD[4 * p + 3] += apk_i * G3 - apk_r * G1;
       }
-      // pair: top node t (its only child is k), parent p.  Here akp = A_kt, apk = A_tk (k's electrical parent is t).
-      const double* c2 = &P.yc[(size_t)t * 8];
-      const double atp_r = v2 * c2[2], atp_i = -v2 * c2[3], apt_r = v2 * c2[4], apt_i = -v2 * c2[5];
-      const double att_r = v2 * c2[0], att_i = -v2 * c2[1], ats_r = v * c2[6], ats_i = -v * c2[7];
-      const double st_r = (att_r + ats_r) + atp_r + apk_r, st_i = (att_i + ats_i) + atp_i + apk_i;     // the child's term A_tk opens the sum
-      const M2 Dt{-(st_i - att_i), st_r + att_r, st_r - att_r, st_i + att_i};
-      const M2 It = inv(Dt), Gtp = mul(It, jac(atp_r, atp_i)), Gtb = mul(It, jac(apk_r, apk_i));
-      const M2 Lbt = jac(akp_r, akp_i), Lpt = jac(apt_r, apt_i);
-      const M2 Dt2b = mul(Lbt, Gtb), Dt2p = mul(Lpt, Gtp);
-      M2 Ubp = mul(Lbt, Gtp), Lpb = mul(Lpt, Gtb);
-      Ubp = M2{-Ubp.a, -Ubp.b, -Ubp.c, -Ubp.d}; Lpb = M2{-Lpb.a, -Lpb.b, -Lpb.c, -Lpb.d};
-      D = M2{D.a - Dt2b.a, D.b - Dt2b.b, D.c - Dt2b.c, D.d - Dt2b.d};
-      const M2 I = inv(D), G = mul(I, Ubp), s = mul(Lpb, G);
-      o[FL_I0] = I.a; o[FL_I1] = I.b; o[FL_I2] = I.c; o[FL_I3] = I.d; o[FL_APR] = 0.0; o[FL_API] = 0.0;
-      o[FL_G0] = G.a; o[FL_G1] = G.b; o[FL_G2] = G.c; o[FL_G3] = G.d;
-      double* o2 = &node2[(size_t)k * FLAT2_N];
-      o2[F2_SR] = st_r; o2[F2_SI] = st_i; o2[F2_I0] = It.a; o2[F2_I1] = It.b; o2[F2_I2] = It.c; o2[F2_I3] = It.d;
-      o2[F2_ABKR] = akp_r; o2[F2_ABKI] = akp_i; o2[F2_APKR] = apt_r; o2[F2_APKI] = apt_i;
-      o2[F2_L0] = Lpb.a; o2[F2_L1] = Lpb.b; o2[F2_L2] = Lpb.c; o2[F2_L3] = Lpb.d;
-      o2[F2_GP0] = Gtp.a; o2[F2_GP1] = Gtp.b; o2[F2_GP2] = Gtp.c; o2[F2_GP3] = Gtp.d;
-      o2[F2_GB0] = Gtb.a; o2[F2_GB1] = Gtb.b; o2[F2_GB2] = Gtb.c; o2[F2_GB3] = Gtb.d;
-      aS[2 * p] += apt_r; aS[2 * p + 1] += apt_i;
-      aD[4 * p] += s.a + Dt2p.a; aD[4 * p + 1] += s.b + Dt2p.b; aD[4 * p + 2] += s.c + Dt2p.c; aD[4 * p + 3] += s.d + Dt2p.d;
     }
     S.flat.assign((size_t)W * R * FLAT_N, 0.0);   // idle steps: all zero (h = t = 0 go to the trash slots)
-    S.flat2.assign((size_t)W * R * FLAT2_N, 0.0);
     for (int w = 0; w < W; ++w)
       for (int r = 0; r < R; ++r) {
-        const int t = rows[r][w];
-        if (t < 0) continue;
-        const int k = sbot(t);
-        std::copy_n(&node[(size_t)k * FLAT_N], (size_t)FLAT_N, &S.flat[((size_t)w * R + r) * FLAT_N]);
-        if (bot_of[t] >= 0) std::copy_n(&node2[(size_t)k * FLAT2_N], (size_t)FLAT2_N, &S.flat2[((size_t)w * R + r) * FLAT2_N]);
+        const int k = rows[r][w];
+        if (k >= 0) std::copy_n(&node[(size_t)k * FLAT_N], (size_t)FLAT_N, &S.flat[((size_t)w * R + r) * FLAT_N]);
       }
   }
 }

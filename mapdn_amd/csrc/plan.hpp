@@ -38,7 +38,6 @@ enum : int32_t {
 // parents and a TRASH slot or node for outputs nobody reads, so the kernel's step body is branch-free per lane.
 //   flags : S_* bits 0-5 | wave-uniform hints bits 6-10 (see SU_*) | number of slot children << 16 | cptr bits 0-7 << 24
 //   slots : oslot | xslot << 10 | pxslot << 20 (contribution / x slots this node writes, parent's x slot) | cptr bits 8-9 << 30
-//           (a PAIR step, S_PAIR: oslot | position of the pair's parent << 10 | cptr bits; kp = bottom node | top node << 16)
 //   chs   : ch0 | ch1 << 10 | ch2 << 20 (contribution slots of the first three slot children, canonical order) | cptr bits 10-11 << 30
 //   kp    : node position | parent position << 16   (idle step: trash node n+1; no parent: slack position n with Y = 0)
 // cptr = start of the overflow child list (slot children 3..) in Schedule::clist.
@@ -64,9 +63,6 @@ enum : uint32_t {
   SU_XW_ANY = 512u,      // backward: some worker writes a real x slot
   SU_XR_ANY = 1024u,     // backward: some worker reads its parent's x from a slot
   SU_SLACK_ANY = 2048u,  // some worker's node neighbours the slack (cks != 0)
-  // chain-pair fusion (Schedule::pairs): the step eliminates TWO nodes, b and its parent k (a node whose only child is b)
-  S_PAIR = 4096u,        // this step is a pair: Schedule::steps2 holds the record of the top node k
-  SU_PAIR_ANY = 8192u,   // wave-uniform: some worker of the wave has a pair in this row
 };
 
 struct Schedule {
@@ -93,32 +89,9 @@ struct Schedule {
   // junction come from mm_child.
   int32_t mm_np = 0;                       // records per worker
   std::vector<StepRec> mm_recs;            // [W][mm_np]
-  // ---- chain-pair fusion.  A node k whose ONLY child is b can be eliminated BEFORE b: its pivot needs no contribution from below
-  // (J(k,k) is made of k's own terms), so a step that holds both nodes computes k's elimination off the critical path (beside the
-  // LDS reads of b's children) and then eliminates b against the Schur-complement coupling  J'(b,p) = -J(b,k) D_k^-1 J(k,p)  to
-  // k's parent p.  The pair is ONE node of the schedule: every fused pair takes a row off its chain (141-bus feeder: 17 -> 11 rows).
-  //   forward :  h_k = D_k^-1 F_k, G_kp = D_k^-1 J(k,p), G_kb = D_k^-1 J(k,b);   D_b' = D_b - sum(children) - J(b,k) G_kb,
-  //              r_b' = F_b - sum(children) - J(b,k) h_k,  h_b = D_b'^-1 r_b',  G_b = D_b'^-1 J'(b,p);
-  //              to p:  S: A_pk,  D: J(p,k) G_kp + J'(p,b) G_b,  R: J(p,k) h_k + J'(p,b) h_b     with J'(p,b) = -J(p,k) G_kb
-  //   backward:  x_b = h_b - G_b x_p,   x_k = h_k - G_kp x_p - G_kb x_b
-  // Pairs are chosen on the topology alone (ascending positions: every node with exactly one child, whose child is not yet the
-  // top of a pair), so the arithmetic of a net does not depend on the launch geometry.
-  int32_t pairs = 0;                       // number of fused pairs (0: the plain schedule)
-  std::vector<StepRec> steps2;             // [W][R] record of the TOP node of a pair step: kp = k | p << 16, Y_kk, Y_kp, Y_pk, Y_k,slack V_slack
-                                           // (single / idle steps: the trash node, like an idle step)
-  std::vector<double> flat2;               // [W][R][FLAT2_N] flat-start constants of the top node (zeros for single steps) — host only: the
-                                           // CPU tests replay the pair algebra with them; a handle with pairs starts with a full sweep
-  std::vector<double> ytop;                // [n + 2][8] Y_kk, Y_kp, Y_pk, Y_k,slack V_slack by NODE (what a pair step needs of its top node;
-                                           // entries n, n + 1: the harmless constants of an idle step)
-  std::vector<int32_t> top_of;             // [n] the top node fused with node b, or -1
 };
-// per-step layout of Schedule::flat (pair steps: the BOTTOM node; FL_APR / FL_API are unused there)
+// per-step layout of Schedule::flat
 enum { FL_SR = 0, FL_SI, FL_I0, FL_I1, FL_I2, FL_I3, FL_APR, FL_API, FL_G0, FL_G1, FL_G2, FL_G3, FLAT_N };
-// ... and of Schedule::flat2 (the top node k of a pair, parent p, bottom b): S_k | D_k^-1 | A_bk (-> J(b,k)) | A_pk (-> J(p,k)) |
-// J'(p,b) | G_kp | G_kb | pad
-enum { F2_SR = 0, F2_SI, F2_I0, F2_I1, F2_I2, F2_I3, F2_ABKR, F2_ABKI, F2_APKR, F2_APKI, F2_L0, F2_L1, F2_L2, F2_L3,
-       F2_GP0, F2_GP1, F2_GP2, F2_GP3, F2_GB0, F2_GB1, F2_GB2, F2_GB3, F2_PAD0, F2_PAD1, FLAT2_N };
-static_assert(FLAT2_N == 24, "flat2 steps are 24 doubles (12 x dwordx4)");
 
 struct LineFlow {      // res_line.pl_mw of one net.line row from the pi model: pl / sn = Re(Sf + St) with If = yff Vf + yft Vt,
   int32_t fpos, tpos;  // It = ytf Vf + ytt Vt  ==  gff |Vf|^2 + gtt |Vt|^2 + (gft + gtf) a + (bft - btf) b,  a + jb = Vf conj(Vt)
@@ -217,6 +190,6 @@ int build_plan(const mapdn_netspec& net, const mapdn_env_config& cfg, Plan& out,
 #ifndef NR_HG_REG_ROWS
 #define NR_HG_REG_ROWS 12
 #endif
-void build_schedule(const Plan& P, int W, Schedule& out, int min_cslots = 0, int S = 1, int min_rows = 0, bool pairs = false);
+void build_schedule(const Plan& P, int W, Schedule& out, int min_cslots = 0, int S = 1, int min_rows = 0);
 
 }  // namespace mapdn

@@ -338,93 +338,3 @@ def test_tolerance_options(lib):
     for tuning, ok in ((None, True), (dict(tolerance_is_pu=1), True), (dict(tolerance_mva=1e-6), True), (dict(tolerance_mva=-1.0), False)):
         rc, g = _geometry(lib, net, 64, tuning)
         assert (rc == 0) == ok, g
-
-
-@pytest.mark.parametrize("case", ["case33", "case141", "case141_deep", "case322"])
-@pytest.mark.parametrize("W", [1, 4, 16, 32])
-def test_chain_pair_schedule_and_its_flat_start_factorisation(lib, case, W):
-    """Chain-pair fusion (plan.hpp Schedule::pairs, round 5): a node k whose only child is b is eliminated in b's step, FIRST (its pivot
-    needs nothing from below).  (i) The schedule is a valid elimination: every node exactly once (as the node of a step or as the top
-    of a pair), a pair's top is the parent of its bottom and has no other child, every step after the steps of its node's children;
-    fewer rows than the plain Hu schedule wherever the feeder has chains.  (ii) Replaying the kernel's flat-start sweeps on the host
-    with the exported constants — pair steps in the kernel's own order of operations — gives the oracle's first Newton step."""
-    from scipy.sparse.linalg import spsolve
-    from oracle.pp_restated import make_ybus, bus_demand, make_sbus, jacobian, _fx
-    net, prof = make_case(case)
-    rc, h = host_handle(lib, net)
-    assert rc == 0
-    nb, n = net.n_bus, net.n_bus - 1
-    dims = np.zeros(2, np.int32)
-    assert lib.mapdn_get_pair_schedule(h, W, _lib._p(dims, _lib._pi), None, None, None, None) == 0
-    R, npairs = int(dims[0]), int(dims[1])
-    bot = np.zeros(W * R, np.int32); top = np.zeros(W * R, np.int32); flat = np.zeros((W * R, 12)); flat2 = np.zeros((W * R, 24))
-    assert lib.mapdn_get_pair_schedule(h, W, _lib._p(dims, _lib._pi), _lib._p(bot, _lib._pi), _lib._p(top, _lib._pi), _lib._p(flat, _lib._pd), _lib._p(flat2, _lib._pd)) == 0
-    par = np.zeros(n, np.int32); bop = np.zeros(n + 1, np.int32); fac = np.zeros((n, 12))
-    Rplain = C.c_int32()
-    assert lib.mapdn_get_schedule(h, min(W, 16), C.byref(Rplain), None, _lib._p(par, _lib._pi)) == 0
-    assert lib.mapdn_get_flat_factors(h, _lib._p(fac, _lib._pd), _lib._p(bop, _lib._pi)) == 0
-    # ---- (i) validity
-    nodes = sorted(bot[bot >= 0].tolist() + top[top >= 0].tolist())
-    assert nodes == list(range(n)) and (top >= 0).sum() == npairs and npairs > 0
-    kids = [[] for _ in range(n + 1)]
-    for k in range(n):
-        kids[par[k]].append(k)
-    bot2, top2 = bot.reshape(W, R), top.reshape(W, R)
-    row_of = {}
-    for w in range(W):
-        for r in range(R):
-            if bot2[w, r] >= 0:
-                row_of[int(bot2[w, r])] = r
-                if top2[w, r] >= 0:
-                    k, b = int(top2[w, r]), int(bot2[w, r])
-                    assert par[b] == k and kids[k] == [b]
-                    row_of[k] = r
-    for k in range(n):
-        if par[k] < n and row_of[par[k]] == row_of[k]:
-            assert any(top2[w, row_of[k]] == par[k] and bot2[w, row_of[k]] == k for w in range(W))   # same row only inside a pair
-        elif par[k] < n:
-            assert row_of[par[k]] > row_of[k]
-    if W <= 16 and W > 1:
-        assert R < Rplain.value, (R, Rplain.value)
-    # ---- (ii) the flat-start sweeps, step by step in schedule order (rows ascending; within a row any order)
-    rng = np.random.default_rng(1)
-    row = int(rng.integers(0, prof.n_rows))
-    pv = prof.pv[row]
-    q = rng.uniform(-0.6, 0.6, net.n_sgen) * np.sqrt(prof.s_max() ** 2 - pv ** 2)
-    sbus = make_sbus(net, *bus_demand(net, prof.load_p[row], prof.load_q[row], pv, q))
-    ybus = make_ybus(net)[0]
-    pq = np.setdiff1d(np.arange(nb), [net.ext_grid_bus])
-    v0 = np.full(nb, net.ext_grid_vm_pu, dtype=np.complex128)
-    dx = -spsolve(jacobian(ybus, v0, pq, pq).tocsc(), _fx(ybus, v0, sbus, pq, pq))
-    dth = np.zeros(nb); dvm = np.zeros(nb)
-    dth[pq] = dx[:n]; dvm[pq] = dx[n:]
-    jac = lambda a: np.array([[a[1], a[0]], [-a[0], a[1]]])        # [[Im A, Re A], [-Re A, Im A]] of A = (re, im)
-    hv = np.zeros((n + 1, 2)); acc = np.zeros((n + 1, 2)); x = np.zeros((n + 1, 2))
-    steps = sorted((r, w) for w in range(W) for r in range(R) if bot2[w, r] >= 0)
-    for r, w in steps:
-        i = w * R + r
-        b, k = int(bot2[w, r]), int(top2[w, r])
-        f1, f2 = flat[i], flat2[i]
-        F = f1[0] + 1j * f1[1] - sbus[bop[b]]
-        rb = np.array([F.real, F.imag]) - acc[b]
-        Ib = f1[2:6].reshape(2, 2)
-        if k < 0:                                               # single step
-            hv[b] = Ib @ rb
-            acc[par[b]] += jac(f1[6:8]) @ hv[b]
-            continue
-        Fk = f2[0] + 1j * f2[1] - sbus[bop[k]]
-        hv[k] = f2[2:6].reshape(2, 2) @ np.array([Fk.real, Fk.imag])
-        rb = rb - jac(f2[6:8]) @ hv[k]                          # J(b,k) h_k
-        hv[b] = Ib @ rb
-        acc[par[k]] += f2[10:14].reshape(2, 2) @ hv[b] + jac(f2[8:10]) @ hv[k]
-    for r, w in reversed(steps):
-        i = w * R + r
-        b, k = int(bot2[w, r]), int(top2[w, r])
-        p = par[k] if k >= 0 else par[b]
-        xp = x[p] if p < n else np.zeros(2)
-        x[b] = hv[b] - flat[i][8:12].reshape(2, 2) @ xp
-        if k >= 0:
-            x[k] = hv[k] - flat2[i][14:18].reshape(2, 2) @ xp - flat2[i][18:22].reshape(2, 2) @ x[b]
-    assert np.abs(-x[:n, 0] - dth[bop[:n]]).max() < 1e-10
-    assert np.abs(-x[:n, 1] * abs(v0[0]) - dvm[bop[:n]]).max() < 1e-10
-    lib.mapdn_destroy(h)

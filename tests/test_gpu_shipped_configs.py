@@ -53,11 +53,8 @@ def test_default_launch_matches_oracle_at_full_size(case, B, monkeypatch):
         oo, _ = o.reset()
         assert np.abs(np.array(oo) - obs[e]).max() < 1e-9
     # the same global ids as single-env handles (another geometry): the same trajectories
-    # (chain-pair fusion, round 5, is another exact elimination order: bit-identity holds among the layouts WITH pairs and among those
-    #  without — the single-env handles are pinned to the batch's class)
-    pairs_cls = dict(nr_pairs=1 if env.geometry()["pairs"] else 2)
     twins = {g: VoltageControlBatch(net, prof, dict(_args(case), auto_reset=True), n_envs=1, device="cuda:0", env_id_offset=g,
-                                    obs_dtype=torch.float64, tuning=pairs_cls) for g in (watch[0], bad_env, watch[-1])}
+                                    obs_dtype=torch.float64) for g in (watch[0], bad_env, watch[-1])}
     for g, tw in twins.items():
         o1, _ = tw.reset()
         assert torch.equal(o1[0], torch.as_tensor(obs[g], device="cuda:0"))
