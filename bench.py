@@ -270,6 +270,8 @@ def main():
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the short case33 / case322 measurements appended to the default line")
     ap.add_argument("--env-id-offset", type=int, default=0, help="global id of this run's first env (a 1-rank run that covers the ids "
                                                                    "of rank r of an N-rank run: r x envs); ranks add rank x envs")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end MADDPG block appended to the default line (BASELINE configs[4]'s "
+                                                          "per-GPU shard: case322 x 8192 envs, 3 episodes at the reference's update intensity)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and run the end-of-rollout gather, the max-over-ranks "
                                                               "all_reduce and the barriers) even at --gpus 1: first contact with RCCL on one GPU")
     ap.add_argument("--dump-returns", default=None, help="rank 0 writes the gathered per-env episode returns of the LAST timed block "
@@ -438,6 +440,30 @@ def main():
                                         "traffic_source": (f"committed rocprofv3 PMC passes: {trsrc2}" if trsrc2 else None)}})
             e2.close()
 
+    # ---- BASELINE configs[4] (end-to-end MADDPG rollout + update with GPU-resident replay), its per-GPU shard: the loop the env feeds.
+    # Default workload at N = 1 only; reported beside the headline, never part of `value`.  A failure here does not cost the line.
+    e2e = None
+    if world == 1 and not a.no_e2e and not a.no_other_shapes and a.case == "case141" and B == 4096:
+        try:
+            from mapdn_amd import e2e as _e2e
+            torch.cuda.empty_cache()
+            t_e2e = time.perf_counter()
+            lines = _e2e.run(case="case322", envs=8192, alg="maddpg", episodes=3, intensity="reference", phases=True, device=dev)
+            last = lines[-1]
+            e2e = {"workload": "case322 (322-bus, 38 agents) x 8192 envs per GPU, MADDPG (shared recurrent agent + MLP critic), GPU-resident replay, "
+                               "the reference's update intensity (models/model.py:39-52: 10 value + 1 policy update per 60 env-steps, batch = a window "
+                               "of 32 steps of every env = 5.87 sampled transitions per env-step); 240-step episodes",
+                   "value": last["env_steps_per_s"], "unit": "env-steps/s (training loop, per GPU)", "episodes": len(lines),
+                   "env_steps_per_s_per_episode": [ln["env_steps_per_s"] for ln in lines],      # the first episode carries allocations / autotuning
+                   "seconds_per_episode": [ln["seconds"] for ln in lines], "phase_share": last.get("phase_share"),
+                   "phase_seconds": last.get("phase_seconds"), "sampled_transitions_per_env_step": last["sampled_transitions_per_env_step"],
+                   "hbm_gb": last["hbm_gb"], "wall_seconds_total": time.perf_counter() - t_e2e,
+                   "env_share_note": "rollout_and_host is where step()+get_obs()+policy forward live: the env is a single-digit share of this loop"}
+        except Exception as exc:          # noqa: BLE001 — the headline line must still be printed
+            e2e = {"error": f"{type(exc).__name__}: {exc}"[:500]}
+        finally:
+            torch.cuda.empty_cache()
+
     if rank == 0:
         n_gpus = world
         value = n_gpus * B * a.steps / dt
@@ -500,6 +526,8 @@ def main():
                            "all_reduce(MAX, block time)", "barrier x2"], "gathered_rows_last_block": int(m["returns"].shape[0]) if m["returns"] is not None else None}
         if shapes:
             out["other_shapes"] = shapes
+        if e2e is not None:
+            out["e2e"] = e2e
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -25,11 +25,9 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SCALE = {"case33": 0.8, "case141": 0.6, "case322": 0.8}
 
 
 def main():
@@ -58,60 +56,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-    from mapdn_amd.env import VoltageControlBatch
-    from mapdn_amd.learner import PGTrainer, make_alg_args
-    from mapdn_amd.netspec import make_case
+    from mapdn_amd import e2e
 
-    torch.manual_seed(1 + rank); np.random.seed(1 + rank)
-    net, prof = make_case(a.case)
-    env_args = dict(episode_limit=a.max_steps, action_scale=SCALE[a.case], action_bias=0.0,
-                    voltage_barrier_type=a.voltage_barrier, seed=0)
-    env = VoltageControlBatch(net, prof, env_args, n_envs=a.envs, device=dev, env_id_offset=rank * a.envs, copy=True)
-    ref_ratio = 11 * 32 / 60.0
-    v_ep, p_ep = 10, 1
-    if a.intensity == "light" and a.updates_per_env_step is None:
-        batch = a.batch_size
-    else:
-        batch = 32 * a.envs                                       # 32 consecutive steps of every env
-        if a.updates_per_env_step is not None:
-            total = a.updates_per_env_step * a.update_freq * a.envs / batch
-            p_ep = max(1, round(total / 11)); v_ep = max(1, round(total - p_ep))
-    ratio = (v_ep + p_ep) * batch / (a.update_freq * a.envs)
-    args = make_alg_args(env.n_agents, env.obs_size, env.n_actions, SCALE[a.case], 0.0, max_steps=a.max_steps,
-                         batch_size=batch, replay_buffer_size=a.envs * max(a.replay_steps, 2 * batch // a.envs),
-                         behaviour_update_freq=a.update_freq, target_update_freq=2 * a.update_freq, num_eval_episodes=a.envs,
-                         value_update_epochs=v_ep, policy_update_epochs=p_ep)
-    trainer = PGTrainer(args, a.alg, env, device=dev)
-    trainer.profile_phases = a.phases
-    for ep in range(a.episodes):
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        stat = {}
-        trainer.train_process(stat)
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
+    def emit(line):
         if rank == 0:
-            line = {"episode": ep, "alg": a.alg, "case": a.case, "n_gpus": world, "envs_per_gpu": a.envs,
-                    "intensity": a.intensity, "batch_size": batch, "value_epochs": v_ep, "policy_epochs": p_ep,
-                    "sampled_transitions_per_env_step": ratio, "reference_ratio": ref_ratio,
-                    "env_steps_per_s": world * a.envs * a.max_steps / dt, "seconds": dt,
-                    "replay_transitions": len(trainer.replay_buffer),
-                    "hbm_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
-            if a.phases:
-                ph = trainer.phase_seconds()
-                ph["rollout_and_host"] = dt - sum(ph.values())
-                line["phase_seconds"] = {k: round(v, 4) for k, v in ph.items()}
-                line["phase_share"] = {k: round(v / dt, 4) for k, v in ph.items()}
-            line.update({k: v for k, v in stat.items() if k in (
-                "mean_train_reward", "mean_train_value_loss", "mean_train_policy_loss", "mean_train_totally_controllable_ratio",
-                "mean_train_q_loss")})
             print(json.dumps(line), flush=True)
             if a.log:
                 with open(a.log, "a") as f:
                     f.write(json.dumps(line) + "\n")
-    if a.save and rank == 0:
-        trainer.save(a.save)
-    env.close()
+    e2e.run(case=a.case, envs=a.envs, alg=a.alg, episodes=a.episodes, max_steps=a.max_steps, intensity=a.intensity, batch_size=a.batch_size,
+            updates_per_env_step=a.updates_per_env_step, replay_steps=a.replay_steps, update_freq=a.update_freq,
+            voltage_barrier=a.voltage_barrier, phases=a.phases, device=dev, rank=rank, world=world, save=a.save, on_line=emit)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 
