@@ -446,6 +446,19 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
     rc = dupload(h, &tmp, varow); if (rc) return rc; h->va_row = (int32_t*)tmp;
     return MAPDN_OK;
   };
+  // ---- step() composition switches that only exist on the tree solver: checked BEFORE the solver-specific set-up returns
+  // (mapdn.h: a pinned switch that cannot take effect is MAPDN_E_INVALID, never silently ignored)
+  {
+    const int fi = knob_tri(cfg->fuse_inject, "MAPDN_FUSE_INJECT");
+    const bool ov = knob_int(cfg->overlap_advance, "MAPDN_OVERLAP_ADVANCE") != 0, xm = knob_tri(cfg->xcd_map, "MAPDN_XCD_MAP") == 1;
+    if (h->solver != 0 && (fi == 1 || ov || xm)) {
+      h->err = "fuse_inject = 1 / overlap_advance / xcd_map exist on the tree solver only (this handle runs the general sparse / dense solver)";
+      return MAPDN_E_INVALID; }
+    if (ov && fi != 2 && !cfg->auto_reset && !knob_int(cfg->inject_full, "MAPDN_INJECT_FULL")) {
+      h->err = "overlap_advance = 1 has no effect while the PV-bus injection runs in the solver's prologue (the prologue reads what the side "
+               "stream's profile rows write): set fuse_inject = 2 as well";
+      return MAPDN_E_INVALID; }
+  }
   // ---- general-topology paths (see the solver choice above)
   if (h->solver == 2) {                           // k_nr_dense (dense.hip): one env per workgroup, dense Jacobian in LDS, f64 MFMA
     d.dense = 1; d.dn_N = (2 * P.n + 15) / 16 * 16; d.dn_lda = d.dn_N + 2;
@@ -670,13 +683,23 @@ static int step_launches(mapdn_handle* h, const void* actions, int32_t actions_d
   const bool fused = h->fuse_inject && h->solver == 0 && !h->sbus_stale;
   if (!fused) inject_launch(h, MODE_STEP, actions, actions_dtype, add_noise, st);
   if (h->overlap && !fused) {
-    // fork after the injection (it queues the row / draw the advance uses), join before the commit rows
-    HIPCHK(h, hipEventRecord(h->ev_fork, st));
-    HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    // fork after the injection (it queues the row / draw the advance uses), join before the commit rows.  The side stream's
+    // profile rows write cur_pv / cur_pl / bus_ld while the solver runs: safe only because the NON-fused k_nr_tree never reads them
+    // (mapdn_create refuses overlap together with the fused prologue).  On an error between fork and join the side stream is
+    // drained and the Sbus buffers are declared stale, so that the next call rebuilds them instead of reading a half-written one.
+    auto bail = [&](const char* what, hipError_t e) {
+      (void)hipStreamSynchronize(h->side);
+      h->sbus_stale = true;
+      h->err = std::string(what) + ": " + hipGetErrorString(e);
+      return MAPDN_E_HIP;
+    };
+    hipError_t e_;
+    if ((e_ = hipEventRecord(h->ev_fork, st)) != hipSuccess) return bail("hipEventRecord(fork)", e_);
+    if ((e_ = hipStreamWaitEvent(h->side, h->ev_fork, 0)) != hipSuccess) return bail("hipStreamWaitEvent(side, fork)", e_);
     launch_advance(d, add_noise, 1, 0, d.sb_off_alt, h->side);
-    HIPCHK(h, hipEventRecord(h->ev_join, h->side));
+    if ((e_ = hipEventRecord(h->ev_join, h->side)) != hipSuccess) return bail("hipEventRecord(join)", e_);
     nr_launch(h, MODE_STEP, reward, terminated, info, st);
-    HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+    if ((e_ = hipStreamWaitEvent(st, h->ev_join, 0)) != hipSuccess) return bail("hipStreamWaitEvent(join)", e_);
     launch_commit_fused(d, st);     // (with fused buses the side stream's profile rows race with this: overlap is an experiment switch)
     launch_advance(d, 0, 0, 1, d.sb_off_alt, st);
   } else {

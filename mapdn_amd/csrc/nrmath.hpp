@@ -41,10 +41,12 @@ NRMATH_FN void sincos_small(double x, double* s, double* c) {
 // solver launch 111 -> 100 us without it).  This form is ~35 instructions: Cody-Waite reduction by pi/2 in three FMAs (fdlibm's
 // pio2_1 / pio2_2 / pio2_3: exact products for |x| up to ~1e5 rad), the same Taylor pair on [-pi/4, pi/4] (remainders 8e-20 /
 // 2e-18), quadrant fix-up.  Within 1-2 ulp there; beyond ~1e5 rad it loses accuracy gracefully (finite values) — such an iterate is
-// diverging and ends in the non-convergence branch whatever its digits.  Every solver path uses THIS function for large steps, so
-// results stay bit-identical across launch geometries.
+// diverging and ends in the non-convergence branch whatever its digits.  Every k_nr_tree geometry uses THIS function for large steps, so
+// the tree solver's results stay bit-identical across launch geometries (k_nr_sparse / k_nr_dense call libm's sincos: they agree with
+// the tree solver to the last ulp or two, not to the bit — the tests compare them with the oracle, at 1e-9).
 NRMATH_FN void sincos_mid(double x, double* s, double* c) {
-  const double k = rint(x * 6.36619772367581382433e-01);       // 2 / pi
+  const double k = fmin(fmax(rint(x * 6.36619772367581382433e-01), -2.0e9), 2.0e9);   // 2 / pi; clamped: the (int) conversion below must not
+                                                                                      // depend on how a device saturates (|x| > 3e9 rad: garbage in, finite out)
   double r = fma(-k, 1.57079632673412561417e+00, x);
   r = fma(-k, 6.07710050630396597660e-11, r);
   r = fma(-k, 2.02226624871116645580e-21, r);

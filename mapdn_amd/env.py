@@ -341,7 +341,9 @@ class VoltageControlBatch:
         return vm, va, it, cv.bool()
 
     def ybus_dense(self):
-        out = np.zeros((self.n_bus, self.n_bus, 2))
+        """Ybus over the ELECTRICAL nodes (n_nodes x n_nodes; == buses unless closed bus-bus switches fuse some: include/mapdn.h)"""
+        nn = self.geometry()["n_nodes"]
+        out = np.zeros((nn, nn, 2))
         _lib.check(self._lib.mapdn_get_ybus_dense(self._h, _lib._p(out, _lib._pd)), self._h)
         return out[..., 0] + 1j * out[..., 1]
 

@@ -141,6 +141,12 @@ def test_fused_net_solve_and_episode_match_the_oracle(case, solver):
     B = 12
     env = VoltageControlBatch(net, prof, a, n_envs=B, device="cuda:0", obs_dtype=torch.float64, tuning=dict(nr_solver=solver if solver != "tree" else 0))
     assert env.n_bus == net.n_bus and env.geometry()["solver"] == dict(tree=0, sparse=1, dense=2)[solver]
+    # Ybus is exported over the electrical NODES (merged buses) — the Python accessor sizes its buffer accordingly
+    from oracle.pp_restated import make_ybus, reduced_net
+    red, _ = reduced_net(net)
+    yb = env.ybus_dense()
+    assert yb.shape == (red.n_bus, red.n_bus) and env.geometry()["n_nodes"] == red.n_bus < net.n_bus
+    assert np.abs(yb - make_ybus(red)[0].toarray()).max() < 1e-9
     pl, ql, pv, qs = inputs(net, prof, B, 2, SCALE[case])
     vm, va, it, cv = [x.cpu().numpy() for x in env.solve(pl, ql, pv, qs)]
     assert cv.all() and vm.shape == (B, net.n_bus)

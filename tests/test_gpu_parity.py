@@ -1086,3 +1086,23 @@ def test_xcd_aligned_env_order_changes_nothing(case, B):
         fa, fb = a.results(), b.results()
         assert all(torch.equal(fa[k], fb[k]) for k in fa)
     a.close(); b.close()
+
+
+def test_step_composition_switches_are_validated_for_every_solver():
+    """fuse_inject = 1 / overlap_advance / xcd_map exist on the tree solver only and used to be ignored silently on the
+    general solvers (their set-up returned before the check); overlap_advance was also a silent no-op beside the fused prologue."""
+    from mapdn_amd._lib import MapdnError
+    net, prof = make_case("case33")
+    for bad in (dict(nr_solver="sparse", fuse_inject=1), dict(nr_solver="dense", overlap_advance=1), dict(nr_solver="sparse", xcd_map=1)):
+        with pytest.raises(MapdnError, match="tree solver only"):
+            VoltageControlBatch(net, prof, args_for("case33"), n_envs=8, device="cuda:0", tuning=bad)
+    with pytest.raises(MapdnError, match="fuse_inject = 2"):
+        VoltageControlBatch(net, prof, args_for("case33"), n_envs=8, device="cuda:0", tuning=dict(overlap_advance=1))
+    a = VoltageControlBatch(net, prof, args_for("case33"), n_envs=8, device="cuda:0", obs_dtype=torch.float64, tuning=dict(overlap_advance=1, fuse_inject=2))
+    b = VoltageControlBatch(net, prof, args_for("case33"), n_envs=8, device="cuda:0", obs_dtype=torch.float64)
+    oa, _ = a.reset(); ob, _ = b.reset()
+    act = torch.full((8, net.n_sgen), 0.3, device="cuda:0", dtype=torch.float64)
+    for _ in range(3):
+        ra, ta, ia = a.step(act); rb, tb, ib = b.step(act)
+        assert torch.equal(ra, rb) and torch.equal(a.get_obs(), b.get_obs())
+    a.close(); b.close()
