@@ -87,3 +87,20 @@ def test_replay_buffers_on_device():
         buf.add_experience({"state": x, "done": torch.zeros(4096, 1, dtype=torch.bool, device="cuda:0")})
     b = buf.get_batch(1024)
     assert b["state"].is_cuda and b["state"].shape == (1024, 22, 58) and len(buf) == 1 << 16
+
+
+def test_non_wrapping_window_is_a_view_of_the_ring():
+    """round 5: a sampled window that does not wrap is handed out as views (no gathered copy: 7 % of the end-to-end loop at
+    32 x 8192 transitions); a wrapping one as a gathered copy — same values either way"""
+    import torch
+    from mapdn_amd.replay import TransReplayBuffer
+    buf = TransReplayBuffer(10)
+    for t in range(13):                                   # the ring has wrapped: oldest entry is t = 3 at ring position 3
+        buf.add_experience({"x": torch.full((1, 2), float(t)), "i": torch.tensor([t])})
+    assert len(buf) == 10
+    a = buf.get_batch(4, start=1)                         # entries t = 4..7: ring positions 4..7, no wrap
+    assert a["i"].tolist() == [4, 5, 6, 7] and a["x"].data_ptr() == buf.store["x"][4].data_ptr()
+    b = buf.get_batch(4, start=5)                         # entries t = 8..11: ring positions 8, 9, 0, 1 — wraps
+    assert b["i"].tolist() == [8, 9, 10, 11] and b["x"][:, 0].tolist() == [8.0, 9.0, 10.0, 11.0]
+    lo, hi = buf.store["x"].data_ptr(), buf.store["x"].data_ptr() + buf.store["x"].numel() * 4
+    assert not (lo <= b["x"].data_ptr() < hi)
