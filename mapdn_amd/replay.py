@@ -3,7 +3,7 @@
 The reference keeps Python lists of `Transition` namedtuples on the host
 (utilities/replay_buffer.py:5-58) — at most a few thousand entries, one env.  Here every field is
 ONE preallocated device tensor used as a ring, B transitions (one per env of a batch) are appended
-per call, and a sample is a view of the ring (a single `index_select` per field when the window wraps); nothing crosses to the host.  What is
+per call, and a sample is a view of the ring (two slices concatenated per field when the window wraps); nothing crosses to the host.  What is
 kept from the reference, exactly:
 
 * FIFO eviction: when the buffer is full the OLDEST entry is dropped (`offset()` = `pop(0)`,
@@ -80,11 +80,6 @@ class TransReplayBuffer:
         self._tail = (self._tail + overflow) % self.size
         self._len = min(self.size, self._len + n)
 
-    def _window(self, start: int, count: int) -> torch.Tensor:
-        base = (self._tail + start) % self.size
-        idx = torch.arange(base, base + count, device=self.device)
-        return idx % self.size if base + count > self.size else idx
-
     def get_single(self, index: int) -> Batch:
         if index < 0:
             index += self._len
@@ -110,8 +105,8 @@ class TransReplayBuffer:
             # env a gathered copy is 2.6 GB and 7 % of the training loop).  Valid until the next add_experience, which is how every
             # caller uses a batch (models/model.py:39-70: sample, update, drop); `.clone()` a field to keep it longer.
             return {k: v[base:base + batch_size] for k, v in self.store.items()}
-        idx = self._window(start, batch_size)
-        return {k: v.index_select(0, idx) for k, v in self.store.items()}
+        first = self.size - base                             # the window wraps: two contiguous pieces, copied at streaming rate
+        return {k: torch.cat((v[base:], v[:batch_size - first]), dim=0) for k, v in self.store.items()}
 
     def clear(self) -> None:
         self._tail = 0

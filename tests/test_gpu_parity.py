@@ -103,12 +103,16 @@ def test_solve_nonconvergence_flag():
     env.close()
 
 
-@pytest.mark.parametrize("case,barrier", [("case33", "bowl"), ("case141", "l1"), ("case322", "courant_beltrami"),
-                                          ("case33", "l2"), ("case33", "bump")])
-def test_episode_parity_with_noise(case, barrier):
+@pytest.mark.parametrize("case,barrier,tuning", [
+    ("case33", "bowl", None), ("case141", "l1", None), ("case322", "courant_beltrami", None), ("case33", "l2", None), ("case33", "bump", None),
+    # round 5: 4 envs per workgroup — the reward / commit epilogue on 64 resp. 32 workers, the per-env reductions by DPP row rotations
+    ("case141", "bowl", dict(nr_waves=4, nr_lanes=4)), ("case322", "bowl", dict(nr_waves=2, nr_lanes=4)), ("case33", "l1", dict(nr_waves=1, nr_lanes=4))])
+def test_episode_parity_with_noise(case, barrier, tuning):
     """reset -> steps with keyed noise: reward, terminated, 11 info values, obs, state, res_* tables"""
     B, T = 4, 8
-    net, prof, env = make(case, B, voltage_barrier_type=barrier)
+    net, prof, env = make(case, B, tuning=tuning, voltage_barrier_type=barrier)
+    if tuning:
+        assert env.geometry()["lanes"] == 4
     a = args_for(case, voltage_barrier_type=barrier)
     oracles = [VoltageControlOracle(net, prof, a, env_id=e, do_reset=False) for e in range(B)]
     obs, state = env.reset()
