@@ -293,3 +293,21 @@ def test_layernorm64_kernels_match_pytorch(rows, relu):
     y2 = _LayerNorm64.apply(x, w, b, 1e-5, relu)
     y2.backward(dy)
     assert torch.equal(w.grad, got[2]) and torch.equal(b.grad, got[3]) and torch.equal(x.grad, got[1])
+
+
+@pytest.mark.gpu
+def test_e2e_entry_point_runs_the_whole_loop():
+    """mapdn_amd.e2e.run — the function behind examples/train_ddpg.py and bench.py's `e2e` block (BASELINE configs[4]): rollout of B envs
+    through the HIP env, GPU replay (window views), MADDPG updates at the reference's intensity; one dict per episode with the phase
+    split.  Small shape: 64 envs of the 33-bus feeder, two 61-step episodes (one update round each)."""
+    from mapdn_amd import e2e
+    seen = []
+    lines = e2e.run(case="case33", envs=64, alg="maddpg", episodes=2, max_steps=61, intensity="reference", phases=True, on_line=seen.append)
+    assert len(lines) == 2 and seen == lines
+    for ln in lines:
+        assert ln["env_steps_per_s"] > 0 and abs(ln["sampled_transitions_per_env_step"] - 11 * 32 / 60) < 1e-12
+        assert ln["batch_size"] == 32 * 64 and ln["value_epochs"] == 10 and ln["policy_epochs"] == 1
+        ph = ln["phase_seconds"]
+        assert set(ph) == {"replay_insert", "sample", "value_update", "policy_update", "target_update", "rollout_and_host"}
+        assert ph["value_update"] > 0 and ph["policy_update"] > 0 and abs(sum(ln["phase_share"].values()) - 1.0) < 1e-3
+        assert np.isfinite(ln["mean_train_value_loss"]) and np.isfinite(ln["mean_train_policy_loss"])
