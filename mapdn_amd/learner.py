@@ -423,7 +423,7 @@ class PGTrainer:
         self.device = torch.device(device if device is not None else getattr(env, "device", "cpu"))
         target = DDPGNet(args, alg).to(self.device) if args.target else None
         self.behaviour_net = DDPGNet(args, alg, target).to(self.device)
-        self.replay_buffer = TransReplayBuffer(int(args.replay_buffer_size), device=self.device)
+        self.replay_buffer = TransReplayBuffer(int(args.replay_buffer_size), device=self.device, window=int(args.batch_size))   # windows are views
         rms = dict(alpha=0.99, eps=1e-5)                                                   # trainer.py:26-27
         self.policy_optimizer = torch.optim.RMSprop(self.behaviour_net.policy_dicts.parameters(), lr=args.policy_lrate, **rms)
         self.value_optimizer = torch.optim.RMSprop(self.behaviour_net.value_dicts.parameters(), lr=args.value_lrate, **rms)

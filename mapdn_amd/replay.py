@@ -31,10 +31,16 @@ Batch = Dict[str, torch.Tensor]
 
 
 class TransReplayBuffer:
-    """Ring of `size` transitions; every field of a transition is a tensor [...], stored as [size, ...]."""
+    """Ring of `size` transitions; every field of a transition is a tensor [...], stored as [size (+ window), ...].
 
-    def __init__(self, size: int, device=None):
+    `window` > 0 appends a MIRROR of the first `window` ring positions behind the ring (every insertion into those positions is
+    written twice), so that a sampled window of up to `window` transitions is always one contiguous slice — a view, never a copy —
+    also when it wraps around the ring.  The learner sets it to its batch size (at 32 x 8192 transitions of the 322-bus env a
+    gathered batch is 10 GB of copies)."""
+
+    def __init__(self, size: int, device=None, window: int = 0):
         self.size = int(size)
+        self.window = max(0, min(int(window), self.size))
         if self.size <= 0:
             raise ValueError("replay buffer size must be positive")
         self.device = torch.device(device) if device is not None else None
@@ -54,7 +60,7 @@ class TransReplayBuffer:
     def _allocate(self, trans: Batch) -> None:
         for k, v in trans.items():
             dev = self.device if self.device is not None else v.device
-            self.store[k] = torch.empty((self.size,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev)
+            self.store[k] = torch.empty((self.size + self.window,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev)
         if self.device is None:
             self.device = next(iter(self.store.values())).device
 
@@ -76,6 +82,13 @@ class TransReplayBuffer:
             dst[head:head + first].copy_(v[skip:skip + first])
             if n > first:
                 dst[0:n - first].copy_(v[skip + first:B])
+            if self.window:                       # ring positions below `window` live a second time behind the ring
+                if head < self.window:
+                    m = min(first, self.window - head)
+                    dst[self.size + head:self.size + head + m].copy_(v[skip:skip + m])
+                if n > first:
+                    m = min(n - first, self.window)
+                    dst[self.size:self.size + m].copy_(v[skip + first:skip + first + m])
         overflow = max(0, self._len + n - self.size)
         self._tail = (self._tail + overflow) % self.size
         self._len = min(self.size, self._len + n)
@@ -100,13 +113,13 @@ class TransReplayBuffer:
         elif not 0 <= start < sample_range:
             raise IndexError(f"window start {start} outside [0, {sample_range})")
         base = (self._tail + start) % self.size
-        if base + batch_size <= self.size:
+        if base + batch_size <= self.size or (base + batch_size <= self.size + self.window and batch_size <= self.window):
             # the window does not wrap around the ring: hand out VIEWS of the ring (no copy — at 32 x 8192 transitions of the 322-bus
             # env a gathered copy is 2.6 GB and 7 % of the training loop).  Valid until the next add_experience, which is how every
             # caller uses a batch (models/model.py:39-70: sample, update, drop); `.clone()` a field to keep it longer.
             return {k: v[base:base + batch_size] for k, v in self.store.items()}
-        first = self.size - base                             # the window wraps: two contiguous pieces, copied at streaming rate
-        return {k: torch.cat((v[base:], v[:batch_size - first]), dim=0) for k, v in self.store.items()}
+        first = self.size - base                             # the window wraps (and no mirror covers it): two contiguous pieces, copied
+        return {k: torch.cat((v[base:self.size], v[:batch_size - first]), dim=0) for k, v in self.store.items()}
 
     def clear(self) -> None:
         self._tail = 0

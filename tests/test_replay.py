@@ -104,3 +104,29 @@ def test_non_wrapping_window_is_a_view_of_the_ring():
     assert b["i"].tolist() == [8, 9, 10, 11] and b["x"][:, 0].tolist() == [8.0, 9.0, 10.0, 11.0]
     lo, hi = buf.store["x"].data_ptr(), buf.store["x"].data_ptr() + buf.store["x"].numel() * 4
     assert not (lo <= b["x"].data_ptr() < hi)
+
+
+def test_mirrored_ring_makes_every_window_a_view():
+    """TransReplayBuffer(size, window=w): the first w ring positions are mirrored behind the ring, so a window that wraps is still one
+    slice.  Same contents as the plain ring for every start, through several wrap-arounds and multi-transition insertions."""
+    import torch
+    from mapdn_amd.replay import TransReplayBuffer
+    rng = np.random.default_rng(0)
+    plain, mir = TransReplayBuffer(12), TransReplayBuffer(12, window=5)
+    nxt = 0
+    for step in range(40):
+        b = int(rng.integers(1, 5))
+        t = {"x": torch.arange(nxt, nxt + b, dtype=torch.float32).view(b, 1).repeat(1, 3), "i": torch.arange(nxt, nxt + b)}
+        nxt += b
+        plain.add_experience(t); mir.add_experience({k: v.clone() for k, v in t.items()})
+        assert len(plain) == len(mir)
+        for w in (1, 3, 5):
+            if len(mir) < w:
+                continue
+            for start in range(len(mir) - w + 1):
+                a, m = plain.get_batch(w, start=start), mir.get_batch(w, start=start)
+                assert torch.equal(a["i"], m["i"]) and torch.equal(a["x"], m["x"])
+                lo = mir.store["x"].data_ptr()
+                assert lo <= m["x"].data_ptr() < lo + mir.store["x"].numel() * 4        # always a view
+    big = mir.get_batch(7, start=0)                       # wider than the mirror: still correct (copied when it wraps)
+    assert torch.equal(big["i"], plain.get_batch(7, start=0)["i"])
