@@ -113,6 +113,47 @@ class _LayerNorm64(torch.autograd.Function):
         return dx.view(ctx.shape), dw, db, None, None
 
 
+class _TallLinear(torch.autograd.Function):
+    """y = x W^T + b for x of MILLIONS of rows and a small weight (the 64 -> 64 and 64 -> 1 layers of the critic / agent trunks on a
+    batch of 32 x 8192 transitions x 38 agents = 10 M rows).  Forward and dX are ordinary GEMMs; the WEIGHT gradient dW = dy^T x is a
+    [out, in] product with the 10 M rows as its reduction dimension — the BLAS back end runs it on two workgroups (8.4 ms and 5.6 ms
+    per call, the two largest GEMM entries of profiles/e2e/r04_e2e_reference_kernel_stats.txt, against 1.3 ms for the forward).  Here
+    the rows are cut into blocks whose partial products are one batched GEMM, then summed (split-K by hand): same sum, other order."""
+
+    BLOCK_ROWS = 16384
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dy @ weight
+        if ctx.needs_input_grad[1]:
+            rows, blk = x.shape[0], _TallLinear.BLOCK_ROWS
+            full = rows // blk * blk
+            dy2, x2 = dy.reshape(rows, -1), x.reshape(rows, -1)
+            dw = torch.bmm(dy2[:full].view(-1, blk, dy2.shape[1]).transpose(1, 2), x2[:full].view(-1, blk, x2.shape[1])).sum(0)
+            if full < rows:
+                dw = dw + dy2[full:].t() @ x2[full:]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.reshape(-1, dy.shape[-1]).sum(0)
+        return dx, dw, db
+
+
+def tall_linear(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """lin(x); with the hand-split weight gradient when x is a tall 2-D batch on the GPU (>= 2^18 rows, <= 128 features each way)"""
+    if (x.is_cuda and x.dim() == 2 and x.shape[0] >= (1 << 18) and lin.in_features <= 128 and lin.out_features <= 128
+            and torch.is_grad_enabled() and lin.weight.requires_grad and os.environ.get("MAPDN_TALL_LINEAR", "1") != "0"):
+        return _TallLinear.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
 def layernorm_act(ln: nn.LayerNorm, act, x: torch.Tensor) -> torch.Tensor:
     """act(LayerNorm(x)): one HIP launch each way for the reference's default shape (64 features, ReLU, fp32, on the GPU), the
     PyTorch modules otherwise (MAPDN_FUSED_LN=0 forces them)."""
@@ -140,7 +181,7 @@ class RNNAgent(nn.Module):
         """x: pre-activation of fc1, [rows, hid]"""
         x = layernorm_act(self.layernorm, self.act, x) if self.use_ln else self.act(x)
         h = self.rnn(x, hidden.reshape(-1, self.hid_size))
-        return self.fc2(h), h
+        return tall_linear(self.fc2, h), h
 
     def forward(self, inputs, hidden):
         a, h = self.trunk(self.fc1(inputs), hidden)
@@ -162,8 +203,8 @@ class MLPCritic(nn.Module):
 
     def trunk(self, x: torch.Tensor):
         x = layernorm_act(self.layernorm, self.act, x) if self.use_ln else self.act(x)
-        h = self.act(self.fc2(x))
-        return self.fc3(h), h
+        h = self.act(tall_linear(self.fc2, x))
+        return tall_linear(self.fc3, h), h
 
     def forward(self, inputs, hidden=None):
         return self.trunk(self.fc1(inputs))

@@ -311,3 +311,24 @@ def test_e2e_entry_point_runs_the_whole_loop():
         assert set(ph) == {"replay_insert", "sample", "value_update", "policy_update", "target_update", "rollout_and_host"}
         assert ph["value_update"] > 0 and ph["policy_update"] > 0 and abs(sum(ln["phase_share"].values()) - 1.0) < 1e-3
         assert np.isfinite(ln["mean_train_value_loss"]) and np.isfinite(ln["mean_train_policy_loss"])
+
+
+def test_tall_linear_weight_gradient_is_the_plain_one(monkeypatch):
+    """round 5: the weight gradient of the trunk's small layers on a batch of millions of rows is computed block-wise (split-K by hand:
+    the BLAS back end runs a [64, 64] product with 10 M rows of reduction on two workgroups).  Same forward, same gradients."""
+    from mapdn_amd.learner import _TallLinear
+    monkeypatch.setattr(_TallLinear, "BLOCK_ROWS", 64)
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 5).double()
+    x = torch.randn(1000, 64, dtype=torch.float64, requires_grad=True)       # 15 full blocks + a remainder of 40 rows
+    y = _TallLinear.apply(x, lin.weight, lin.bias)
+    (y ** 2).sum().backward()
+    got = (lin.weight.grad.clone(), lin.bias.grad.clone(), x.grad.clone())
+    lin.zero_grad(); x.grad = None
+    y2 = lin(x)
+    (y2 ** 2).sum().backward()
+    assert torch.equal(y, y2) and torch.allclose(got[0], lin.weight.grad, rtol=0, atol=1e-11)
+    assert torch.equal(got[1], lin.bias.grad) and torch.equal(got[2], x.grad)
+    assert torch.autograd.gradcheck(lambda a, w, b: _TallLinear.apply(a, w, b),
+                                    (torch.randn(130, 8, dtype=torch.float64, requires_grad=True), torch.randn(3, 8, dtype=torch.float64, requires_grad=True),
+                                     torch.randn(3, dtype=torch.float64, requires_grad=True)))
