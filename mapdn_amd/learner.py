@@ -435,8 +435,11 @@ class DDPGNet(nn.Module):
             policy_loss = wmean(-advantages)
         if "value" in want:
             with torch.no_grad():
-                _, next_actions, _, _, _ = self.get_actions(next_state, "train", False, avail,
-                                                            not self.args.double_q, hid)
+                if "next_action_cached" in batch:                # PGTrainer precomputed them for the whole replay ring (same values)
+                    next_actions = batch["next_action_cached"]
+                else:
+                    _, next_actions, _, _, _ = self.get_actions(next_state, "train", False, avail,
+                                                                not self.args.double_q, hid)
                 next_values = self.target_net.value(next_state, next_actions).view(-1, n)
                 returns = rewards + self.args.gamma * (1 - done) * next_values
             values = self.value(state, actions).view(-1, n)
@@ -559,14 +562,45 @@ class PGTrainer:
         with self._phase("policy_update"):
             self.policy_transition_process(stat, batch)
 
+    def _cache_next_actions(self) -> bool:
+        """The value loss needs pi(next_state) of every sampled transition (maddpg.py:103-125).  The value epochs of one update round
+        (models/model.py:46-49: ten of them) train the CRITIC only, so the policy that produces those actions does not change between
+        them, and their windows overlap heavily (32 of the ring's 64 steps each): the actions are computed ONCE for the whole ring —
+        two policy forwards instead of ten — and handed out with the sampled windows as one more (temporary) field of the replay
+        store.  Same kernel, same inputs, same values.  MAPDN_CACHE_NEXT_ACTIONS=0 disables it."""
+        rb, net, a = self.replay_buffer, self.behaviour_net, self.args
+        if not isinstance(rb, TransReplayBuffer) or os.environ.get("MAPDN_CACHE_NEXT_ACTIONS", "1") == "0" or len(rb) == 0:
+            return False
+        st = rb.store
+        if not all(k in st for k in ("next_state", "action_avail", "hid", "action")):
+            return False
+        n_ring = rb.size if len(rb) == rb.size else len(rb)      # (the ring fills from position 0: a partly filled ring is [0, len))
+        cache = torch.empty_like(st["action"])
+        chunk = max(int(a.batch_size), 1)
+        with torch.no_grad():
+            for lo in range(0, n_ring, chunk):
+                hi = min(lo + chunk, n_ring)
+                _, na, _, _, _ = net.get_actions(st["next_state"][lo:hi], "train", False, st["action_avail"][lo:hi], not a.double_q, st["hid"][lo:hi])
+                cache[lo:hi] = na
+            if rb.window:
+                m = min(rb.window, n_ring)
+                cache[rb.size:rb.size + m] = cache[:m]
+        st["next_action_cached"] = cache
+        return True
+
     def transition_update(self, trans: Batch, stat):
         """models/model.py:39-70 with replay=True, mixer=False"""
         a = self.args
         with self._phase("replay_insert"):
             self.replay_buffer.add_experience(trans)
         if self.steps > a.replay_warmup and len(self.replay_buffer) >= a.batch_size and self.steps % a.behaviour_update_freq == 0:
-            for _ in range(a.value_update_epochs):
-                self.value_replay_process(stat)
+            cached = a.value_update_epochs > 1 and self._cache_next_actions()
+            try:
+                for _ in range(a.value_update_epochs):
+                    self.value_replay_process(stat)
+            finally:
+                if cached:
+                    del self.replay_buffer.store["next_action_cached"]
             for _ in range(a.policy_update_epochs):
                 self.policy_replay_process(stat)
         if a.target and self.steps % a.target_update_freq == 0:

@@ -332,3 +332,30 @@ def test_tall_linear_weight_gradient_is_the_plain_one(monkeypatch):
     assert torch.autograd.gradcheck(lambda a, w, b: _TallLinear.apply(a, w, b),
                                     (torch.randn(130, 8, dtype=torch.float64, requires_grad=True), torch.randn(3, 8, dtype=torch.float64, requires_grad=True),
                                      torch.randn(3, dtype=torch.float64, requires_grad=True)))
+
+
+@pytest.mark.parametrize("alg", ["maddpg", "iddpg"])
+def test_cached_next_actions_train_the_same_network(alg, monkeypatch):
+    """round 5: the value epochs of one update round read pi(next_state) from a per-round cache over the whole replay ring (the policy
+    does not change while the critic trains) instead of running the policy once per epoch.  Bit-identical training: two seeded runs,
+    cache on / off, end in the same state_dict — through several rounds, a wrapping ring, the mirror region and a partly filled ring."""
+    def run(cache):
+        monkeypatch.setenv("MAPDN_CACHE_NEXT_ACTIONS", "1" if cache else "0")
+        torch.manual_seed(0); np.random.seed(0)
+        env = _ToyEnv(4, 3, 5)
+        args = make_alg_args(3, 5, 1, hid_size=16, max_steps=12, batch_size=8, replay_buffer_size=28,
+                             behaviour_update_freq=4, target_update_freq=6, value_update_epochs=3, num_eval_episodes=4)
+        tr = PGTrainer(args, alg, env, device="cpu", data_parallel=False)
+        seen = []
+        orig = tr._cache_next_actions
+        tr._cache_next_actions = lambda: (seen.append(1), orig())[1]
+        stat = {}
+        for ep in range(3):
+            tr.train_process(stat)
+        assert "next_action_cached" not in tr.replay_buffer.store       # removed after every round
+        return {k: v.clone() for k, v in tr.behaviour_net.state_dict().items()}, len(seen), stat["mean_train_value_loss"]
+    a, na, la = run(True)
+    b, nb, lb = run(False)
+    assert na == nb >= 6 and la == lb
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
