@@ -148,10 +148,50 @@ class _TallLinear(torch.autograd.Function):
 
 def tall_linear(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     """lin(x); with the hand-split weight gradient when x is a tall 2-D batch on the GPU (>= 2^18 rows, <= 128 features each way)"""
-    if (x.is_cuda and x.dim() == 2 and x.shape[0] >= (1 << 18) and lin.in_features <= 128 and lin.out_features <= 128
-            and torch.is_grad_enabled() and lin.weight.requires_grad and os.environ.get("MAPDN_TALL_LINEAR", "1") != "0"):
+    if x.dim() == 2 and _tall_ok(x, x.shape[0], lin.weight):
         return _TallLinear.apply(x, lin.weight, lin.bias)
     return lin(x)
+
+
+def _tall_ok(x: torch.Tensor, rows: int, weight: torch.Tensor) -> bool:
+    return (x.is_cuda and rows >= (1 << 18) and weight.shape[0] <= 256 and weight.shape[1] <= 128 and torch.is_grad_enabled()
+            and weight.requires_grad and os.environ.get("MAPDN_TALL_LINEAR", "1") != "0")
+
+
+_GRU_FUSED_OK: Dict[str, bool] = {}
+
+
+def _gru_fused_ok(device) -> bool:
+    """one-time self-check of the route gru_cell_tall takes (input / hidden projections as _TallLinear, then ATen's fused GRU cell on
+    the pre-computed gates) against nn.GRUCell, values and gradients; any exception or mismatch disables the route for the process"""
+    key = str(device)
+    if key not in _GRU_FUSED_OK:
+        ok = False
+        try:
+            g = torch.Generator(device="cpu").manual_seed(1)
+            cell = nn.GRUCell(8, 8).to(device)
+            x = torch.randn(32, 8, generator=g).to(device).requires_grad_(True)
+            h = torch.randn(32, 8, generator=g).to(device).requires_grad_(True)
+            ref = cell(x, h)
+            gr = torch.autograd.grad(ref.square().sum(), [x, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh])
+            out = torch.ops.aten._thnn_fused_gru_cell(_TallLinear.apply(x, cell.weight_ih, None), _TallLinear.apply(h, cell.weight_hh, None),
+                                                      h, cell.bias_ih, cell.bias_hh)[0]
+            go = torch.autograd.grad(out.square().sum(), [x, h, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh])
+            ok = bool(torch.allclose(out, ref, rtol=1e-5, atol=1e-6)) and all(bool(torch.allclose(a, b, rtol=1e-4, atol=1e-5)) for a, b in zip(go, gr))
+        except Exception:                      # noqa: BLE001 — an ATen signature change must not break training: the stock cell is used
+            ok = False
+        _GRU_FUSED_OK[key] = ok
+    return _GRU_FUSED_OK[key]
+
+
+def gru_cell_tall(rnn: nn.GRUCell, x: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+    """rnn(x, h); on a tall GPU batch under autograd the two projections go through _TallLinear (their weight gradients are products
+    with millions of rows of reduction) and ATen's fused cell does the gate arithmetic, as inside nn.GRUCell"""
+    if x.dim() == 2 and _tall_ok(x, x.shape[0], rnn.weight_ih) and rnn.bias and _gru_fused_ok(x.device):
+        ig = _TallLinear.apply(x, rnn.weight_ih, None)
+        hg = _TallLinear.apply(h, rnn.weight_hh, None)
+        return torch.ops.aten._thnn_fused_gru_cell(ig, hg, h, rnn.bias_ih, rnn.bias_hh)[0]
+    return rnn(x, h)
 
 
 def layernorm_act(ln: nn.LayerNorm, act, x: torch.Tensor) -> torch.Tensor:
@@ -180,7 +220,7 @@ class RNNAgent(nn.Module):
     def trunk(self, x: torch.Tensor, hidden: torch.Tensor):
         """x: pre-activation of fc1, [rows, hid]"""
         x = layernorm_act(self.layernorm, self.act, x) if self.use_ln else self.act(x)
-        h = self.rnn(x, hidden.reshape(-1, self.hid_size))
+        h = gru_cell_tall(self.rnn, x, hidden.reshape(-1, self.hid_size))
         return tall_linear(self.fc2, h), h
 
     def forward(self, inputs, hidden):
@@ -303,7 +343,10 @@ class DDPGNet(nn.Module):
         if self.args.shared_params:
             ag = self.policy_dicts[0]
             w = ag.fc1.weight
-            x = F.linear(obs, w[:, :o], ag.fc1.bias)                     # observation columns
+            if _tall_ok(obs, b * n, w):                                  # (the policy update on a replay batch: weight gradient over b * n rows)
+                x = _TallLinear.apply(obs.reshape(b * n, o), w[:, :o], ag.fc1.bias).view(b, n, -1)
+            else:
+                x = F.linear(obs, w[:, :o], ag.fc1.bias)                 # observation columns
             if self.args.agent_id:
                 x = x + w[:, o:].t().unsqueeze(0)                        # one-hot id i selects column o + i
             means, hid = ag.trunk(x.reshape(b * n, -1), last_hid)

@@ -359,3 +359,36 @@ def test_cached_next_actions_train_the_same_network(alg, monkeypatch):
     assert na == nb >= 6 and la == lb
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_tall_batch_routes_give_the_stock_gradients(monkeypatch):
+    """round 5, on the GPU at a size that takes the tall routes (b * n = 2^18 rows): the policy loss and the value loss of one batch,
+    with MAPDN_TALL_LINEAR on / off — split-K weight gradients in the critic and agent trunks, the policy's first layer, the GRU cell
+    through ATen's fused cell on pre-computed gates — same losses, gradients equal to f32 summation-order accuracy."""
+    from mapdn_amd.learner import _gru_fused_ok
+    dev = torch.device("cuda:0")
+    n, o, h, bs = 32, 20, 64, 8192
+    assert _gru_fused_ok(dev)
+    torch.manual_seed(3)
+    args = make_alg_args(n, o, 1, hid_size=h, reward_normalisation=False)
+    net = DDPGNet(args, "maddpg").to(dev)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)      # noqa: E731
+    batch = dict(state=r(bs, n, o), action=torch.tanh(r(bs, n, 1)), reward=r(bs, 1).expand(bs, n).contiguous(), next_state=r(bs, n, o),
+                 done=(torch.rand(bs, 1, generator=g) < 0.2).float().to(dev), last_step=torch.zeros(bs, 1, device=dev),
+                 action_avail=torch.ones(bs, n, 1, device=dev), last_hid=0.3 * r(bs, n, h), hid=0.3 * r(bs, n, h))
+    params = [p for p in net.parameters() if p.requires_grad]
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MAPDN_TALL_LINEAR", flag)
+        pl, vl, _ = net.get_loss(batch)
+        gp = torch.autograd.grad(pl, params, retain_graph=True, allow_unused=True)
+        gv = torch.autograd.grad(vl, params, allow_unused=True)
+        res[flag] = (pl.item(), vl.item(), gp, gv)
+    assert abs(res["1"][0] - res["0"][0]) < 1e-6 and abs(res["1"][1] - res["0"][1]) < 1e-6
+    for which in (2, 3):
+        for a, b in zip(res["1"][which], res["0"][which]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.allclose(a, b, rtol=2e-3, atol=2e-6), (which, (a - b).abs().max().item(), b.abs().max().item())
