@@ -372,13 +372,13 @@ def test_tall_batch_routes_give_the_stock_gradients(monkeypatch):
     assert _gru_fused_ok(dev)
     torch.manual_seed(3)
     args = make_alg_args(n, o, 1, hid_size=h, reward_normalisation=False)
-    net = DDPGNet(args, "maddpg").to(dev)
+    net = DDPGNet(args, "maddpg", DDPGNet(args, "maddpg").to(dev)).to(dev)
     g = torch.Generator(device="cpu").manual_seed(5)
     r = lambda *s: torch.randn(*s, generator=g).to(dev)      # noqa: E731
     batch = dict(state=r(bs, n, o), action=torch.tanh(r(bs, n, 1)), reward=r(bs, 1).expand(bs, n).contiguous(), next_state=r(bs, n, o),
                  done=(torch.rand(bs, 1, generator=g) < 0.2).float().to(dev), last_step=torch.zeros(bs, 1, device=dev),
                  action_avail=torch.ones(bs, n, 1, device=dev), last_hid=0.3 * r(bs, n, h), hid=0.3 * r(bs, n, h))
-    params = [p for p in net.parameters() if p.requires_grad]
+    params = [p for name, p in net.named_parameters() if p.requires_grad and not name.startswith("target_net")]
     res = {}
     for flag in ("1", "0"):
         monkeypatch.setenv("MAPDN_TALL_LINEAR", flag)
