@@ -74,8 +74,22 @@ def _inputs(net, prof, B, seed):
 
 @pytest.mark.parametrize("name", list(SHAPES))
 def test_host_plan_of_unusual_shapes(name):
+    _check_host_plan(name, *SHAPES[name])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_host_plan_of_random_trees(seed):
+    """24 random feeders, 2 ... 120 buses, from pure chains (attach to the newest bus) to near-stars (attach to a random old bus):
+    the same host-plan checks as the named shapes"""
+    rng = np.random.default_rng(1000 + seed)
+    nb = int(rng.integers(2, 121))
+    chaininess = rng.random()
+    parent = [-1] + [int(i - 1 if rng.random() < chaininess else rng.integers(0, i)) for i in range(1, nb)]
+    _check_host_plan(f"rand{seed}", *feeder(f"rand{seed}", parent, n_sgen=int(rng.integers(1, 5)), seed=seed))
+
+
+def _check_host_plan(name, net, prof):
     lib = _lib.load()
-    net, prof = SHAPES[name]
     cn, keep = _lib.make_cnetspec(net)
     cc = _lib.make_cconfig(ARGS)
     h = C.c_void_p()
