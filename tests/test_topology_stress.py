@@ -81,11 +81,7 @@ def test_host_plan_of_unusual_shapes(name):
 def test_host_plan_of_random_trees(seed):
     """24 random feeders, 2 ... 120 buses, from pure chains (attach to the newest bus) to near-stars (attach to a random old bus):
     the same host-plan checks as the named shapes"""
-    rng = np.random.default_rng(1000 + seed)
-    nb = int(rng.integers(2, 121))
-    chaininess = rng.random()
-    parent = [-1] + [int(i - 1 if rng.random() < chaininess else rng.integers(0, i)) for i in range(1, nb)]
-    _check_host_plan(f"rand{seed}", *feeder(f"rand{seed}", parent, n_sgen=int(rng.integers(1, 5)), seed=seed))
+    _check_host_plan(f"rand{seed}", *_random_tree(seed))
 
 
 def _check_host_plan(name, net, prof):
@@ -166,6 +162,34 @@ def test_tree_solver_on_unusual_shapes(name):
         else:                                                  # every geometry: the same bits
             ok = ref[3].astype(bool)
             assert np.array_equal(it, ref[2]) and np.array_equal(cv, ref[3]) and np.array_equal(vm[ok], ref[0][ok]) and np.array_equal(va[ok], ref[1][ok]), tuning
+
+
+def _random_tree(seed):
+    rng = np.random.default_rng(1000 + seed)
+    nb = int(rng.integers(2, 121))
+    chaininess = rng.random()
+    parent = [-1] + [int(i - 1 if rng.random() < chaininess else rng.integers(0, i)) for i in range(1, nb)]
+    return feeder(f"rand{seed}", parent, n_sgen=int(rng.integers(1, 5)), seed=seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(0, 24, 2))
+def test_tree_solver_on_random_trees(seed):
+    """twelve of the random feeders of test_host_plan_of_random_trees through the solver (default geometry) against the oracle"""
+    import torch
+    from mapdn_amd.env import VoltageControlBatch
+    from tests.edge_rule import same_newton_count
+    net, prof = _random_tree(seed)
+    B = 24
+    ins = _inputs(net, prof, B, 11 + seed)
+    env = VoltageControlBatch(net, prof, ARGS, n_envs=B, device="cuda:0", obs_dtype=torch.float64)
+    vm, va, it, cv = [t.cpu().numpy() for t in env.solve(*ins)]
+    env.close()
+    for e in range(B):
+        r = runpp_restated(net, ins[0][e], ins[1][e], ins[2][e], ins[3][e])
+        assert same_newton_count(net, tuple(x[e] for x in ins), it[e], cv[e], r), (seed, e, it[e], r.iterations)
+        if r.converged and cv[e]:
+            assert np.abs(vm[e] - r.vm_pu).max() < 1e-9 and np.abs(va[e] - r.va_degree).max() < 1e-7
 
 
 @pytest.mark.gpu
