@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE: kept as the record of how the experiment was run — the debug library / switch it uses (lib_ab32.so, MAPDN_NR_PAIRS, lib_defer.so) was removed
+# again once the result was in profiles/ (f32 mirror: r05_f32_obs_mirror_ab.txt; chain pairs: commit 2ce82a4 + r05_chain_pair_fusion_experiment.txt;
+# deferred update: r05_xprop_deferred_update_ab.txt).  It does not run against the current tree.
 # round 5, question 4: what would an f32 obs mirror buy?  Timing A/B with the debug library mapdn_amd/lib_ab32.so (built with
 # MAPDN_EXTRA_FLAGS="-DMAPDN_DEBUG_BUILD -DMAPDN_AB_F32MIRROR"): the obs gather reading 4-byte columns, the commit rows writing the
 # mirror.  Same box, same process order, alternating.

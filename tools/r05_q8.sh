@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE: kept as the record of how the experiment was run — the debug library / switch it uses (lib_ab32.so, MAPDN_NR_PAIRS, lib_defer.so) was removed
+# again once the result was in profiles/ (f32 mirror: r05_f32_obs_mirror_ab.txt; chain pairs: commit 2ce82a4 + r05_chain_pair_fusion_experiment.txt;
+# deferred update: r05_xprop_deferred_update_ab.txt).  It does not run against the current tree.
 # round 5: x-propagation backward sweep with the voltage update deferred into the next row's shadow (instead of the update pass) — A/B
 mkdir -p gpurun_out; O=gpurun_out/r05_q8.txt; : > $O
 L=$PWD/mapdn_amd/lib_defer.so
