@@ -47,6 +47,7 @@ int main(void) {
 
   mapdn_dims_t d;
   if (mapdn_dims(h, &d) != MAPDN_OK) return 2;
+  printf("library built from sources with %s\n", mapdn_build_info());
   printf("n_envs %d n_bus %d n_line %d n_load %d n_sgen %d n_agents %d obs_size %d state_size %d radial %d\n",
          d.n_envs, d.n_bus, d.n_line, d.n_load, d.n_sgen, d.n_agents, d.obs_size, d.state_size, d.is_radial);
 

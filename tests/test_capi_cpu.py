@@ -247,6 +247,8 @@ def test_header_is_plain_c_and_usable_from_a_c_host(lib, tmp_path):
                     "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "n_bus 5" in out and "radial 1" in out and "n_agents 2" in out
+    from mapdn_amd import build
+    assert "MAPDN_SRC_HASH=" + build.source_hash() in out
     assert "mapdn_reset on a host-only handle -> -4" in out
 
 
