@@ -346,6 +346,15 @@ int mapdn_layernorm64_backward_blocks(int64_t rows);
 int mapdn_layernorm64_backward(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean,
                                const float* rstd, float* dx, float* dgamma, float* dbeta, float* partial, int64_t rows,
                                int32_t relu, void* stream);
+/* ... with every input row FORMED as base[row / n] + per_n[row % n] instead of read (base [rows / n][64], per_n [n][64], rows a multiple
+ * of n): the central critic's first layer feeds the LayerNorm  W_obs·obs_all + b  per batch element plus the id column of the agent
+ * (critics/mlp_critic.py:22-27 behind models/maddpg.py:35-79), and the [batch, agents, 64] tensor of their sum is never materialised.
+ * _bc_backward returns dx per formed row; the caller reduces it over the agents / over the batch. */
+int mapdn_layernorm64_bc_forward(const float* base, const float* per_n, int32_t n, const float* gamma, const float* beta, float* y,
+                                 float* mean, float* rstd, int64_t rows, float eps, int32_t relu, void* stream);
+int mapdn_layernorm64_bc_backward(const float* dy, const float* base, const float* per_n, int32_t n, const float* gamma, const float* beta,
+                                  const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta, float* partial,
+                                  int64_t rows, int32_t relu, void* stream);
 
 /* Calibration aid for the HBM counters (tools/calibrate_traffic.py): copies rows x Bp x 16 bytes from src to dst (device pointers) with
  * the solver's own global access pattern — raw-buffer 16-byte loads / stores of env-minor pair rows, 256 contiguous bytes per

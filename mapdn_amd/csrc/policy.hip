@@ -175,14 +175,19 @@ k_policy_fwd(const float* __restrict__ obs, const float* __restrict__ hid_in, co
 // (dy masked by the ReLU), dgamma / dbeta as per-thread column sums over a grid-stride loop, reduced per block in LDS and
 // across blocks by a second tiny launch in a fixed order (no atomics: deterministic).
 // =====================================================================================================================
-template <bool RELU>
+// BC ("broadcast input"): the row is not read but FORMED as x[row / n] + xn[row % n] — the central critic's first layer hands the
+// LayerNorm base[b] + id_column[agent] (learner.py::_value_central): the [b, n, 64] tensor is never written or read (2 x 2.7 GB per
+// forward at 10 M rows).  One f32 add, the one PyTorch's broadcast add performs: same bits as the materialised route.
+template <bool RELU, bool BC>
 __global__ void __launch_bounds__(256)
-k_ln64_fwd(const f4* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, f4* __restrict__ y,
-           float* __restrict__ mean, float* __restrict__ rstd, long rows, float eps) {
+k_ln64_fwd(const f4* __restrict__ x, const f4* __restrict__ xn, int n, const float* __restrict__ gamma, const float* __restrict__ beta,
+           f4* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long rows, float eps) {
   const int l16 = threadIdx.x & 15;
   const f4 g = ((const f4*)gamma)[l16], b = ((const f4*)beta)[l16];
   for (long row = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; row < rows; row += ((long)gridDim.x * 256) >> 4) {
-    const f4 v = x[row * 16 + l16];
+    f4 v;
+    if (BC) { const long q = row / n; v = x[q * 16 + l16] + xn[(row - q * n) * 16 + l16]; }
+    else v = x[row * 16 + l16];
     const float mu = row_sum16((v.x + v.y) + (v.z + v.w)) * (1.0f / 64.0f);
     const f4 dv = v - mu;
     const float var = row_sum16((dv.x * dv.x + dv.y * dv.y) + (dv.z * dv.z + dv.w * dv.w)) * (1.0f / 64.0f);
@@ -196,16 +201,19 @@ k_ln64_fwd(const f4* __restrict__ x, const float* __restrict__ gamma, const floa
   }
 }
 
-template <bool RELU>
+template <bool RELU, bool BC>
 __global__ void __launch_bounds__(256)
-k_ln64_bwd(const f4* __restrict__ dy, const f4* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-           const float* __restrict__ mean, const float* __restrict__ rstd, f4* __restrict__ dx, float* __restrict__ partial, long rows) {
+k_ln64_bwd(const f4* __restrict__ dy, const f4* __restrict__ x, const f4* __restrict__ xn, int n, const float* __restrict__ gamma,
+           const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd, f4* __restrict__ dx,
+           float* __restrict__ partial, long rows) {
   __shared__ f4 s_g[16][16], s_b[16][16];
   const int l16 = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const f4 g = ((const f4*)gamma)[l16], b = ((const f4*)beta)[l16];
   f4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
   for (long row = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; row < rows; row += ((long)gridDim.x * 256) >> 4) {
-    const f4 v = x[row * 16 + l16];
+    f4 v;
+    if (BC) { const long q = row / n; v = x[q * 16 + l16] + xn[(row - q * n) * 16 + l16]; }
+    else v = x[row * 16 + l16];
     f4 d = dy[row * 16 + l16];
     const float mu = mean[row], r = rstd[row];
     const f4 xh = (v - mu) * r;
@@ -260,8 +268,19 @@ extern "C" int mapdn_layernorm64_forward(const float* x, const float* gamma, con
   using namespace mapdn;
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 1) return MAPDN_E_INVALID;
   const int nb = ln64_blocks(rows);
-  if (relu) hipLaunchKernelGGL(k_ln64_fwd<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)x, gamma, beta, (f4*)y, mean, rstd, (long)rows, eps);
-  else hipLaunchKernelGGL(k_ln64_fwd<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)x, gamma, beta, (f4*)y, mean, rstd, (long)rows, eps);
+  if (relu) hipLaunchKernelGGL((k_ln64_fwd<true, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)x, (const f4*)nullptr, 1, gamma, beta, (f4*)y, mean, rstd, (long)rows, eps);
+  else hipLaunchKernelGGL((k_ln64_fwd<false, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)x, (const f4*)nullptr, 1, gamma, beta, (f4*)y, mean, rstd, (long)rows, eps);
+  return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
+}
+
+// ... with the input row formed as base[row / n] + per_n[row % n] (base [rows / n][64], per_n [n][64]); rows must be a multiple of n
+extern "C" int mapdn_layernorm64_bc_forward(const float* base, const float* per_n, int32_t n, const float* gamma, const float* beta, float* y,
+                                            float* mean, float* rstd, int64_t rows, float eps, int32_t relu, void* stream) {
+  using namespace mapdn;
+  if (!base || !per_n || n < 1 || !gamma || !beta || !y || !mean || !rstd || rows < 1 || rows % n) return MAPDN_E_INVALID;
+  const int nb = ln64_blocks(rows);
+  if (relu) hipLaunchKernelGGL((k_ln64_fwd<true, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)base, (const f4*)per_n, (int)n, gamma, beta, (f4*)y, mean, rstd, (long)rows, eps);
+  else hipLaunchKernelGGL((k_ln64_fwd<false, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)base, (const f4*)per_n, (int)n, gamma, beta, (f4*)y, mean, rstd, (long)rows, eps);
   return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
 }
 
@@ -273,8 +292,22 @@ extern "C" int mapdn_layernorm64_backward(const float* dy, const float* x, const
   using namespace mapdn;
   if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || !partial || rows < 1) return MAPDN_E_INVALID;
   const int nb = ln64_blocks(rows);
-  if (relu) hipLaunchKernelGGL(k_ln64_bwd<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)dy, (const f4*)x, gamma, beta, mean, rstd, (f4*)dx, partial, (long)rows);
-  else hipLaunchKernelGGL(k_ln64_bwd<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)dy, (const f4*)x, gamma, beta, mean, rstd, (f4*)dx, partial, (long)rows);
+  if (relu) hipLaunchKernelGGL((k_ln64_bwd<true, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)dy, (const f4*)x, (const f4*)nullptr, 1, gamma, beta, mean, rstd, (f4*)dx, partial, (long)rows);
+  else hipLaunchKernelGGL((k_ln64_bwd<false, false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)dy, (const f4*)x, (const f4*)nullptr, 1, gamma, beta, mean, rstd, (f4*)dx, partial, (long)rows);
+  hipLaunchKernelGGL(k_ln64_reduce, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, nb, dgamma, dbeta);
+  return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
+}
+
+// backward of mapdn_layernorm64_bc_forward: dx [rows][64] is the gradient wrt the FORMED rows (the caller sums it over n / over rows / n
+// for base / per_n), dgamma / dbeta as above
+extern "C" int mapdn_layernorm64_bc_backward(const float* dy, const float* base, const float* per_n, int32_t n, const float* gamma, const float* beta,
+                                             const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta, float* partial,
+                                             int64_t rows, int32_t relu, void* stream) {
+  using namespace mapdn;
+  if (!dy || !base || !per_n || n < 1 || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || !partial || rows < 1 || rows % n) return MAPDN_E_INVALID;
+  const int nb = ln64_blocks(rows);
+  if (relu) hipLaunchKernelGGL((k_ln64_bwd<true, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)dy, (const f4*)base, (const f4*)per_n, (int)n, gamma, beta, mean, rstd, (f4*)dx, partial, (long)rows);
+  else hipLaunchKernelGGL((k_ln64_bwd<false, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)dy, (const f4*)base, (const f4*)per_n, (int)n, gamma, beta, mean, rstd, (f4*)dx, partial, (long)rows);
   hipLaunchKernelGGL(k_ln64_reduce, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, nb, dgamma, dbeta);
   return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
 }

@@ -194,6 +194,62 @@ def gru_cell_tall(rnn: nn.GRUCell, x: torch.Tensor, h: torch.Tensor) -> torch.Te
     return rnn(x, h)
 
 
+class _LayerNorm64BC(torch.autograd.Function):
+    """relu(LayerNorm(base[b] + per_n[i])) for every (b, i), rows ordered (b, i), WITHOUT materialising the [b, n, 64] sum — the central
+    critic's first layer (DDPGNet._value_central) is exactly such a sum: W_obs·obs_all + bias per batch element plus the agent's id
+    column.  HIP kernels mapdn_layernorm64_bc_* (csrc/policy.hip): the row is formed in registers (one f32 add, as PyTorch's broadcast
+    add would), forward and backward; the backward hands back dx per formed row, reduced here over the agents / over the batch."""
+
+    @staticmethod
+    def forward(ctx, base, per_n, weight, bias, eps, relu):
+        from . import _lib
+        lib = _lib.load()
+        b2, p2 = base.contiguous(), per_n.contiguous()
+        w, bb = weight.detach().contiguous(), bias.detach().contiguous()
+        nb, n = b2.shape[0], p2.shape[0]
+        rows = nb * n
+        y = torch.empty(rows, 64, dtype=torch.float32, device=base.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=base.device)
+        rstd = torch.empty_like(mean)
+        with torch.cuda.device(base.device):
+            _lib.check(lib.mapdn_layernorm64_bc_forward(b2.data_ptr(), p2.data_ptr(), n, w.data_ptr(), bb.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                        rstd.data_ptr(), rows, float(eps), int(relu), torch.cuda.current_stream(base.device).cuda_stream))
+        ctx.save_for_backward(b2, p2, w, bb, mean, rstd)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        lib = _lib.load()
+        b2, p2, w, bb, mean, rstd = ctx.saved_tensors
+        nb, n = b2.shape[0], p2.shape[0]
+        rows = nb * n
+        dy2 = dy.reshape(rows, 64).contiguous()
+        dx = torch.empty_like(dy2)
+        dw, db = torch.empty_like(w), torch.empty_like(bb)
+        with torch.cuda.device(b2.device):
+            partial = torch.empty(lib.mapdn_layernorm64_backward_blocks(rows) * 128, dtype=torch.float32, device=b2.device)
+            _lib.check(lib.mapdn_layernorm64_bc_backward(dy2.data_ptr(), b2.data_ptr(), p2.data_ptr(), n, w.data_ptr(), bb.data_ptr(), mean.data_ptr(),
+                                                         rstd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), partial.data_ptr(), rows,
+                                                         int(ctx.relu), torch.cuda.current_stream(b2.device).cuda_stream))
+        dx3 = dx.view(nb, n, 64)
+        dbase = dx3.sum(1) if ctx.needs_input_grad[0] else None
+        dpern = dx3.sum(0) if ctx.needs_input_grad[1] else None
+        return dbase, dpern, dw, db, None, None
+
+
+def layernorm_act_bc(ln: nn.LayerNorm, act, base: torch.Tensor, per_n: torch.Tensor):
+    """act(LayerNorm(base.unsqueeze(1) + per_n.unsqueeze(0))).reshape(b * n, 64) through the broadcast-input kernels, or None when the
+    case is not theirs (the caller then forms the sum and takes layernorm_act)"""
+    if (base.is_cuda and base.dtype == torch.float32 and per_n.dtype == torch.float32 and base.dim() == 2 and per_n.dim() == 2
+            and base.shape[-1] == 64 and per_n.shape[-1] == 64 and act is F.relu and ln.elementwise_affine and ln.bias is not None
+            and ln.weight.dtype == torch.float32 and base.shape[0] * per_n.shape[0] >= 1024
+            and os.environ.get("MAPDN_FUSED_LN", "1") != "0" and os.environ.get("MAPDN_FUSED_LN_BC", "1") != "0"):
+        return _LayerNorm64BC.apply(base, per_n, ln.weight, ln.bias, ln.eps, True)
+    return None
+
+
 def layernorm_act(ln: nn.LayerNorm, act, x: torch.Tensor) -> torch.Tensor:
     """act(LayerNorm(x)): one HIP launch each way for the reference's default shape (64 features, ReLU, fp32, on the GPU), the
     PyTorch modules otherwise (MAPDN_FUSED_LN=0 forces them)."""
@@ -243,6 +299,10 @@ class MLPCritic(nn.Module):
 
     def trunk(self, x: torch.Tensor):
         x = layernorm_act(self.layernorm, self.act, x) if self.use_ln else self.act(x)
+        return self.head(x)
+
+    def head(self, x: torch.Tensor):
+        """what follows the first layer's LayerNorm + activation: fc2 -> act -> fc3"""
         h = self.act(tall_linear(self.fc2, x))
         return tall_linear(self.fc3, h), h
 
@@ -418,6 +478,14 @@ class DDPGNet(nn.Module):
 
         if self.args.shared_params:
             cr = self.value_dicts[0]
+            if ids and own is None and cr.use_ln:
+                # no gradient path through the actions (value loss, target values): the first layer's output is base[b] + id_column[i] —
+                # LayerNorm + ReLU straight from the two small operands, the [b, n, h] sum is never written
+                w = cr.fc1.weight
+                base = F.linear(obs_all, w[:, :n * o], cr.fc1.bias) + F.linear(act_all.detach(), w[:, n * o + ids:])
+                xn = layernorm_act_bc(cr.layernorm, cr.act, base, w[:, n * o:n * o + n].t())
+                if xn is not None:
+                    return cr.head(xn)[0].view(b, n, 1)
             v, _ = cr.trunk(first_layer(cr, None).reshape(b * n, -1))
             return v.view(b, n, 1)
         return torch.stack([cr.trunk(first_layer(cr, i))[0] for i, cr in enumerate(self.value_dicts)], 1)

@@ -392,3 +392,53 @@ def test_tall_batch_routes_give_the_stock_gradients(monkeypatch):
             assert (a is None) == (b is None)
             if a is not None:
                 assert torch.allclose(a, b, rtol=2e-3, atol=2e-6), (which, (a - b).abs().max().item(), b.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,n", [(700, 38), (4096, 6), (33, 22)])
+def test_broadcast_input_layernorm_equals_the_materialised_one(nb, n):
+    """mapdn_layernorm64_bc_* (round 5): relu(LayerNorm(base[b] + per_n[i])) without the [b, n, 64] tensor — output BIT-identical to
+    the materialised route through mapdn_layernorm64_forward (the row is formed by the same single f32 add), dgamma / dbeta identical,
+    dbase / dper_n equal to the autograd reductions of that route."""
+    from mapdn_amd.learner import _LayerNorm64, _LayerNorm64BC
+    g = torch.Generator(device="cuda:0"); g.manual_seed(nb + n)
+    base = (torch.randn(nb, 64, device="cuda:0", generator=g) * 1.3).requires_grad_(True)
+    pern = (torch.randn(n, 64, device="cuda:0", generator=g) * 0.7).requires_grad_(True)
+    w = (torch.randn(64, device="cuda:0", generator=g) * 0.5 + 1.0).requires_grad_(True)
+    b = (torch.randn(64, device="cuda:0", generator=g) * 0.2).requires_grad_(True)
+    dy = torch.randn(nb * n, 64, device="cuda:0", generator=g)
+    y = _LayerNorm64BC.apply(base, pern, w, b, 1e-5, True)
+    y.backward(dy)
+    got = [y.detach().clone(), base.grad.clone(), pern.grad.clone(), w.grad.clone(), b.grad.clone()]
+    base.grad = pern.grad = w.grad = b.grad = None
+    x = (base.unsqueeze(1) + pern.unsqueeze(0)).reshape(nb * n, 64)
+    ref = _LayerNorm64.apply(x, w, b, 1e-5, True)
+    ref.backward(dy)
+    assert torch.equal(got[0], ref.detach())
+    assert torch.equal(got[3], w.grad) and torch.equal(got[4], b.grad)
+    assert torch.allclose(got[1], base.grad, rtol=1e-5, atol=1e-5) and torch.allclose(got[2], pern.grad, rtol=1e-4, atol=1e-4 * max(1.0, nb ** 0.5))
+
+
+@pytest.mark.gpu
+def test_central_critic_takes_the_broadcast_route_and_gives_the_same_values(monkeypatch):
+    """DDPGNet._value_central without an action-gradient path (value loss, target values): same values and parameter gradients with
+    MAPDN_FUSED_LN_BC on / off"""
+    dev = torch.device("cuda:0")
+    n, o, h, bs = 22, 20, 64, 600
+    torch.manual_seed(4)
+    args = make_alg_args(n, o, 1, hid_size=h, reward_normalisation=False)
+    net = DDPGNet(args, "maddpg", DDPGNet(args, "maddpg").to(dev)).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(6)
+    obs, act = torch.randn(bs, n, o, generator=g).to(dev), torch.tanh(torch.randn(bs, n, 1, generator=g)).to(dev)
+    params = [p for name, p in net.named_parameters() if name.startswith("value_dicts")]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MAPDN_FUSED_LN_BC", flag)
+        v = net.value(obs, act)
+        gr = torch.autograd.grad(v.square().mean(), params, allow_unused=True)
+        out[flag] = (v.detach().clone(), gr)
+    assert torch.equal(out["1"][0], out["0"][0])
+    for a, b in zip(out["1"][1], out["0"][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
