@@ -355,6 +355,12 @@ int mapdn_layernorm64_bc_forward(const float* base, const float* per_n, int32_t 
 int mapdn_layernorm64_bc_backward(const float* dy, const float* base, const float* per_n, int32_t n, const float* gamma, const float* beta,
                                   const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta, float* partial,
                                   int64_t rows, int32_t relu, void* stream);
+/* The critic's last two steps on rows of 64 as one pass: v[row] = relu(pre[row, :]) . w + bias  (critics/mlp_critic.py:22-36: the
+ * activation after fc2, then fc3 with one output) — relu(pre) is not materialised.  Backward: dpre = [pre > 0] dv w; dw [64]; db [64]
+ * with the bias gradient in db[0]; `partial` = mapdn_layernorm64_backward_blocks(rows) x 128 floats of scratch (fixed-order reduction). */
+int mapdn_relu_dot64_forward(const float* pre, const float* w, float bias, float* v, int64_t rows, void* stream);
+int mapdn_relu_dot64_backward(const float* dv, const float* pre, const float* w, float* dpre, float* dw, float* db, float* partial,
+                              int64_t rows, void* stream);
 
 /* Calibration aid for the HBM counters (tools/calibrate_traffic.py): copies rows x Bp x 16 bytes from src to dst (device pointers) with
  * the solver's own global access pattern — raw-buffer 16-byte loads / stores of env-minor pair rows, 256 contiguous bytes per

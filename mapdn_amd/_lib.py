@@ -32,7 +32,7 @@ EXPORTS = (
     "mapdn_solve_only", "mapdn_get_ybus_dense", "mapdn_get_obs_index", "mapdn_get_schedule", "mapdn_get_flat_factors", "mapdn_stats", "mapdn_nr_timing",
     "mapdn_nr_time_ms", "mapdn_get_auto_reset_mask", "mapdn_dense_solve", "mapdn_step_obs", "mapdn_get_sparse_program", "mapdn_policy_forward",
     "mapdn_policy_forward_fits", "mapdn_layernorm64_forward", "mapdn_layernorm64_backward", "mapdn_layernorm64_backward_blocks",
-    "mapdn_get_nr_geometry", "mapdn_debug_stream", "mapdn_build_info", "mapdn_layernorm64_bc_forward", "mapdn_layernorm64_bc_backward",
+    "mapdn_get_nr_geometry", "mapdn_debug_stream", "mapdn_build_info", "mapdn_layernorm64_bc_forward", "mapdn_layernorm64_bc_backward", "mapdn_relu_dot64_forward", "mapdn_relu_dot64_backward",
 )
 
 _pd = C.POINTER(C.c_double)
@@ -162,6 +162,8 @@ def load():
     lib.mapdn_layernorm64_backward.argtypes = [vp] * 10 + [C.c_int64, C.c_int32, vp]
     lib.mapdn_layernorm64_bc_forward.argtypes = [vp, vp, C.c_int32] + [vp] * 5 + [C.c_int64, C.c_float, C.c_int32, vp]
     lib.mapdn_layernorm64_bc_backward.argtypes = [vp, vp, vp, C.c_int32] + [vp] * 8 + [C.c_int64, C.c_int32, vp]
+    lib.mapdn_relu_dot64_forward.argtypes = [vp, vp, C.c_float, vp, C.c_int64, vp]
+    lib.mapdn_relu_dot64_backward.argtypes = [vp] * 7 + [C.c_int64, vp]
     lib.mapdn_dense_solve.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, vp]
     lib.mapdn_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int32), vp]
     lib.mapdn_nr_timing.argtypes = [vp, C.c_int32]

@@ -254,6 +254,54 @@ __global__ void __launch_bounds__(1024) k_ln64_reduce(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The critic's last two steps on rows of 64: v = relu(pre) . w3 + b3 (critics/mlp_critic.py:22-36: act(fc2(x)) -> fc3) as ONE pass over
+// the pre-activation — the [rows, 64] tensor of relu(pre) is neither written nor read back (2 x 2.7 GB per forward at 10 M rows; the
+// [rows, 64] x [64, 1] product PyTorch runs for fc3 reads it a third time).  16 lanes per row as in the LayerNorm kernels.
+__global__ void __launch_bounds__(256)
+k_relu_dot64_fwd(const f4* __restrict__ pre, const float* __restrict__ w, float b3, float* __restrict__ v, long rows) {
+  const int l16 = threadIdx.x & 15;
+  const f4 wv = ((const f4*)w)[l16];
+  for (long row = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; row < rows; row += ((long)gridDim.x * 256) >> 4) {
+    f4 h = pre[row * 16 + l16];
+    // torch.relu propagates NaN
+    h.x = h.x > 0.0f ? h.x : (h.x != h.x ? h.x : 0.0f); h.y = h.y > 0.0f ? h.y : (h.y != h.y ? h.y : 0.0f);
+    h.z = h.z > 0.0f ? h.z : (h.z != h.z ? h.z : 0.0f); h.w = h.w > 0.0f ? h.w : (h.w != h.w ? h.w : 0.0f);
+    const float s = row_sum16((h.x * wv.x + h.y * wv.y) + (h.z * wv.z + h.w * wv.w));
+    if (l16 == 0) v[row] = s + b3;
+  }
+}
+// backward: dpre = [pre > 0] dv w3;  partial[block][0:64] = sum_rows relu(pre) dv (-> dw3), partial[block][64] = sum_rows dv (-> db3)
+__global__ void __launch_bounds__(256)
+k_relu_dot64_bwd(const float* __restrict__ dv, const f4* __restrict__ pre, const float* __restrict__ w, f4* __restrict__ dpre,
+                 float* __restrict__ partial, long rows) {
+  __shared__ f4 s_g[16][16]; __shared__ float s_b[16];
+  const int l16 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const f4 wv = ((const f4*)w)[l16];
+  f4 ag = {0.f, 0.f, 0.f, 0.f}; float ab = 0.0f;
+  for (long row = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; row < rows; row += ((long)gridDim.x * 256) >> 4) {
+    const f4 p = pre[row * 16 + l16];
+    const float d = dv[row];
+    f4 o;
+    o.x = p.x > 0.0f ? d * wv.x : 0.0f; o.y = p.y > 0.0f ? d * wv.y : 0.0f; o.z = p.z > 0.0f ? d * wv.z : 0.0f; o.w = p.w > 0.0f ? d * wv.w : 0.0f;
+    dpre[row * 16 + l16] = o;
+    ag.x += (p.x > 0.0f ? p.x : 0.0f) * d; ag.y += (p.y > 0.0f ? p.y : 0.0f) * d; ag.z += (p.z > 0.0f ? p.z : 0.0f) * d; ag.w += (p.w > 0.0f ? p.w : 0.0f) * d;
+    ab += d;
+  }
+  s_g[rg][l16] = ag;
+  if (l16 == 0) s_b[rg] = ab;
+  __syncthreads();
+  if (rg == 0) {
+    f4 tg = s_g[0][l16];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) tg += s_g[i][l16];
+    ((f4*)partial)[(size_t)blockIdx.x * 32 + l16] = tg;
+    f4 tb = {0.f, 0.f, 0.f, 0.f};
+    if (l16 == 0) { float t = s_b[0]; for (int i = 1; i < 16; ++i) t += s_b[i]; tb.x = t; }
+    ((f4*)partial)[(size_t)blockIdx.x * 32 + 16 + l16] = tb;
+  }
+}
+
 }  // namespace mapdn
 
 static int ln64_blocks(long rows) {
@@ -309,6 +357,24 @@ extern "C" int mapdn_layernorm64_bc_backward(const float* dy, const float* base,
   if (relu) hipLaunchKernelGGL((k_ln64_bwd<true, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)dy, (const f4*)base, (const f4*)per_n, (int)n, gamma, beta, mean, rstd, (f4*)dx, partial, (long)rows);
   else hipLaunchKernelGGL((k_ln64_bwd<false, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, (const f4*)dy, (const f4*)base, (const f4*)per_n, (int)n, gamma, beta, mean, rstd, (f4*)dx, partial, (long)rows);
   hipLaunchKernelGGL(k_ln64_reduce, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, nb, dgamma, dbeta);
+  return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
+}
+
+extern "C" int mapdn_relu_dot64_forward(const float* pre, const float* w, float bias, float* v, int64_t rows, void* stream) {
+  using namespace mapdn;
+  if (!pre || !w || !v || rows < 1) return MAPDN_E_INVALID;
+  hipLaunchKernelGGL(k_relu_dot64_fwd, dim3(ln64_blocks(rows)), dim3(256), 0, (hipStream_t)stream, (const f4*)pre, w, bias, v, (long)rows);
+  return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
+}
+
+// dw [64], db [64] (db[0] is the bias gradient, the rest zero); partial: mapdn_layernorm64_backward_blocks(rows) x 128 floats of scratch
+extern "C" int mapdn_relu_dot64_backward(const float* dv, const float* pre, const float* w, float* dpre, float* dw, float* db, float* partial,
+                                         int64_t rows, void* stream) {
+  using namespace mapdn;
+  if (!dv || !pre || !w || !dpre || !dw || !db || !partial || rows < 1) return MAPDN_E_INVALID;
+  const int nb = ln64_blocks(rows);
+  hipLaunchKernelGGL(k_relu_dot64_bwd, dim3(nb), dim3(256), 0, (hipStream_t)stream, dv, (const f4*)pre, w, (f4*)dpre, partial, (long)rows);
+  hipLaunchKernelGGL(k_ln64_reduce, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, nb, dw, db);
   return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
 }
 

@@ -239,6 +239,45 @@ class _LayerNorm64BC(torch.autograd.Function):
         return dbase, dpern, dw, db, None, None
 
 
+class _ReluDot64(torch.autograd.Function):
+    """v = relu(pre) @ w^T + b for pre [rows, 64], w [1, 64]: the critic's activation after fc2 and its one-output fc3 as one pass
+    over the pre-activation (mapdn_relu_dot64_*, csrc/policy.hip); relu(pre) is never materialised, forward or backward."""
+
+    @staticmethod
+    def forward(ctx, pre, weight, bias):
+        from . import _lib
+        lib = _lib.load()
+        p2 = pre.contiguous()
+        w = weight.detach().reshape(64).contiguous()
+        rows = p2.shape[0]
+        v = torch.empty(rows, 1, dtype=torch.float32, device=pre.device)
+        with torch.cuda.device(pre.device):
+            _lib.check(lib.mapdn_relu_dot64_forward(p2.data_ptr(), w.data_ptr(), 0.0, v.data_ptr(), rows,
+                                                    torch.cuda.current_stream(pre.device).cuda_stream))
+        ctx.save_for_backward(p2, w)
+        return v + bias.detach()          # (the bias stays a device tensor: no host read of a parameter inside the training loop)
+
+    @staticmethod
+    def backward(ctx, dv):
+        from . import _lib
+        lib = _lib.load()
+        p2, w = ctx.saved_tensors
+        rows = p2.shape[0]
+        dv2 = dv.reshape(rows).contiguous()
+        dpre = torch.empty_like(p2)
+        dw, db = torch.empty(64, dtype=torch.float32, device=p2.device), torch.empty(64, dtype=torch.float32, device=p2.device)
+        with torch.cuda.device(p2.device):
+            partial = torch.empty(lib.mapdn_layernorm64_backward_blocks(rows) * 128, dtype=torch.float32, device=p2.device)
+            _lib.check(lib.mapdn_relu_dot64_backward(dv2.data_ptr(), p2.data_ptr(), w.data_ptr(), dpre.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                                     partial.data_ptr(), rows, torch.cuda.current_stream(p2.device).cuda_stream))
+        return dpre, dw.view(1, 64), db[:1].clone()
+
+
+def relu_dot64_ok(act, fc3: nn.Linear, pre: torch.Tensor) -> bool:
+    return (pre.is_cuda and pre.dtype == torch.float32 and pre.dim() == 2 and pre.shape[1] == 64 and pre.shape[0] >= 64 * 1024 and act is F.relu
+            and fc3.out_features == 1 and fc3.bias is not None and os.environ.get("MAPDN_FUSED_RELU_DOT", "1") != "0")
+
+
 def layernorm_act_bc(ln: nn.LayerNorm, act, base: torch.Tensor, per_n: torch.Tensor):
     """act(LayerNorm(base.unsqueeze(1) + per_n.unsqueeze(0))).reshape(b * n, 64) through the broadcast-input kernels, or None when the
     case is not theirs (the caller then forms the sum and takes layernorm_act)"""
@@ -303,7 +342,10 @@ class MLPCritic(nn.Module):
 
     def head(self, x: torch.Tensor):
         """what follows the first layer's LayerNorm + activation: fc2 -> act -> fc3"""
-        h = self.act(tall_linear(self.fc2, x))
+        pre = tall_linear(self.fc2, x)
+        if relu_dot64_ok(self.act, self.fc3, pre):
+            return _ReluDot64.apply(pre, self.fc3.weight, self.fc3.bias), None      # (no caller uses the hidden activation)
+        h = self.act(pre)
         return tall_linear(self.fc3, h), h
 
     def forward(self, inputs, hidden=None):

@@ -442,3 +442,29 @@ def test_central_critic_takes_the_broadcast_route_and_gives_the_same_values(monk
         assert (a is None) == (b is None)
         if a is not None:
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [65536, 300001])
+def test_relu_dot64_kernels_match_pytorch(rows):
+    """mapdn_relu_dot64_* (round 5): v = relu(pre) @ w^T + b on rows of 64 as one pass — values and the three gradients against
+    torch.relu + F.linear with autograd; deterministic (fixed-order block reduction)."""
+    from mapdn_amd.learner import _ReluDot64
+    g = torch.Generator(device="cuda:0"); g.manual_seed(rows)
+    pre = (torch.randn(rows, 64, device="cuda:0", generator=g) * 1.5).requires_grad_(True)
+    w = (torch.randn(1, 64, device="cuda:0", generator=g) * 0.3).requires_grad_(True)
+    b = torch.randn(1, device="cuda:0", generator=g).requires_grad_(True)
+    dv = torch.randn(rows, 1, device="cuda:0", generator=g)
+    v = _ReluDot64.apply(pre, w, b)
+    v.backward(dv)
+    got = [v.detach().clone(), pre.grad.clone(), w.grad.clone(), b.grad.clone()]
+    pre.grad = w.grad = b.grad = None
+    ref = torch.nn.functional.linear(torch.relu(pre), w, b)
+    ref.backward(dv)
+    assert torch.allclose(got[0], ref.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(got[1], pre.grad)                               # dpre = [pre > 0] dv w: one product per element, same bits
+    scale = rows ** 0.5
+    assert (got[2] - w.grad).abs().max().item() < 1e-5 * scale * 10 and (got[3] - b.grad).abs().max().item() < 1e-5 * scale * 10
+    pre.grad = None
+    v2 = _ReluDot64.apply(pre, w, b); v2.backward(dv)
+    assert torch.equal(v2.detach(), got[0]) and torch.equal(pre.grad, got[1])
