@@ -362,6 +362,28 @@ int mapdn_relu_dot64_forward(const float* pre, const float* w, float bias, float
 int mapdn_relu_dot64_backward(const float* dv, const float* pre, const float* w, float* dpre, float* dw, float* db, float* partial,
                               int64_t rows, void* stream);
 
+/* The critic trunk behind its first layer as ONE launch each way (critics/mlp_critic.py:22-36 as trained by
+ * learning_algorithms/ddpg.py:15-39 / models/maddpg.py:103-125):   v[row] = relu( relu(LayerNorm(x[row])) W2^T + b2 ) . w3 + b3
+ * on rows of 64, fp32 on v_mfma_f32_16x16x4_f32 (csrc/critic.hip).  x is read ([rows][64], per_n == NULL) or FORMED as
+ * base[row / n] + per_n[row % n] (x = base [rows / n][64], per_n [n][64], rows a multiple of n, n <= 256: the central critic).
+ * Device pointers, contiguous; gamma, beta, b2, w3 [64], w2 [64][64] (out, in), b3 [1]; rows < 2^31.
+ * backward recomputes the forward from the same inputs (nothing is saved but them):
+ *   dx      [rows][64]                       (x read)   — or dbase [rows / n][64] = sum of dx over every group of n rows (x formed);
+ *   grads   [4416 (+ n * 64)] when param_grads != 0 or x is formed:  dW2 [64][64] | dgamma | dbeta | db2 | dw3 [64 each] | db3 [1] + pad to
+ *           4416 | dper_n [n][64] (formed rows only; with param_grads == 0 only dper_n is written);
+ *   scratch mapdn_critic_head_scratch_floats(rows, n, formed) floats (per-wavefront partial sums, reduced in a fixed order: deterministic).
+ * _backward_dot: only dact[row] = dx[row] . dot_w[row % n] (dot_w [n][64]; n = 1 when x is read) — the policy update through the
+ * central critic, whose own-action column of fc1 (models/maddpg.py:52-58) is the only gradient path back to the policy. */
+int mapdn_critic_head_forward(const float* x, const float* per_n, int32_t n, const float* gamma, const float* beta, float eps,
+                              const float* w2, const float* b2, const float* w3, const float* b3, float* v, int64_t rows, void* stream);
+int64_t mapdn_critic_head_scratch_floats(int64_t rows, int32_t n, int32_t formed);
+int mapdn_critic_head_backward(const float* dv, const float* x, const float* per_n, int32_t n, const float* gamma, const float* beta,
+                               float eps, const float* w2, const float* b2, const float* w3, const float* b3, float* dx, float* grads,
+                               float* scratch, int64_t rows, int32_t param_grads, void* stream);
+int mapdn_critic_head_backward_dot(const float* dv, const float* x, const float* per_n, int32_t n, const float* gamma, const float* beta,
+                                   float eps, const float* w2, const float* b2, const float* w3, const float* b3, const float* dot_w,
+                                   float* dact, int64_t rows, void* stream);
+
 /* Calibration aid for the HBM counters (tools/calibrate_traffic.py): copies rows x Bp x 16 bytes from src to dst (device pointers) with
  * the solver's own global access pattern — raw-buffer 16-byte loads / stores of env-minor pair rows, 256 contiguous bytes per
  * 16-lane worker (pattern 0) — or with whole waves on one row (pattern 1), so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be read

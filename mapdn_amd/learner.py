@@ -278,6 +278,107 @@ def relu_dot64_ok(act, fc3: nn.Linear, pre: torch.Tensor) -> bool:
             and fc3.out_features == 1 and fc3.bias is not None and os.environ.get("MAPDN_FUSED_RELU_DOT", "1") != "0")
 
 
+class _CriticHead(torch.autograd.Function):
+    """v = relu(relu(LayerNorm(x)) W2^T + b2) . w3 + b3 on rows of 64 — everything of the critic behind its first layer
+    (critics/mlp_critic.py:22-36) — as ONE HIP launch forward and one backward (libmapdn_hip.so: mapdn_critic_head_*, csrc/critic.hip:
+    fp32 MFMA, the 16-row tile stays in registers from the LayerNorm input to v / from dv to dx and the parameter gradients; the backward
+    recomputes the forward, so nothing but the inputs is saved).  x is read ([rows, 64], per_n None) or formed as base[b] + per_n[i]
+    (rows ordered (b, i): the central critic); the backward then returns dbase / dper_n already summed over the agents / the batch."""
+
+    @staticmethod
+    def forward(ctx, x, per_n, ln_w, ln_b, eps, w2, b2, w3, b3):
+        from . import _lib
+        lib = _lib.load()
+        x2 = x.contiguous()
+        pn = per_n.contiguous() if per_n is not None else None
+        n = pn.shape[0] if pn is not None else 1
+        rows = x2.shape[0] * n
+        prm = tuple(t.detach().contiguous() for t in (ln_w, ln_b, w2, b2, w3.reshape(64), b3.reshape(1)))
+        v = torch.empty(rows, 1, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.mapdn_critic_head_forward(x2.data_ptr(), pn.data_ptr() if pn is not None else None, n, prm[0].data_ptr(), prm[1].data_ptr(),
+                                                     float(eps), prm[2].data_ptr(), prm[3].data_ptr(), prm[4].data_ptr(), prm[5].data_ptr(), v.data_ptr(),
+                                                     rows, torch.cuda.current_stream(x.device).cuda_stream))
+        ctx.save_for_backward(x2, pn, *prm)
+        ctx.eps, ctx.rows, ctx.n = float(eps), rows, n
+        return v
+
+    @staticmethod
+    def backward(ctx, dv):
+        from . import _lib
+        lib = _lib.load()
+        x2, pn, g, b, w2, b2, w3, b3 = ctx.saved_tensors
+        rows, n, formed = ctx.rows, ctx.n, pn is not None
+        need = ctx.needs_input_grad
+        param_grads = bool(need[2] or need[3] or need[5] or need[6] or need[7] or need[8])
+        dv2 = dv.reshape(rows).contiguous()
+        dx = torch.empty_like(x2)
+        dev = x2.device
+        with torch.cuda.device(dev):
+            grads = torch.empty(4416 + (n * 64 if formed else 0), dtype=torch.float32, device=dev)
+            scratch = torch.empty(max(1, lib.mapdn_critic_head_scratch_floats(rows, n, int(formed))), dtype=torch.float32, device=dev)
+            _lib.check(lib.mapdn_critic_head_backward(dv2.data_ptr(), x2.data_ptr(), pn.data_ptr() if formed else None, n, g.data_ptr(), b.data_ptr(),
+                                                      ctx.eps, w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), dx.data_ptr(), grads.data_ptr(),
+                                                      scratch.data_ptr(), rows, int(param_grads), torch.cuda.current_stream(dev).cuda_stream))
+        dpn = grads[4416:].view(n, 64) if formed and need[1] else None
+        if not param_grads:
+            return dx, dpn, None, None, None, None, None, None, None
+        return (dx, dpn, grads[4096:4160], grads[4160:4224], None, grads[:4096].view(64, 64), grads[4224:4288], grads[4288:4352].view(1, 64),
+                grads[4352:4353])
+
+
+class _CriticHeadOwnAction(torch.autograd.Function):
+    """The central critic's value as a function of every agent's OWN action only (models/maddpg.py:52-58: the other agents' actions
+    enter detached): forward = _CriticHead on base[b] + id_column[i] (the own-action term (a - a.detach()) W_act[:, i] is zero in
+    value), backward = d loss / d act[b, i] = dx[b, i, :] . W_act[:, i] straight from the kernel (mapdn_critic_head_backward_dot);
+    no [b, n, 64] tensor exists in either direction and the critic's parameters receive no gradient — the policy optimiser does not
+    own them (utilities/trainer.py:26-27, 73-98)."""
+
+    @staticmethod
+    def forward(ctx, act, base, per_n, dot_w, ln_w, ln_b, eps, w2, b2, w3, b3):
+        from . import _lib
+        lib = _lib.load()
+        x2, pn, dw = base.detach().contiguous(), per_n.detach().contiguous(), dot_w.detach().contiguous()
+        n = pn.shape[0]
+        rows = x2.shape[0] * n
+        prm = tuple(t.detach().contiguous() for t in (ln_w, ln_b, w2, b2, w3.reshape(64), b3.reshape(1)))
+        v = torch.empty(rows, 1, dtype=torch.float32, device=base.device)
+        with torch.cuda.device(base.device):
+            _lib.check(lib.mapdn_critic_head_forward(x2.data_ptr(), pn.data_ptr(), n, prm[0].data_ptr(), prm[1].data_ptr(), float(eps), prm[2].data_ptr(),
+                                                     prm[3].data_ptr(), prm[4].data_ptr(), prm[5].data_ptr(), v.data_ptr(), rows,
+                                                     torch.cuda.current_stream(base.device).cuda_stream))
+        ctx.save_for_backward(x2, pn, dw, *prm)
+        ctx.eps, ctx.rows, ctx.n, ctx.act_shape = float(eps), rows, n, act.shape
+        return v
+
+    @staticmethod
+    def backward(ctx, dv):
+        from . import _lib
+        lib = _lib.load()
+        x2, pn, dw, g, b, w2, b2, w3, b3 = ctx.saved_tensors
+        rows, n, dev = ctx.rows, ctx.n, x2.device
+        dv2 = dv.reshape(rows).contiguous()
+        dact = torch.empty(rows, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mapdn_critic_head_backward_dot(dv2.data_ptr(), x2.data_ptr(), pn.data_ptr(), n, g.data_ptr(), b.data_ptr(), ctx.eps,
+                                                          w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), dw.data_ptr(), dact.data_ptr(), rows,
+                                                          torch.cuda.current_stream(dev).cuda_stream))
+        return (dact.view(ctx.act_shape),) + (None,) * 10
+
+
+def critic_head_ok(cr: "MLPCritic", x: torch.Tensor, rows: int) -> bool:
+    """the one-launch critic head covers the reference's default critic (LayerNorm, ReLU, hidden size 64, one output) in fp32 on the GPU"""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[-1] == 64 and rows >= 1024 and rows < 2 ** 31 and cr.use_ln
+            and cr.act is F.relu and cr.layernorm.elementwise_affine and cr.layernorm.bias is not None and cr.fc2.in_features == 64
+            and cr.fc2.out_features == 64 and cr.fc2.bias is not None and cr.fc3.out_features == 1 and cr.fc3.bias is not None
+            and cr.fc2.weight.dtype == torch.float32 and os.environ.get("MAPDN_FUSED_HEAD", "1") != "0")
+
+
+def critic_head(cr: "MLPCritic", x: torch.Tensor, per_n: Optional[torch.Tensor] = None) -> torch.Tensor:
+    ln = cr.layernorm
+    return _CriticHead.apply(x, per_n, ln.weight, ln.bias, ln.eps, cr.fc2.weight, cr.fc2.bias, cr.fc3.weight, cr.fc3.bias)
+
+
 def layernorm_act_bc(ln: nn.LayerNorm, act, base: torch.Tensor, per_n: torch.Tensor):
     """act(LayerNorm(base.unsqueeze(1) + per_n.unsqueeze(0))).reshape(b * n, 64) through the broadcast-input kernels, or None when the
     case is not theirs (the caller then forms the sum and takes layernorm_act)"""
@@ -337,6 +438,8 @@ class MLPCritic(nn.Module):
         self.act = _activation(args.hid_activation)
 
     def trunk(self, x: torch.Tensor):
+        if critic_head_ok(self, x, x.shape[0]):
+            return critic_head(self, x), None                      # (no caller uses the hidden activation)
         x = layernorm_act(self.layernorm, self.act, x) if self.use_ln else self.act(x)
         return self.head(x)
 
@@ -468,9 +571,10 @@ class DDPGNet(nn.Module):
         return means, log_stds, hid
 
     # ---- critics ---------------------------------------------------------------------------------
-    def value(self, obs: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
-        """obs [b, n, o], act [b, n, a] -> [b, n, 1]"""
-        return self._value_central(obs, act) if self.alg == "maddpg" else self._value_independent(obs, act)
+    def value(self, obs: torch.Tensor, act: torch.Tensor, own_action_only: bool = False) -> torch.Tensor:
+        """obs [b, n, o], act [b, n, a] -> [b, n, 1].  own_action_only: the caller differentiates with respect to `act` alone (the policy
+        loss): the central critic may then skip the gradients of its own parameters, which the policy optimiser never reads."""
+        return self._value_central(obs, act, own_action_only) if self.alg == "maddpg" else self._value_independent(obs, act)
 
     def _value_independent(self, obs, act):
         """IDDPG (iddpg.py:32-58): critic input [obs_i | id_i | act_i]"""
@@ -490,7 +594,7 @@ class DDPGNet(nn.Module):
             return v.view(b, n, -1)
         return torch.stack([cr.trunk(first_layer(cr, obs[:, i], act[:, i], i))[0] for i, cr in enumerate(self.value_dicts)], 1)
 
-    def _value_central(self, obs, act):
+    def _value_central(self, obs, act, own_action_only=False):
         """MADDPG (maddpg.py:35-79): agent i's critic sees [all obs | id_i | all actions] and only its OWN
         action carries gradient.  First layer = W_obs·obs_all + W_id[:, i] + W_act·act_all, where the joint
         action enters detached and agent i's own (act_i - act_i.detach()) — zero in value — restores its
@@ -520,11 +624,23 @@ class DDPGNet(nn.Module):
 
         if self.args.shared_params:
             cr = self.value_dicts[0]
+            if ids and cr.use_ln and own is not None and a == 1 and own_action_only and critic_head_ok(cr, obs_all.new_empty(0, 64), b * n):
+                # the policy update (maddpg.py:52-58, 103-125): value = the head on base[b] + id_column[i] (the own-action term is zero in
+                # value), gradient = d/d act[b, i] only, from the kernel; the critic's own parameters are not differentiated
+                w = cr.fc1.weight.detach()
+                with torch.no_grad():
+                    base = F.linear(obs_all, w[:, :n * o], cr.fc1.bias.detach()) + F.linear(act_all.detach(), w[:, n * o + ids:])
+                ln = cr.layernorm
+                v = _CriticHeadOwnAction.apply(act, base, w[:, n * o:n * o + n].t(), w[:, n * o + ids:].t(), ln.weight, ln.bias, ln.eps,
+                                               cr.fc2.weight, cr.fc2.bias, cr.fc3.weight, cr.fc3.bias)
+                return v.view(b, n, 1)
             if ids and own is None and cr.use_ln:
                 # no gradient path through the actions (value loss, target values): the first layer's output is base[b] + id_column[i] —
                 # LayerNorm + ReLU straight from the two small operands, the [b, n, h] sum is never written
                 w = cr.fc1.weight
                 base = F.linear(obs_all, w[:, :n * o], cr.fc1.bias) + F.linear(act_all.detach(), w[:, n * o + ids:])
+                if critic_head_ok(cr, base, b * n):
+                    return critic_head(cr, base, w[:, n * o:n * o + n].t()).view(b, n, 1)
                 xn = layernorm_act_bc(cr.layernorm, cr.act, base, w[:, n * o:n * o + n].t())
                 if xn is not None:
                     return cr.head(xn)[0].view(b, n, 1)
@@ -582,18 +698,21 @@ class DDPGNet(nn.Module):
         policy_loss = value_loss = action_out = None
         if "policy" in want:
             _, actions_pol, _, action_out, _ = self.get_actions(state, "train", False, avail, False, last_hid)
-            advantages = self.value(state, actions_pol).view(-1, n)
+            advantages = self.value(state, actions_pol, own_action_only=True).view(-1, n)
             if self.args.normalize_advantages:
                 advantages = self._adv_batchnorm.to(advantages.device)(advantages)
             policy_loss = wmean(-advantages)
         if "value" in want:
             with torch.no_grad():
-                if "next_action_cached" in batch:                # PGTrainer precomputed them for the whole replay ring (same values)
-                    next_actions = batch["next_action_cached"]
+                if "next_value_cached" in batch:                 # PGTrainer precomputed both for the whole replay ring (same values)
+                    next_values = batch["next_value_cached"].view(-1, n)
                 else:
-                    _, next_actions, _, _, _ = self.get_actions(next_state, "train", False, avail,
-                                                                not self.args.double_q, hid)
-                next_values = self.target_net.value(next_state, next_actions).view(-1, n)
+                    if "next_action_cached" in batch:
+                        next_actions = batch["next_action_cached"]
+                    else:
+                        _, next_actions, _, _, _ = self.get_actions(next_state, "train", False, avail,
+                                                                    not self.args.double_q, hid)
+                    next_values = self.target_net.value(next_state, next_actions).view(-1, n)
                 returns = rewards + self.args.gamma * (1 - done) * next_values
             values = self.value(state, actions).view(-1, n)
             value_loss = wmean((returns - values).pow(2))
@@ -715,12 +834,15 @@ class PGTrainer:
         with self._phase("policy_update"):
             self.policy_transition_process(stat, batch)
 
-    def _cache_next_actions(self) -> bool:
-        """The value loss needs pi(next_state) of every sampled transition (maddpg.py:103-125).  The value epochs of one update round
-        (models/model.py:46-49: ten of them) train the CRITIC only, so the policy that produces those actions does not change between
-        them, and their windows overlap heavily (32 of the ring's 64 steps each): the actions are computed ONCE for the whole ring —
-        two policy forwards instead of ten — and handed out with the sampled windows as one more (temporary) field of the replay
-        store.  Same kernel, same inputs, same values.  MAPDN_CACHE_NEXT_ACTIONS=0 disables it."""
+    def _cache_targets(self) -> bool:
+        """The value loss needs pi(next_state) and Q_target(next_state, pi(next_state)) of every sampled transition (maddpg.py:103-125).
+        The value epochs of one update round (models/model.py:46-49: ten of them) train the behaviour CRITIC only: neither the policy
+        that produces those actions nor the target critic that values them changes between the epochs, and their windows overlap
+        heavily (32 of the ring's 64 steps each).  Both are therefore computed ONCE for the whole ring, in chunks of one batch — the
+        same kernels on the same inputs as the per-epoch passes, same values — and handed out with the sampled windows as two more
+        (temporary) fields of the replay store.  Only when that is the cheaper order: a ring longer than the transitions the round's
+        value epochs sample (the reference's own defaults: a 5000-transition ring against 10 x 32) keeps the per-epoch passes.
+        MAPDN_CACHE_NEXT_ACTIONS=0 disables it."""
         rb, net, a = self.replay_buffer, self.behaviour_net, self.args
         if not isinstance(rb, TransReplayBuffer) or os.environ.get("MAPDN_CACHE_NEXT_ACTIONS", "1") == "0" or len(rb) == 0:
             return False
@@ -728,17 +850,26 @@ class PGTrainer:
         if not all(k in st for k in ("next_state", "action_avail", "hid", "action")):
             return False
         n_ring = rb.size if len(rb) == rb.size else len(rb)      # (the ring fills from position 0: a partly filled ring is [0, len))
+        if n_ring > int(a.value_update_epochs) * int(a.batch_size):
+            return False
         cache = torch.empty_like(st["action"])
+        values = torch.empty(st["action"].shape[0], net.n_, dtype=torch.float32, device=cache.device) if a.target else None
         chunk = max(int(a.batch_size), 1)
         with torch.no_grad():
             for lo in range(0, n_ring, chunk):
                 hi = min(lo + chunk, n_ring)
                 _, na, _, _, _ = net.get_actions(st["next_state"][lo:hi], "train", False, st["action_avail"][lo:hi], not a.double_q, st["hid"][lo:hi])
                 cache[lo:hi] = na
+                if values is not None:
+                    values[lo:hi] = net.target_net.value(st["next_state"][lo:hi], na).view(-1, net.n_)
             if rb.window:
                 m = min(rb.window, n_ring)
                 cache[rb.size:rb.size + m] = cache[:m]
+                if values is not None:
+                    values[rb.size:rb.size + m] = values[:m]
         st["next_action_cached"] = cache
+        if values is not None:
+            st["next_value_cached"] = values
         return True
 
     def transition_update(self, trans: Batch, stat):
@@ -747,13 +878,14 @@ class PGTrainer:
         with self._phase("replay_insert"):
             self.replay_buffer.add_experience(trans)
         if self.steps > a.replay_warmup and len(self.replay_buffer) >= a.batch_size and self.steps % a.behaviour_update_freq == 0:
-            cached = a.value_update_epochs > 1 and self._cache_next_actions()
+            cached = a.value_update_epochs > 1 and self._cache_targets()
             try:
                 for _ in range(a.value_update_epochs):
                     self.value_replay_process(stat)
             finally:
                 if cached:
-                    del self.replay_buffer.store["next_action_cached"]
+                    self.replay_buffer.store.pop("next_action_cached", None)
+                    self.replay_buffer.store.pop("next_value_cached", None)
             for _ in range(a.policy_update_epochs):
                 self.policy_replay_process(stat)
         if a.target and self.steps % a.target_update_freq == 0:

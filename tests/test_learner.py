@@ -335,30 +335,49 @@ def test_tall_linear_weight_gradient_is_the_plain_one(monkeypatch):
 
 
 @pytest.mark.parametrize("alg", ["maddpg", "iddpg"])
-def test_cached_next_actions_train_the_same_network(alg, monkeypatch):
-    """round 5: the value epochs of one update round read pi(next_state) from a per-round cache over the whole replay ring (the policy
-    does not change while the critic trains) instead of running the policy once per epoch.  Bit-identical training: two seeded runs,
-    cache on / off, end in the same state_dict — through several rounds, a wrapping ring, the mirror region and a partly filled ring."""
+def test_cached_targets_train_the_same_network(alg, monkeypatch):
+    """round 5 / 6: the value epochs of one update round read pi(next_state) — and, round 6, the target critic's value of it — from a
+    per-round cache over the whole replay ring (neither the policy nor the target net changes while the critic trains) instead of
+    running both once per epoch.  Bit-identical training: two seeded runs, cache on / off, end in the same state_dict — through
+    several rounds, a wrapping ring, the mirror region and a partly filled ring."""
     def run(cache):
         monkeypatch.setenv("MAPDN_CACHE_NEXT_ACTIONS", "1" if cache else "0")
         torch.manual_seed(0); np.random.seed(0)
         env = _ToyEnv(4, 3, 5)
         args = make_alg_args(3, 5, 1, hid_size=16, max_steps=12, batch_size=8, replay_buffer_size=28,
-                             behaviour_update_freq=4, target_update_freq=6, value_update_epochs=3, num_eval_episodes=4)
+                             behaviour_update_freq=4, target_update_freq=6, value_update_epochs=4, num_eval_episodes=4)
         tr = PGTrainer(args, alg, env, device="cpu", data_parallel=False)
         seen = []
-        orig = tr._cache_next_actions
-        tr._cache_next_actions = lambda: (seen.append(1), orig())[1]
+        orig = tr._cache_targets
+        tr._cache_targets = lambda: (seen.append(orig()), seen[-1])[1]
         stat = {}
         for ep in range(3):
             tr.train_process(stat)
-        assert "next_action_cached" not in tr.replay_buffer.store       # removed after every round
-        return {k: v.clone() for k, v in tr.behaviour_net.state_dict().items()}, len(seen), stat["mean_train_value_loss"]
+        assert "next_action_cached" not in tr.replay_buffer.store and "next_value_cached" not in tr.replay_buffer.store   # removed after every round
+        return {k: v.clone() for k, v in tr.behaviour_net.state_dict().items()}, seen, stat["mean_train_value_loss"]
     a, na, la = run(True)
     b, nb, lb = run(False)
-    assert na == nb >= 6 and la == lb
+    assert len(na) == len(nb) >= 6 and all(na) and not any(nb) and la == lb
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_target_cache_is_gated_on_cost():
+    """a whole-ring pass pays off only when the round's value epochs sample at least the ring (value_update_epochs x
+    batch_size >= ring length).  The reference's own defaults (a 5000-transition ring, 10 epochs of 32) keep the per-epoch passes."""
+    torch.manual_seed(0); np.random.seed(0)
+    env = _ToyEnv(4, 3, 5)
+    for ring, epochs, want in ((64, 3, False), (24, 3, True), (5000, 10, False)):
+        args = make_alg_args(3, 5, 1, hid_size=16, max_steps=12, batch_size=8, replay_buffer_size=ring, behaviour_update_freq=4,
+                             target_update_freq=6, value_update_epochs=epochs, num_eval_episodes=4)
+        tr = PGTrainer(args, "maddpg", env, device="cpu", data_parallel=False)
+        got = []
+        orig = tr._cache_targets
+        tr._cache_targets = lambda: (got.append(orig()), got[-1])[1]
+        for ep in range(3):
+            tr.train_process({})
+        assert len(got) >= 6 and got[-1] == want and got[-2] == want, (ring, epochs, got)     # (the ring is as full as it gets by then)
+        assert got[0]                                             # a ring that still holds less than the round samples IS cached
 
 
 @pytest.mark.gpu
@@ -432,6 +451,7 @@ def test_central_critic_takes_the_broadcast_route_and_gives_the_same_values(monk
     obs, act = torch.randn(bs, n, o, generator=g).to(dev), torch.tanh(torch.randn(bs, n, 1, generator=g)).to(dev)
     params = [p for name, p in net.named_parameters() if name.startswith("value_dicts")]
     out = {}
+    monkeypatch.setenv("MAPDN_FUSED_HEAD", "0")                  # (round 6's one-launch head would take both: tests/test_critic_head.py)
     for flag in ("1", "0"):
         monkeypatch.setenv("MAPDN_FUSED_LN_BC", flag)
         v = net.value(obs, act)
