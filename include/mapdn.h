@@ -380,6 +380,12 @@ int64_t mapdn_critic_head_scratch_floats(int64_t rows, int32_t n, int32_t formed
 int mapdn_critic_head_backward(const float* dv, const float* x, const float* per_n, int32_t n, const float* gamma, const float* beta,
                                float eps, const float* w2, const float* b2, const float* w3, const float* b3, float* dx, float* grads,
                                float* scratch, int64_t rows, int32_t param_grads, void* stream);
+/* the value loss of the DDPG family (learning_algorithms/ddpg.py:36-38) and every gradient of it in ONE launch, without a forward:
+ * loss = sum_rows scale[0] * wrow[row / n] * (ret[row] - v[row])^2 (wrow NULL: 1; wrow [rows / n], or [rows] when x is read) -> grads[4353];
+ * dx / dbase and grads as mapdn_critic_head_backward(param_grads = 1) for dv = d loss / d v. */
+int mapdn_critic_head_mse(const float* ret, const float* wrow, const float* scale, const float* x, const float* per_n, int32_t n,
+                          const float* gamma, const float* beta, float eps, const float* w2, const float* b2, const float* w3,
+                          const float* b3, float* dx, float* grads, float* scratch, int64_t rows, void* stream);
 int mapdn_critic_head_backward_dot(const float* dv, const float* x, const float* per_n, int32_t n, const float* gamma, const float* beta,
                                    float eps, const float* w2, const float* b2, const float* w3, const float* b3, const float* dot_w,
                                    float* dact, int64_t rows, void* stream);

@@ -134,12 +134,16 @@ k_head_fwd(HeadArgs p, float* __restrict__ v, long rows) {
 // backward.  MODE 0: dx (or, for formed rows, dbase = sum over the n rows of a group, and dper_n) + every parameter gradient;
 //            MODE 1: dx / dbase / dper_n only (the parameters do not require grad);
 //            MODE 2: dact[row] = dx[row] . dot_w[row % n] only (the policy update through the central critic: the own-action column
-//                    of fc1 — models/maddpg.py:52-58 — is the only path back to the policy).
+//                    of fc1 — models/maddpg.py:52-58 — is the only path back to the policy);
+//            MODE 3: MODE 0 with the value loss fused in (learning_algorithms/ddpg.py:36-38, models/maddpg.py:122-124):
+//                    loss = sum_rows w[row] (ret[row] - v[row])^2, w[row] = scale[0] * wrow[row / n] (wrow may be null: 1), and dv is
+//                    formed in the kernel as -2 w (ret - v) — the forward launch and its product are not needed at all.
 // A wavefront owns a contiguous range of rows (whole groups of n for formed rows: the sum over a group never crosses wavefronts).
 template <bool BC, int MODE>
 __global__ void __launch_bounds__(256)
 k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, const float* __restrict__ dot_w, float* __restrict__ dact,
-           float* __restrict__ partial, int pstride, long rows) {
+           float* __restrict__ partial, int pstride, long rows, const float* __restrict__ wrow, const float* __restrict__ scale) {
+  constexpr bool PG = MODE == 0 || MODE == 3;        // parameter gradients wanted
   extern __shared__ float sm[];
   f4* sW = (f4*)sm;                         // [4 nt][4 c][64]: W2[16 nt + j][16 c + 4 g + q]       A operand of pre^T = W2 xn^T
   f4* sWT = sW + 1024;                      // [4 nt][4 c][64]: W2[16 c + 4 g + q][16 nt + j]       A operand of dxn^T = W2^T dpre^T
@@ -154,7 +158,7 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
     for (int q = 0; q < 4; ++q) t[q] = p.w2[(size_t)(16 * c + 4 * lg + q) * 64 + 16 * nt + lj];
     sWT[i] = t;
   }
-  if (BC && MODE < 2) for (int i = lane; i < p.n * 64; i += 64) accn[i] = 0.0f;
+  if (BC && MODE != 2) for (int i = lane; i < p.n * 64; i += 64) accn[i] = 0.0f;
   f4 gam[4], bet[4], b2v[4], w3v[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
@@ -172,6 +176,8 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
   f4 accW[4][4];                            // dW2[16 ntu + 4 g + r][16 ntk + j]
   f4 ag[4], ab[4], aw3[4], ab2[4];          // column sums in A layout (this lane's row j only): dgamma, dbeta, dw3, db2
   float ab3 = 0.0f, carry = 0.0f;           // db3; running sum of dx over the rows of the current group (lane = column)
+  float aloss = 0.0f;
+  const float b3 = MODE == 3 ? p.b3[0] : 0.0f, lscale = MODE == 3 ? scale[0] : 0.0f;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
 #pragma unroll
@@ -179,11 +185,27 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
     ag[a] = ab[a] = aw3[a] = ab2[a] = f4{0, 0, 0, 0};
   }
 
+  // the rows of the NEXT tile are requested while the current one is in the matrix cores (one wavefront per SIMD: nobody else hides
+  // the HBM / L2 latency)
+  f4 xnext[4];
+  float dvnext = 0.0f;
+  if (r0 < r1) {
+    const long row = r0 + j;
+    load_row<BC>(p, row < r1 ? row : r1 - 1, g, xnext);
+    dvnext = row < r1 ? dv[row] : 0.0f;
+  }
   for (long row0 = r0; row0 < r1; row0 += 16) {
     const long row = row0 + j;
     const bool valid = row < r1;
     f4 xh[4];
-    load_row<BC>(p, valid ? row : r1 - 1, g, xh);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xh[c] = xnext[c];
+    const float dvcur = dvnext;
+    if (row0 + 16 < r1) {
+      const long rn = row + 16;
+      load_row<BC>(p, rn < r1 ? rn : r1 - 1, g, xnext);
+      dvnext = rn < r1 ? dv[rn] : 0.0f;
+    }
     const float rs = ln_stats(xh, p.eps);
     f4 xn[4];
 #pragma unroll
@@ -204,7 +226,19 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
         for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][q], xn[c][q], acc[nt], 0, 0, 0);
     }
     // ---- dpre = [pre > 0] dv w3 (in place of acc); dw3 += relu(pre) dv; db2 += dpre; db3 += dv
-    const float dvr = valid ? dv[row] : 0.0f;
+    float dvr = dvcur;                       // (MODE 3: dv holds the returns)
+    if (MODE == 3) {
+      float dot = 0.0f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dot = fmaf(relu_nan(acc[nt][r] + b2v[nt][r]), w3v[nt][r], dot);
+      const float err = dvcur - (sum_g(dot) + b3);
+      float wgt = lscale;
+      if (wrow) { const unsigned rc = (unsigned)(valid ? row : r1 - 1); wgt *= wrow[BC ? rc / (unsigned)p.n : rc]; }
+      dvr = valid ? -2.0f * wgt * err : 0.0f;
+      if (valid && g == 0) aloss = fmaf(wgt * err, err, aloss);
+    }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -212,10 +246,10 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
         const float pre = acc[nt][r] + b2v[nt][r];
         const bool pos = pre > 0.0f;
         const float dp = pos ? dvr * w3v[nt][r] : 0.0f;
-        if (MODE == 0) { aw3[nt][r] = fmaf(pos ? pre : 0.0f, dvr, aw3[nt][r]); ab2[nt][r] += dp; }
+        if (PG) { aw3[nt][r] = fmaf(pos ? pre : 0.0f, dvr, aw3[nt][r]); ab2[nt][r] += dp; }
         acc[nt][r] = dp;
       }
-    if (MODE == 0 && g == 0) ab3 += dvr;
+    if (PG && g == 0) ab3 += dvr;
     // ---- dxn^T = W2^T dpre^T
     f4 dxn[4] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
 #pragma unroll
@@ -229,7 +263,7 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
         for (int nt = 0; nt < 4; ++nt) dxn[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][q], acc[c][q], dxn[nt], 0, 0, 0);
     }
     // ---- dW2 += dpre^T xn: both operands through LDS into C layout (rows on the contraction axis)
-    if (MODE == 0) {
+    if (PG) {
       float* s0 = stage; float* s1 = stage + 16 * HS;
 #pragma unroll
       for (int c = 0; c < 4; ++c) { *(f4*)(s0 + j * HS + 16 * c + 4 * g) = acc[c]; *(f4*)(s1 + j * HS + 16 * c + 4 * g) = xn[c]; }
@@ -254,7 +288,7 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
       f4 d;
 #pragma unroll
       for (int q = 0; q < 4; ++q) d[q] = xn[c][q] > 0.0f ? dxn[c][q] : 0.0f;
-      if (MODE == 0) { ag[c] += d * xh[c]; ab[c] += d; }
+      if (PG) { ag[c] += d * xh[c]; ab[c] += d; }
       const f4 a = d * gam[c];
       s1a += hsum(a); s2a += hsum(a * xh[c]);
       dxn[c] = a;
@@ -291,11 +325,34 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
       const unsigned rel = (unsigned)(row0 - r0);
       unsigned grp = rel / (unsigned)p.n, i = rel - grp * (unsigned)p.n;
       float* pbase = dx + ((size_t)(r0 / p.n) + grp) * 64 + lane;
-      for (int rr = 0; rr < cnt; ++rr) {
-        const float val = s0[rr * HS + lane];
-        carry += val;
-        accn[i * 64 + lane] += val;
-        if (++i == (unsigned)p.n) { *pbase = carry; carry = 0.0f; i = 0; pbase += 64; }
+      if (p.n >= 16) {
+        // the tile's 16 rows belong to 16 DIFFERENT agents: their dper_n slots are independent — 16 reads, 16 adds, 16 writes in flight
+        // instead of 16 dependent LDS round trips
+        float val[16], cur[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          unsigned ii = i + rr; if (ii >= (unsigned)p.n) ii -= p.n;
+          val[rr] = rr < cnt ? s0[rr * HS + lane] : 0.0f;
+          cur[rr] = accn[ii * 64 + lane];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          unsigned ii = i + rr; if (ii >= (unsigned)p.n) ii -= p.n;
+          accn[ii * 64 + lane] = cur[rr] + val[rr];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr)
+          if (rr < cnt) {
+            carry += val[rr];
+            if (++i == (unsigned)p.n) { *pbase = carry; carry = 0.0f; i = 0; pbase += 64; }
+          }
+      } else {
+        for (int rr = 0; rr < cnt; ++rr) {
+          const float val = s0[rr * HS + lane];
+          carry += val;
+          accn[i * 64 + lane] += val;
+          if (++i == (unsigned)p.n) { *pbase = carry; carry = 0.0f; i = 0; pbase += 64; }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -303,9 +360,9 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
   }
 
   // ---- this wavefront's partial sums -> partial[w][...]
-  if (MODE < 2) {
+  if (MODE != 2) {
     float* pp = partial + (size_t)w * pstride;
-    if (MODE == 0) {
+    if (PG) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -322,8 +379,8 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
             pp[4096 + col] = tg; pp[4160 + col] = tb; pp[4224 + col] = t2; pp[4288 + col] = t3;
           }
         }
-      const float t = sum_j(ab3);           // (lanes with g != 0 hold 0)
-      if (lane == 0) pp[4352] = t;
+      const float t = sum_j(ab3), tl = sum_j(aloss);           // (lanes with g != 0 hold 0)
+      if (lane == 0) { pp[4352] = t; pp[4353] = tl; }
     }
     if (BC) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -383,17 +440,17 @@ extern "C" int64_t mapdn_critic_head_scratch_floats(int64_t rows, int32_t n, int
 
 template <bool BC, int MODE>
 static int head_bwd_launch(const mapdn::HeadArgs& a, const float* dv, float* dx, const float* dot_w, float* dact, float* scratch, float* grads,
-                           int64_t rows, hipStream_t st) {
+                           int64_t rows, hipStream_t st, const float* wrow = nullptr, const float* scale = nullptr) {
   using namespace mapdn;
   const int blocks = head_bwd_blocks(rows, a.n, BC), nw = blocks * 4;
   const int pstride = HP + (BC ? a.n * 64 : 0);
-  const size_t lds = (size_t)2 * 1024 * 16 + (size_t)4 * 2 * 16 * HS * 4 + (BC && MODE < 2 ? (size_t)4 * a.n * 64 * 4 : 0);
+  const size_t lds = (size_t)2 * 1024 * 16 + (size_t)4 * 2 * 16 * HS * 4 + (BC && MODE != 2 ? (size_t)4 * a.n * 64 * 4 : 0);
   if (lds > (size_t)160 * 1024) return MAPDN_E_INVALID;
   const void* fn = (const void*)k_head_bwd<BC, MODE>;
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MAPDN_E_HIP;
-  hipLaunchKernelGGL((k_head_bwd<BC, MODE>), dim3(blocks), dim3(256), lds, st, a, dv, dx, dot_w, dact, scratch, pstride, (long)rows);
-  if (MODE == 0) hipLaunchKernelGGL(k_head_reduce, dim3((HP + 63) / 64), dim3(256), 0, st, scratch, nw, pstride, 0, HP, grads);
-  if (BC && MODE < 2) hipLaunchKernelGGL(k_head_reduce, dim3(a.n), dim3(256), 0, st, scratch, nw, pstride, HP, HP + a.n * 64, grads);
+  hipLaunchKernelGGL((k_head_bwd<BC, MODE>), dim3(blocks), dim3(256), lds, st, a, dv, dx, dot_w, dact, scratch, pstride, (long)rows, wrow, scale);
+  if (MODE == 0 || MODE == 3) hipLaunchKernelGGL(k_head_reduce, dim3((HP + 63) / 64), dim3(256), 0, st, scratch, nw, pstride, 0, HP, grads);
+  if (BC && MODE != 2) hipLaunchKernelGGL(k_head_reduce, dim3(a.n), dim3(256), 0, st, scratch, nw, pstride, HP, HP + a.n * 64, grads);
   return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
 }
 
@@ -420,4 +477,17 @@ extern "C" int mapdn_critic_head_backward_dot(const float* dv, const float* x, c
   hipStream_t st = (hipStream_t)stream;
   return per_n ? head_bwd_launch<true, 2>(a, dv, nullptr, dot_w, dact, nullptr, nullptr, rows, st)
                : head_bwd_launch<false, 2>(a, dv, nullptr, dot_w, dact, nullptr, nullptr, rows, st);
+}
+
+// value loss and every gradient of it in one launch (no forward launch): loss = sum_rows scale[0] wrow[row / n] (ret[row] - v[row])^2
+// (wrow may be NULL: weight 1) -> grads[4353]; dx / dbase, grads as mapdn_critic_head_backward with param_grads = 1
+extern "C" int mapdn_critic_head_mse(const float* ret, const float* wrow, const float* scale, const float* x, const float* per_n, int32_t n,
+                                     const float* gamma, const float* beta, float eps, const float* w2, const float* b2, const float* w3,
+                                     const float* b3, float* dx, float* grads, float* scratch, int64_t rows, void* stream) {
+  using namespace mapdn;
+  if (!head_args_ok(x, per_n, n, gamma, beta, w2, b2, w3, b3, rows) || !ret || !scale || !dx || !grads || !scratch) return MAPDN_E_INVALID;
+  const HeadArgs a{x, per_n, per_n ? n : 1, gamma, beta, eps, w2, b2, w3, b3};
+  hipStream_t st = (hipStream_t)stream;
+  return per_n ? head_bwd_launch<true, 3>(a, ret, dx, nullptr, nullptr, scratch, grads, rows, st, wrow, scale)
+               : head_bwd_launch<false, 3>(a, ret, dx, nullptr, nullptr, scratch, grads, rows, st, wrow, scale);
 }

@@ -366,6 +366,46 @@ class _CriticHeadOwnAction(torch.autograd.Function):
         return (dact.view(ctx.act_shape),) + (None,) * 10
 
 
+class _CriticHeadMSE(torch.autograd.Function):
+    """The value loss of the DDPG family (learning_algorithms/ddpg.py:36-38 == models/maddpg.py:122-124),
+        loss = sum_rows w[row] (returns[row] - v[row])^2,    w[row] = scale * wrow[row / n]   (wrow None: 1),
+    with v the critic head of _CriticHead — as ONE launch that produces the loss AND every gradient of it (mapdn_critic_head_mse):
+    d loss / d v = -2 w (returns - v) is known per row the moment v is, so the separate forward launch (a fifth 64 x 64 product over
+    all rows) disappears.  backward only scales the stored gradients by the incoming one (1 for `loss.backward()`)."""
+
+    @staticmethod
+    def forward(ctx, x, per_n, ln_w, ln_b, eps, w2, b2, w3, b3, returns, wrow, scale):
+        from . import _lib
+        lib = _lib.load()
+        x2 = x.detach().contiguous()
+        pn = per_n.detach().contiguous() if per_n is not None else None
+        n = pn.shape[0] if pn is not None else 1
+        rows, formed, dev = x2.shape[0] * n, pn is not None, x2.device
+        prm = tuple(t.detach().contiguous() for t in (ln_w, ln_b, w2, b2, w3.reshape(64), b3.reshape(1)))
+        ret = returns.detach().reshape(rows).contiguous().float()
+        wr = wrow.detach().contiguous().float() if wrow is not None else None
+        sc = scale.detach().reshape(1).contiguous().float()
+        dx = torch.empty_like(x2)
+        with torch.cuda.device(dev):
+            grads = torch.empty(4416 + (n * 64 if formed else 0), dtype=torch.float32, device=dev)
+            scratch = torch.empty(max(1, lib.mapdn_critic_head_scratch_floats(rows, n, int(formed))), dtype=torch.float32, device=dev)
+            _lib.check(lib.mapdn_critic_head_mse(ret.data_ptr(), wr.data_ptr() if wr is not None else None, sc.data_ptr(), x2.data_ptr(),
+                                                 pn.data_ptr() if formed else None, n, prm[0].data_ptr(), prm[1].data_ptr(), float(eps), prm[2].data_ptr(),
+                                                 prm[3].data_ptr(), prm[4].data_ptr(), prm[5].data_ptr(), dx.data_ptr(), grads.data_ptr(), scratch.data_ptr(),
+                                                 rows, torch.cuda.current_stream(dev).cuda_stream))
+        ctx.save_for_backward(dx, grads)
+        ctx.n, ctx.formed = n, formed
+        return grads[4353].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        dx, grads = ctx.saved_tensors
+        n, need = ctx.n, ctx.needs_input_grad
+        gs = grads * g
+        return (dx * g if need[0] else None, gs[4416:].view(n, 64) if ctx.formed and need[1] else None, gs[4096:4160], gs[4160:4224], None,
+                gs[:4096].view(64, 64), gs[4224:4288], gs[4288:4352].view(1, 64), gs[4352:4353], None, None, None)
+
+
 def critic_head_ok(cr: "MLPCritic", x: torch.Tensor, rows: int) -> bool:
     """the one-launch critic head covers the reference's default critic (LayerNorm, ReLU, hidden size 64, one output) in fp32 on the GPU"""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[-1] == 64 and rows >= 1024 and rows < 2 ** 31 and cr.use_ln
@@ -648,6 +688,40 @@ class DDPGNet(nn.Module):
             return v.view(b, n, 1)
         return torch.stack([cr.trunk(first_layer(cr, i))[0] for i, cr in enumerate(self.value_dicts)], 1)
 
+    def value_mse(self, obs, act, returns, valid=None):
+        """mean over (batch, agent) of (returns - Q(obs, act))^2 — the value loss of maddpg.py:122-124 / ddpg.py:36-38 — weighted by
+        `valid` [b] when given (1 everywhere = the reference).  With the default critic on the GPU the loss and its gradients come out of
+        ONE head launch (_CriticHeadMSE); otherwise value() + the plain expression."""
+        b, n, o = obs.shape[0], self.n_, self.obs_dim
+        a = self.args
+        ids = n if a.agent_id else 0
+        if (a.shared_params and torch.is_grad_enabled() and not act.requires_grad and obs.is_cuda
+                and os.environ.get("MAPDN_FUSED_MSE", "1") != "0"):
+            cr = self.value_dicts[0]
+            w = cr.fc1.weight
+            x = per_n = None
+            if self.alg == "maddpg" and ids and cr.use_ln:
+                x = F.linear(obs.reshape(b, n * o), w[:, :n * o], cr.fc1.bias) + F.linear(act.reshape(b, n * self.act_dim), w[:, n * o + ids:])
+                per_n = w[:, n * o:n * o + n].t()
+            elif self.alg == "iddpg":
+                x = F.linear(obs, w[:, :o], cr.fc1.bias) + F.linear(act, w[:, o + ids:])
+                if ids:
+                    x = x + w[:, o:o + n].t().unsqueeze(0)
+                x = x.reshape(b * n, -1)
+            if x is not None and critic_head_ok(cr, x, b * n):
+                if valid is None:
+                    scale, wrow = x.new_full((1,), 1.0 / (b * n)), None
+                else:
+                    vf = valid.float().view(-1)
+                    scale = (1.0 / (vf.sum().clamp(min=1.0) * n)).reshape(1)
+                    wrow = vf if per_n is not None else vf.repeat_interleave(n)
+                ln = cr.layernorm
+                return _CriticHeadMSE.apply(x, per_n, ln.weight, ln.bias, ln.eps, cr.fc2.weight, cr.fc2.bias, cr.fc3.weight, cr.fc3.bias,
+                                            returns, wrow, scale)
+        values = self.value(obs, act).view(-1, n)
+        d2 = (returns - values).pow(2)
+        return d2.mean() if valid is None else (d2 * valid.float().view(-1, 1)).sum() / (valid.float().sum().clamp(min=1.0) * d2.shape[1])
+
     # ---- action selection (maddpg.py:81-101 == iddpg.py:60-80; utilities/util.py:52-98) ----------
     def get_actions(self, state, status, exploration, actions_avail, target=False, last_hid=None):
         net = self.target_net if (target and self.args.target) else self
@@ -714,8 +788,7 @@ class DDPGNet(nn.Module):
                                                                     not self.args.double_q, hid)
                     next_values = self.target_net.value(next_state, next_actions).view(-1, n)
                 returns = rewards + self.args.gamma * (1 - done) * next_values
-            values = self.value(state, actions).view(-1, n)
-            value_loss = wmean((returns - values).pow(2))
+            value_loss = self.value_mse(state, actions, returns, valid)
         return policy_loss, value_loss, action_out
 
 

@@ -29,7 +29,7 @@ def _stock(cr, x):
 
 
 def _close(a, b, tol, what):
-    scale = max(1.0, float(b.abs().max()))
+    scale = max(1.0, float(b.detach().abs().max()))
     err = float((a.double() - b.double()).abs().max())
     assert err <= tol * scale, (what, err, scale)
 
@@ -166,3 +166,43 @@ def test_head_refuses_bad_arguments():
     assert lib.mapdn_critic_head_forward(p, p, 7, p, p, 1e-5, p, p, p, p, p, 20, None) == -1     # rows not a multiple of n
     assert lib.mapdn_critic_head_forward(None, None, 1, p, p, 1e-5, p, p, p, p, p, 16, None) == -1
     assert lib.mapdn_critic_head_scratch_floats(0, 1, 0) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,n,formed,weighted", [(700, 38, True, False), (5000, 22, True, True), (300, 6, False, True), (40000, 1, False, False)])
+def test_fused_value_loss_matches_the_modules(nb, n, formed, weighted):
+    """mapdn_critic_head_mse: sum_rows w (returns - v)^2 and every gradient of it out of one launch (no forward launch), against the
+    same expression through the stock modules with autograd; the incoming gradient scales the result."""
+    from mapdn_amd.learner import _CriticHeadMSE
+    dev = torch.device("cuda:0")
+    cr = _critic(dev, nb + n + 1)
+    prm = [dict(cr.named_parameters())[k] for k in HEAD_PARAMS]
+    g = torch.Generator(device="cpu").manual_seed(nb * 10 + n)
+    rows = nb * n
+    if formed:
+        base = (1.2 * torch.randn(nb, 64, generator=g)).to(dev).requires_grad_(True)
+        pern = (0.8 * torch.randn(n, 64, generator=g)).to(dev).requires_grad_(True)
+        x = (base.unsqueeze(1) + pern.unsqueeze(0)).reshape(rows, 64)
+        leaves = [base, pern]
+    else:
+        xin = (1.2 * torch.randn(rows, 64, generator=g)).to(dev).requires_grad_(True)
+        x, pern, leaves = xin, None, [xin]
+    ret = torch.randn(rows, generator=g).to(dev)
+    valid = (torch.rand(nb, generator=g) < 0.7).float().to(dev) if weighted else None
+    if valid is None:
+        scale, wrow, wfull = torch.full((1,), 1.0 / rows, device=dev), None, torch.full((rows,), 1.0 / rows, device=dev, dtype=torch.float64)
+    else:
+        scale = (1.0 / (valid.sum().clamp(min=1.0) * n)).reshape(1)
+        wrow = valid if formed else valid.repeat_interleave(n)
+        wfull = valid.repeat_interleave(n).double() * scale.double()
+    ln = cr.layernorm
+    loss = _CriticHeadMSE.apply(leaves[0], pern if formed else None, ln.weight, ln.bias, ln.eps, cr.fc2.weight, cr.fc2.bias, cr.fc3.weight,
+                                cr.fc3.bias, ret, wrow, scale)
+    got = torch.autograd.grad(3.0 * loss, leaves + prm)
+    ref = (wfull * (ret.double() - _stock(cr, x).view(-1)) ** 2).sum()
+    want = torch.autograd.grad(3.0 * ref, leaves + prm)
+    assert abs(loss.item() - ref.item()) <= 3e-6 * max(1.0, abs(ref.item()))
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a.shape == b.shape
+        err, ref_max = float((a.double() - b).abs().max()), float(b.abs().max())
+        assert err <= 2e-4 * ref_max, (i, err, ref_max)                  # (the weights are 1 / rows: gradients of order 1e-6 — relative bar)
