@@ -36,4 +36,18 @@ test-gpu: $(LIB)
 bench: $(LIB)
 	python bench.py
 
-.PHONY: lib test-cpu test-gpu bench
+# SURVEY section 5 "sanitizers" row: the HOST C++ of the library (plan.cpp's index arithmetic, the C ABI in capi.hip) under
+# AddressSanitizer + UndefinedBehaviorSanitizer (device code is not instrumented: -fno-gpu-sanitize; GPU ASan is not available on
+# this pool).  Every CPU test that reaches the plan through mapdn_create(..., device = -1) — the 24 random trees and forests of
+# tests/test_topology_stress.py, the meshed nets of tests/test_general_topology.py, bus fusion, ingestion, the C-ABI checks — runs
+# against build/libmapdn_hip_asan.so with the sanitizer runtime preloaded into python; any report is fatal.
+ASAN_RT := $(shell /opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
+asan:
+	@mkdir -p build
+	MAPDN_BUILD_OUT=$(CURDIR)/build/libmapdn_hip_asan.so \
+	MAPDN_EXTRA_FLAGS="-fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -g -shared-libsan" python -m mapdn_amd.build --force
+	LD_PRELOAD=$(ASAN_RT) ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+	MAPDN_LIB_PATH=$(CURDIR)/build/libmapdn_hip_asan.so python -m pytest tests/test_topology_stress.py tests/test_general_topology.py \
+	    tests/test_capi_cpu.py tests/test_bus_fusion.py tests/test_data_ingestion.py tests/test_data_formats.py -q -m "not gpu" -p no:cacheprovider
+
+.PHONY: lib test-cpu test-gpu bench asan

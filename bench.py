@@ -39,6 +39,14 @@ def algorithmic_bytes_per_env_step(env):
     return 8 * (2 * nl + 2 * ns) + 8 * 2 * nb + 4 * env.n_agents * env.obs_size + (8 + 1 + 8 * 11)
 
 
+def solver_bytes_per_env_step(env):
+    """what the k_nr_tree launch ITSELF must move per env: read Sbus 16 n + q 8 ns; write e, f 16 n, pl 8 n_line,
+    q 8 ns, reward / terminated / info 97 B (n = non-slack buses, n_line = n on a radial feeder).  The obs / state outputs and the
+    profile rows belong to k_gather / k_advance: they are in algorithmic_bytes_per_env_step, not here."""
+    n, ns = env.n_bus - 1, env.n_sgen
+    return 16 * n + 8 * ns + 16 * n + 8 * n + 8 * ns + (8 + 1 + 8 * 11)
+
+
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def _oracle_args(case):
     return dict(episode_limit=240, action_scale=SCALE[case], action_bias=0.0, voltage_barrier_type="bowl", seed=0)
@@ -220,7 +228,7 @@ def measure_traffic(case, envs):
 
 
 def committed_traffic(case, envs):
-    for tag in ("r04_final", "r03_final", "r02_final", "r02_base", "r01"):
+    for tag in ("r06_final", "r05_final", "r04_final", "r03_final", "r02_final", "r02_base", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_traffic_{case}_b{envs}.json")
         if os.path.exists(path):
             return json.load(open(path))["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
@@ -387,9 +395,20 @@ def main():
         resets_in_region = resets[0]
         stats = env.stats()
         # ---- dominant kernel (NR solve) duration, HIP events on its launch stream, separate short pass
+        # (>= 240 step launches whatever --steps is: 20 launches gave +-5 %; the power flow of a reset — another launch shape, no fused
+        # prologue — is kept OUT of the average: timing is off around it)
         env.nr_timing(True)
-        for _ in range(min(a.steps, 60)):
-            one_step()
+        for _ in range(max(240, min(a.steps, 480))):
+            act = acts[step_no[0] % n_act]
+            step_no[0] += 1
+            env.step(act)
+            env.get_obs()
+            steps_in_ep[0] += 1
+            if steps_in_ep[0] >= env.episode_limit - 1:
+                env.nr_timing(False)
+                env.reset()
+                env.nr_timing(True)
+                steps_in_ep[0] = 0
         torch.cuda.synchronize(dev)
         nr_ms, nr_launches = env.nr_time_ms()
         env.nr_timing(False)
@@ -414,7 +433,8 @@ def main():
     blocks_sorted = sorted(blocks)
     dt = blocks_sorted[len(blocks) // 2]
     kname = "k_nr_tree"
-    head = dict(n_bus=env.n_bus, n_agents=env.n_agents, obs_size=env.obs_size, bytes_step=algorithmic_bytes_per_env_step(env))
+    head = dict(n_bus=env.n_bus, n_agents=env.n_agents, obs_size=env.obs_size, bytes_step=algorithmic_bytes_per_env_step(env),
+                solver_bytes=solver_bytes_per_env_step(env))
     env.close()
 
     # ---- the other shapes north_star names, in the same run and under the same clock (short: 0.2 s of timed blocks each):
@@ -436,6 +456,9 @@ def main():
                            "nr_iterations": {"mean": m2["stats"]["mean_nr_iters"], "max": m2["stats"]["max_nr_iters"]},
                            "roofline": {"bound": "hbm", "achieved": by2 * b2 / nr2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": by2 * b2 / nr2 / 1e9 / HBM_PEAK_GBS, "kernel_avg_ms": nr2 * 1e3,
+                                        "frac_kernel_bytes": solver_bytes_per_env_step(e2) * b2 / nr2 / 1e9 / HBM_PEAK_GBS,
+                                        "frac_step": by2 * b2 / (d2 / a.steps) / 1e9 / HBM_PEAK_GBS,
+                                        "kernel_launches_timed": m2["nr_launches"],
                                         "algorithmic_bytes_per_env_step": by2, "traffic": tr2,
                                         "traffic_source": (f"committed rocprofv3 PMC passes: {trsrc2}" if trsrc2 else None)}})
             e2.close()
@@ -507,11 +530,20 @@ def main():
                          "kernel_scope": "one k_nr_tree launch = PV-bus injection (prologue, since round 4: it was a launch of its own, "
                                          "6.8 us, before) + Newton-Raphson solve + reward / res_line / sgen commit epilogue",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         # the same roof read two other ways: `frac` divides the WHOLE step's bytes (obs
+                         # output included) by the solver launch's time; frac_kernel_bytes = the solver launch's own bytes / its time;
+                         # frac_step = the whole step's bytes / the whole step's time (ms_per_step: k_nr_tree + k_advance + k_gather)
+                         "frac_kernel_bytes": head["solver_bytes"] * B / nr_avg_s / 1e9 / HBM_PEAK_GBS,
+                         "frac_step": bytes_step * B / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
+                         "kernel_bytes_per_env_step": head["solver_bytes"],
+                         "traffic": traffic, "traffic_source": tsrc,
                          "traffic_detail": tdetail,
                          "algorithmic_bytes_per_launch": bytes_step * B,
                          "algorithmic_bytes_per_env_step": bytes_step, "envs_per_launch": B,
-                         "kernel_avg_ms": nr_avg_s * 1e3, "kernel_avg_ms_per_rank": nr_per_rank, "kernel_launches_timed": nr_launches},
+                         "kernel_avg_ms": nr_avg_s * 1e3, "kernel_avg_ms_per_rank": nr_per_rank, "kernel_launches_timed": nr_launches,
+                         "kernel_timing": "HIP events on the launch stream around every step's k_nr_tree launch (>= 240 launches; the reset's "
+                                          "power flow excluded); the events add ~3 us of command-processor time to rocprofv3's kernel duration"},
             # compute-side view: ~184 * nb f64 flops per NR iteration (SpMV, mismatch, Jacobian,
             # block-tree solve, update) x (iterations + 1 mismatch evaluation), against the f64 vector peak
             "compute": {"algorithmic_flops_per_env_step": flops_step, "achieved_tflops": tfl, "peak_tflops": FP64_PEAK_TFLOPS,

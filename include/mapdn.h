@@ -34,6 +34,8 @@ extern "C" {
 #define MAPDN_E_TOPOLOGY (-2)  /* net not connected, or meshed and too large for a CU's LDS        */
 #define MAPDN_E_HIP (-3)       /* HIP runtime error (no device, OOM, launch failure)           */
 #define MAPDN_E_STATE (-4)     /* call order violated (e.g. step before set_profiles/reset)    */
+#define MAPDN_E_NOMEM (-5)     /* host allocation failed (std::bad_alloc caught at the boundary)  */
+#define MAPDN_E_INTERNAL (-6)  /* any other C++ exception caught at the boundary (text: mapdn_last_error) */
 
 #define MAPDN_N_INFO 11        /* keys of `info`, voltage_control_env.py:586-606,621 — column order:
                                   percentage_of_v_out_of_control, percentage_of_lower_than_lower_v,

@@ -89,7 +89,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
             objs = list(ex.map(run, jobs))
         tmp = LIB + f".tmp{os.getpid()}"
-        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [f for f in extra if f.startswith("-fsanitize") or f == "-fno-gpu-sanitize"] \
+            + ["-o", tmp] + objs
         if verbose:
             print(" ".join(link), file=sys.stderr)
         subprocess.run(link, check=True)

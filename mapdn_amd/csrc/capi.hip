@@ -54,6 +54,17 @@ struct mapdn_handle {
 
 static std::string g_create_err;
 
+// Nothing may leave an extern "C" entry point by exception: every one of them is a function-try-block ending in
+// MAPDN_CATCH, which turns std::bad_alloc into MAPDN_E_NOMEM and anything else into MAPDN_E_INTERNAL, with the text in mapdn_last_error.
+static int api_fail(const mapdn_handle* h, int code, const char* what) noexcept {
+  try { (h ? const_cast<mapdn_handle*>(h)->err : g_create_err) = what; } catch (...) {}      // (the message itself may not fit any more)
+  return code;
+}
+#define MAPDN_CATCH(h)                                                                                       \
+  catch (const std::bad_alloc&) { return api_fail((h), MAPDN_E_NOMEM, "out of host memory (std::bad_alloc)"); } \
+  catch (const std::exception& e) { return api_fail((h), MAPDN_E_INTERNAL, e.what()); }                      \
+  catch (...) { return api_fail((h), MAPDN_E_INTERNAL, "unknown C++ exception"); }
+
 #define NEEDDEV(h) do { if ((h)->host_only) { (h)->err = "host-only handle (device == -1): no device entry points"; return MAPDN_E_STATE; } } while (0)
 #define HIPCHK(h, call)                                                                         \
   do {                                                                                          \
@@ -570,11 +581,17 @@ static int create_impl(mapdn_handle* h, const mapdn_netspec* net, const mapdn_en
 int mapdn_create(const mapdn_netspec* net, const mapdn_env_config* cfg, int32_t n_envs, int32_t device, mapdn_handle** out) {
   if (!out) { g_create_err = "null out pointer"; return MAPDN_E_INVALID; }
   *out = nullptr;
-  mapdn_handle* h = new mapdn_handle();
-  int rc = create_impl(h, net, cfg, n_envs, device);
-  if (rc) { g_create_err = h->err; mapdn_destroy(h); return rc; }
-  *out = h;
-  return MAPDN_OK;
+  mapdn_handle* h = nullptr;
+  try {
+    h = new mapdn_handle();
+    const int rc = create_impl(h, net, cfg, n_envs, device);        // plan.cpp: dozens of std::vector / std::string allocations
+    if (rc) { g_create_err = h->err; mapdn_destroy(h); return rc; }
+    *out = h;
+    return MAPDN_OK;
+  } catch (...) {
+    mapdn_destroy(h);                                                // (frees whatever the half-built handle owns; null is fine)
+    try { throw; } MAPDN_CATCH(nullptr)
+  }
 }
 
 void mapdn_destroy(mapdn_handle* h) {
@@ -587,17 +604,17 @@ void mapdn_destroy(mapdn_handle* h) {
   delete h;
 }
 
-int mapdn_dims(const mapdn_handle* h, mapdn_dims_t* out) {
+int mapdn_dims(const mapdn_handle* h, mapdn_dims_t* out) try {
   if (!h || !out) return MAPDN_E_INVALID;
   const Plan& P = h->plan;
   out->n_envs = h->d.B; out->n_bus = P.nbo; out->n_line = P.n_line; out->n_load = P.nl; out->n_sgen = P.ns;
   out->n_agents = P.n_agents; out->n_actions = 1; out->obs_size = P.obs_size; out->state_size = P.state_size;
   out->n_info = MAPDN_N_INFO; out->is_radial = P.radial ? 1 : 0; out->max_zone_size = P.max_zone;
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
 int mapdn_set_profiles(mapdn_handle* h, const double* pv, const double* load_p, const double* load_q,
-                       int64_t T, int32_t time_delta_min, int32_t days) {
+                       int64_t T, int32_t time_delta_min, int32_t days) try {
   if (!h) return MAPDN_E_INVALID;
   if (!pv || !load_p || !load_q || T < 2) { h->err = "set_profiles: null table or too few rows"; return MAPDN_E_INVALID; }
   if (time_delta_min <= 0 || 60 % time_delta_min) { h->err = "set_profiles: time_delta_min must divide 60"; return MAPDN_E_INVALID; }
@@ -644,7 +661,7 @@ int mapdn_set_profiles(mapdn_handle* h, const double* pv, const double* load_p, 
   d.table = h->table; d.stdv = h->stdv; d.smax = h->smax; d.T = T;
   h->have_profiles = true;
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
 static void nr_launch(mapdn_handle* h, int mode, double* reward, uint8_t* term, double* info, hipStream_t st,
                       const void* fused_actions = nullptr, int fused_dtype = 0) {
@@ -711,7 +728,7 @@ static int step_launches(mapdn_handle* h, const void* actions, int32_t actions_d
   return MAPDN_OK;
 }
 
-int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, int32_t max_tries, void* stream) {
+int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, int32_t max_tries, void* stream) try {
   if (!h) return MAPDN_E_INVALID;
   if (!h->have_profiles) { h->err = "reset before set_profiles"; return MAPDN_E_STATE; }
   if (max_tries < 1) max_tries = 1;
@@ -730,10 +747,10 @@ int mapdn_reset(mapdn_handle* h, const int64_t* start_rows, int32_t add_noise, i
   HIPCHK(h, hipGetLastError());
   h->was_reset = true;
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
 int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int32_t add_noise, double* reward,
-               uint8_t* terminated, double* info, void* stream) {
+               uint8_t* terminated, double* info, void* stream) try {
   if (!h) return MAPDN_E_INVALID;
   if (!h->was_reset) { h->err = "step before reset"; return MAPDN_E_STATE; }
   if (!actions || !reward || !terminated || !info) { h->err = "step: null buffer"; return MAPDN_E_INVALID; }
@@ -746,10 +763,10 @@ int mapdn_step(mapdn_handle* h, const void* actions, int32_t actions_dtype, int3
   (void)d;
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
 int mapdn_step_obs(mapdn_handle* h, const void* actions, int32_t actions_dtype, int32_t add_noise, double* reward,
-                   uint8_t* terminated, double* info, void* obs, int32_t obs_dtype, void* stream) {
+                   uint8_t* terminated, double* info, void* obs, int32_t obs_dtype, void* stream) try {
   if (!h) return MAPDN_E_INVALID;
   if (!h->was_reset) { h->err = "step before reset"; return MAPDN_E_STATE; }
   if (!actions || !reward || !terminated || !info || !obs) { h->err = "step_obs: null buffer"; return MAPDN_E_INVALID; }
@@ -764,9 +781,9 @@ int mapdn_step_obs(mapdn_handle* h, const void* actions, int32_t actions_dtype, 
   launch_gather(d, d.gbuf, h->obs_rows, h->obs_scale, 1.0, h->obs_xptr, h->obs_xrow, obs, obs_dtype, C, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_get_obs(mapdn_handle* h, void* obs, int32_t dtype, void* stream) {
+int mapdn_get_obs(mapdn_handle* h, void* obs, int32_t dtype, void* stream) try {
   if (!h || !obs) return MAPDN_E_INVALID;
   if (!h->was_reset) { h->err = "get_obs before reset"; return MAPDN_E_STATE; }
   NEEDDEV(h);
@@ -776,9 +793,9 @@ int mapdn_get_obs(mapdn_handle* h, void* obs, int32_t dtype, void* stream) {
                 h->plan.n_agents * h->plan.obs_size, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_get_state(mapdn_handle* h, void* state, int32_t dtype, void* stream) {
+int mapdn_get_state(mapdn_handle* h, void* state, int32_t dtype, void* stream) try {
   if (!h || !state) return MAPDN_E_INVALID;
   if (!h->was_reset) { h->err = "get_state before reset"; return MAPDN_E_STATE; }
   NEEDDEV(h);
@@ -787,14 +804,14 @@ int mapdn_get_state(mapdn_handle* h, void* state, int32_t dtype, void* stream) {
   launch_gather(h->d, h->d.gbuf, h->state_rows, h->state_scale, 1.0, nullptr, nullptr, state, dtype, h->plan.state_size, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
 static void transpose_out(mapdn_handle* h, const double* src, double scale, const int32_t* rows, double* out, int n, hipStream_t st) {
   launch_gather(h->d, src, rows, nullptr, scale, nullptr, nullptr, out, MAPDN_F64, n, st);
 }
 
 int mapdn_get_results(mapdn_handle* h, double* vm_pu, double* va_degree, double* p_mw, double* q_mvar, double* pl_mw,
-                      double* sgen_p, double* sgen_q, void* stream) {
+                      double* sgen_p, double* sgen_q, void* stream) try {
   if (!h) return MAPDN_E_INVALID;
   if (!h->was_reset) { h->err = "get_results before reset"; return MAPDN_E_STATE; }
   NEEDDEV(h);
@@ -810,9 +827,9 @@ int mapdn_get_results(mapdn_handle* h, double* vm_pu, double* va_degree, double*
   if (sgen_q) transpose_out(h, d.cur_q, 1.0, h->iota_idx, sgen_q, d.ns, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_get_loads(mapdn_handle* h, double* load_p, double* load_q, void* stream) {
+int mapdn_get_loads(mapdn_handle* h, double* load_p, double* load_q, void* stream) try {
   if (!h) return MAPDN_E_INVALID;
   NEEDDEV(h);
   HIPCHK(h, hipSetDevice(h->device));
@@ -821,34 +838,34 @@ int mapdn_get_loads(mapdn_handle* h, double* load_p, double* load_q, void* strea
   if (load_q) transpose_out(h, h->d.cur_ql, 1.0, h->iota_idx, load_q, h->d.nl, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_get_start_rows(mapdn_handle* h, int64_t* start_rows, void* stream) {
+int mapdn_get_start_rows(mapdn_handle* h, int64_t* start_rows, void* stream) try {
   if (!h || !start_rows) return MAPDN_E_INVALID;
   NEEDDEV(h);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(start_rows, h->d.start_row, (size_t)h->d.B * sizeof(int64_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_get_auto_reset_mask(mapdn_handle* h, uint8_t* mask, void* stream) {
+int mapdn_get_auto_reset_mask(mapdn_handle* h, uint8_t* mask, void* stream) try {
   if (!h || !mask) return MAPDN_E_INVALID;
   NEEDDEV(h);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(mask, h->d.resetting, (size_t)h->d.B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_get_returns(mapdn_handle* h, double* returns, void* stream) {
+int mapdn_get_returns(mapdn_handle* h, double* returns, void* stream) try {
   if (!h || !returns) return MAPDN_E_INVALID;
   NEEDDEV(h);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(returns, h->d.sum_rewards, (size_t)h->d.B * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
 int mapdn_solve_only(mapdn_handle* h, const double* p_load, const double* q_load, const double* p_sgen, const double* q_sgen,
-                     double* vm_pu, double* va_degree, int32_t* iterations, uint8_t* converged, void* stream) {
+                     double* vm_pu, double* va_degree, int32_t* iterations, uint8_t* converged, void* stream) try {
   if (!h) return MAPDN_E_INVALID;
   if (!p_load || !q_load || !p_sgen || !q_sgen) { h->err = "solve_only: null input"; return MAPDN_E_INVALID; }
   NEEDDEV(h);
@@ -870,23 +887,23 @@ int mapdn_solve_only(mapdn_handle* h, const double* p_load, const double* q_load
   if (converged) launch_copy_u8(d.conv, converged, d.B, st);
   HIPCHK(h, hipGetLastError());
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_get_ybus_dense(const mapdn_handle* h, double* out) {
+int mapdn_get_ybus_dense(const mapdn_handle* h, double* out) try {
   if (!h || !out) return MAPDN_E_INVALID;
   const Plan& P = h->plan;
   for (size_t i = 0; i < P.ybus.size(); ++i) { out[2 * i] = P.ybus[i].real(); out[2 * i + 1] = P.ybus[i].imag(); }
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_get_obs_index(const mapdn_handle* h, int32_t* kind, int32_t* index) {
+int mapdn_get_obs_index(const mapdn_handle* h, int32_t* kind, int32_t* index) try {
   if (!h || !kind || !index) return MAPDN_E_INVALID;
   std::memcpy(kind, h->plan.obs_kind.data(), h->plan.obs_kind.size() * sizeof(int32_t));
   std::memcpy(index, h->plan.obs_idx.data(), h->plan.obs_idx.size() * sizeof(int32_t));
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_get_nr_geometry(const mapdn_handle* h, int32_t* out) {
+int mapdn_get_nr_geometry(const mapdn_handle* h, int32_t* out) try {
   if (!h || !out) return MAPDN_E_INVALID;
   const mapdn_handle::Geo& g = h->geo;
   const bool fuse_possible = h->solver == 0 && !h->cfg.auto_reset && !knob_int(h->cfg.inject_full, "MAPDN_INJECT_FULL") &&
@@ -897,9 +914,9 @@ int mapdn_get_nr_geometry(const mapdn_handle* h, int32_t* out) {
   std::memcpy(out, v, sizeof(v));
   if (h->solver == 1) out[2] = h->sp_lanes;
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_get_flat_factors(const mapdn_handle* h, double* factors, int32_t* bus_of_pos) {
+int mapdn_get_flat_factors(const mapdn_handle* h, double* factors, int32_t* bus_of_pos) try {
   if (!h || !factors) return MAPDN_E_INVALID;
   if (!h->plan.radial) return MAPDN_E_TOPOLOGY;   // the tree factorisation exists for radial feeders only
   Schedule S;
@@ -911,9 +928,9 @@ int mapdn_get_flat_factors(const mapdn_handle* h, double* factors, int32_t* bus_
   }
   if (bus_of_pos) std::memcpy(bus_of_pos, h->plan.bus_of_pos.data(), (size_t)(n + 1) * sizeof(int32_t));
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_get_schedule(const mapdn_handle* h, int32_t W, int32_t* n_rows, int32_t* rows, int32_t* parent) {
+int mapdn_get_schedule(const mapdn_handle* h, int32_t W, int32_t* n_rows, int32_t* rows, int32_t* parent) try {
   if (!h || !n_rows || W < 1 || W > 16) return MAPDN_E_INVALID;
   if (!h->plan.radial) return MAPDN_E_TOPOLOGY;
   Schedule S;
@@ -922,9 +939,9 @@ int mapdn_get_schedule(const mapdn_handle* h, int32_t W, int32_t* n_rows, int32_
   if (rows) for (size_t i = 0; i < S.steps.size(); ++i) rows[i] = (S.steps[i].flags & S_LIVE) ? (int32_t)(S.steps[i].kp & 0xffffu) : -1;
   if (parent) std::memcpy(parent, h->plan.par.data(), h->plan.par.size() * sizeof(int32_t));
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_get_sparse_program(const mapdn_handle* h, int32_t S, int32_t* dims, int32_t* ops, int32_t* order, int32_t* slots_ij) {
+int mapdn_get_sparse_program(const mapdn_handle* h, int32_t S, int32_t* dims, int32_t* ops, int32_t* order, int32_t* slots_ij) try {
   if (!h || !dims || S < 1 || S > 64) return MAPDN_E_INVALID;
   SparseProg G;
   sparse_program(h->plan, S, G);
@@ -934,15 +951,15 @@ int mapdn_get_sparse_program(const mapdn_handle* h, int32_t S, int32_t* dims, in
   if (order) std::memcpy(order, G.order.data(), G.order.size() * sizeof(int32_t));
   if (slots_ij) std::memcpy(slots_ij, G.slots_ij.data(), G.slots_ij.size() * sizeof(int32_t));
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_dense_solve(const double* a, const double* b, double* x, int32_t n, int32_t batch, void* stream) {
+int mapdn_dense_solve(const double* a, const double* b, double* x, int32_t n, int32_t batch, void* stream) try {
   if (!a || !b || !x) return MAPDN_E_INVALID;
   const int rc = dense_solve_debug(a, b, x, n, batch, (hipStream_t)stream);
   return rc == 0 ? MAPDN_OK : (rc == -1 ? MAPDN_E_INVALID : MAPDN_E_HIP);
-}
+} MAPDN_CATCH(nullptr)
 
-int mapdn_stats(mapdn_handle* h, int64_t* reset_failures, double* mean_iters, int32_t* max_iters, void* stream) {
+int mapdn_stats(mapdn_handle* h, int64_t* reset_failures, double* mean_iters, int32_t* max_iters, void* stream) try {
   if (!h) return MAPDN_E_INVALID;
   NEEDDEV(h);
   HIPCHK(h, hipSetDevice(h->device));
@@ -955,15 +972,15 @@ int mapdn_stats(mapdn_handle* h, int64_t* reset_failures, double* mean_iters, in
   if (mean_iters) *mean_iters = host[2] ? (double)host[1] / (double)host[2] : 0.0;
   if (max_iters) *max_iters = (int32_t)host[3];
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_nr_timing(mapdn_handle* h, int32_t enable) {
+int mapdn_nr_timing(mapdn_handle* h, int32_t enable) try {
   if (!h) return MAPDN_E_INVALID;
   h->timing = enable != 0;
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
-int mapdn_nr_time_ms(mapdn_handle* h, double* total_ms, int64_t* launches) {
+int mapdn_nr_time_ms(mapdn_handle* h, double* total_ms, int64_t* launches) try {
   if (!h) return MAPDN_E_INVALID;
   NEEDDEV(h);
   HIPCHK(h, hipSetDevice(h->device));
@@ -978,6 +995,6 @@ int mapdn_nr_time_ms(mapdn_handle* h, double* total_ms, int64_t* launches) {
   if (total_ms) *total_ms = ms;
   if (launches) *launches = n;
   return MAPDN_OK;
-}
+} MAPDN_CATCH(h)
 
 }  // extern "C"
