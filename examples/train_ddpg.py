@@ -45,20 +45,36 @@ def main():
     ap.add_argument("--update-freq", type=int, default=60)
     ap.add_argument("--voltage-barrier", default="bowl")
     ap.add_argument("--save", default=None)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm); 'gloo' only to exercise the N-rank "
+                                                      "data-parallel learner with ranks sharing GPUs (pre-flight on a 1-GPU box)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed at world size 1 as well: the learner's broadcast, flat "
+                                                              "gradient all-reduce and early-exit all-reduce run through the backend on one rank")
     ap.add_argument("--phases", action="store_true", help="per-phase device time of every episode in the JSON line (CUDA events around "
                                                          "replay insertion / sampling / value update / policy update / target update; rollout = the rest)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.backend != "nccl":                                   # test mode: ranks may share a GPU
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if "MASTER_ADDR" not in os.environ:                   # --force-dist without a launcher: a one-rank rendezvous on the loopback
+            import socket
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
     from mapdn_amd import e2e
 
     def emit(line):
+        if use_dist:
+            line["dist"] = {"backend": a.backend, "world_size": world, "rccl_loaded": "librccl" in open("/proc/self/maps").read()}
         if rank == 0:
             print(json.dumps(line), flush=True)
             if a.log:
@@ -66,8 +82,9 @@ def main():
                     f.write(json.dumps(line) + "\n")
     e2e.run(case=a.case, envs=a.envs, alg=a.alg, episodes=a.episodes, max_steps=a.max_steps, intensity=a.intensity, batch_size=a.batch_size,
             updates_per_env_step=a.updates_per_env_step, replay_steps=a.replay_steps, update_freq=a.update_freq,
-            voltage_barrier=a.voltage_barrier, phases=a.phases, device=dev, rank=rank, world=world, save=a.save, on_line=emit)
-    if world > 1:
+            voltage_barrier=a.voltage_barrier, phases=a.phases, device=dev, rank=rank, world=world, save=a.save, on_line=emit,
+            check_replicas=use_dist)
+    if use_dist:
         dist.barrier(); dist.destroy_process_group()
 
 

@@ -19,7 +19,7 @@ SCALE = {"case33": 0.8, "case141": 0.6, "case322": 0.8}
 
 def run(case="case322", envs=8192, alg="maddpg", episodes=3, max_steps=240, intensity="reference", batch_size=4096,
         updates_per_env_step=None, replay_steps=64, update_freq=60, voltage_barrier="bowl", phases=True, device=None, rank=0, world=1,
-        save=None, on_line=None):
+        save=None, on_line=None, check_replicas=False):
     """Runs `episodes` training episodes and returns one dict per episode (rank 0 semantics: env_steps_per_s is the whole job's).
     `on_line(dict)` is called after every episode (the CLI prints / logs there)."""
     import numpy as np
@@ -67,6 +67,11 @@ def run(case="case322", envs=8192, alg="maddpg", episodes=3, max_steps=240, inte
                 ph["rollout_and_host"] = dt - sum(ph.values())
                 line["phase_seconds"] = {k: round(v, 4) for k, v in ph.items()}
                 line["phase_share"] = {k: round(v / dt, 4) for k, v in ph.items()}
+            if check_replicas or world > 1:                     # data-parallel ranks must hold bit-identical replicas after every episode
+                line["replicas_identical"] = bool(trainer.replicas_identical())
+                line["learner_collectives"] = dict(trainer.collectives)
+                if not line["replicas_identical"]:
+                    raise RuntimeError(f"rank {rank}: the data-parallel replicas diverged in episode {ep}")
             line.update({k: v for k, v in stat.items() if k in (
                 "mean_train_reward", "mean_train_value_loss", "mean_train_policy_loss", "mean_train_totally_controllable_ratio",
                 "mean_train_q_loss")})

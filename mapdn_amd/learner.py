@@ -754,7 +754,27 @@ class DDPGNet(nn.Module):
 
     # ---- loss (models/maddpg.py:103-125 == learning_algorithms/ddpg.py:15-39) ----------------------
     def normalise_reward(self, reward: torch.Tensor) -> torch.Tensor:
-        return self.batchnorm(reward) if self.args.reward_normalisation else reward     # model.py:316-317
+        """model.py:316-317: BatchNorm1d over the batch, per agent.  Data-parallel ranks (PGTrainer sets `_dp_all_reduce`) normalise with
+        the statistics of the UNION of their batches — one small all-reduce of (count, sum, sum of squares) — so that an N-rank update
+        equals the one-rank update on the concatenated batch and the running statistics stay identical on every replica."""
+        if not self.args.reward_normalisation:
+            return reward
+        bn, red = self.batchnorm, self.__dict__.get("_dp_all_reduce")
+        if red is None or not bn.training:
+            return bn(reward)
+        x = reward.double()
+        st = torch.cat((x.new_full((1,), float(x.shape[0])), x.sum(0), (x * x).sum(0)))
+        red(st)
+        cnt, n = st[0], x.shape[1]
+        mean = st[1:1 + n] / cnt
+        var = (st[1 + n:] / cnt - mean * mean).clamp(min=0.0)                      # biased, as BatchNorm normalises with
+        with torch.no_grad():
+            m = bn.momentum if bn.momentum is not None else 0.1
+            bn.running_mean.mul_(1 - m).add_(m * mean.to(bn.running_mean.dtype))
+            bn.running_var.mul_(1 - m).add_(m * (var * cnt / (cnt - 1).clamp(min=1.0)).to(bn.running_var.dtype))
+            bn.num_batches_tracked += 1
+        y = (reward - mean.to(reward.dtype)) * torch.rsqrt(var.to(reward.dtype) + bn.eps)
+        return y * bn.weight + bn.bias
 
     def get_loss(self, batch: Batch, want=("policy", "value")):
         """batch: state/next_state [bs, n, o], action/action_avail [bs, n, a], reward [bs, n], done [bs, 1],
@@ -821,9 +841,26 @@ class PGTrainer:
         self.entr = args.entr
         import torch.distributed as dist
         self._dist = dist if (data_parallel if data_parallel is not None else (dist.is_available() and dist.is_initialized())) else None
+        self.collectives = {"broadcast": 0, "all_reduce_grads": 0, "all_reduce_flag": 0, "all_reduce_reward_stats": 0}   # issued so far
+        if self._dist is not None:
+            def _bn_reduce(t):
+                self._collective(self._dist.all_reduce, t)
+                self.collectives["all_reduce_reward_stats"] += 1
+            self.behaviour_net.__dict__["_dp_all_reduce"] = _bn_reduce
         if self._dist is not None:                               # identical replicas to start from
             for t in self.behaviour_net.state_dict().values():
-                self._dist.broadcast(t, src=0)
+                self._collective(self._dist.broadcast, t, src=0)
+                self.collectives["broadcast"] += 1
+
+    def _collective(self, fn, t: torch.Tensor, **kw):
+        """fn(t, **kw) in place.  RCCL ("nccl") takes the device tensor as it is; any other backend (gloo: the CPU / one-GPU pre-flight of
+        the N-rank path) gets a host copy and the result is written back."""
+        if t.is_cuda and self._dist.get_backend() != "nccl":
+            h = t.detach().cpu()
+            fn(h, **kw)
+            t.copy_(h)
+        else:
+            fn(t, **kw)
 
     # ---- one optimiser step (trainer.py:73-98) ---------------------------------------------------
     def _all_reduce_grads(self, params):
@@ -831,11 +868,34 @@ class PGTrainer:
             return
         grads = [p.grad for p in params if p.grad is not None]
         flat = torch.cat([g.reshape(-1) for g in grads])
-        self._dist.all_reduce(flat)
+        self._collective(self._dist.all_reduce, flat)
+        self.collectives["all_reduce_grads"] += 1
         flat /= self._dist.get_world_size()
         off = 0
         for g in grads:
             g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+
+    def replica_fingerprint(self) -> torch.Tensor:
+        """[2] float64: (sum of every state_dict value, sum of their bit patterns read as integers) — equal on every rank exactly when the
+        replicas are (bit-)identical, which data-parallel training must keep them (same broadcast start, same averaged gradients, same
+        optimiser arithmetic).  replicas_identical() gathers and compares it."""
+        tot, bits = torch.zeros((), dtype=torch.float64, device=self.device), torch.zeros((), dtype=torch.float64, device=self.device)
+        for v in self.behaviour_net.state_dict().values():
+            if v.dtype == torch.float32:
+                tot += v.double().sum(); bits += v.contiguous().view(torch.int32).double().sum()
+            else:
+                tot += v.double().sum(); bits += v.double().sum()
+        return torch.stack((tot, bits))
+
+    def replicas_identical(self) -> bool:
+        if self._dist is None:
+            return True
+        fp = self.replica_fingerprint()
+        world = self._dist.get_world_size()
+        mine = fp if self._dist.get_backend() == "nccl" else fp.cpu()
+        out = [torch.empty_like(mine) for _ in range(world)]
+        self._dist.all_gather(out, mine)
+        return all(torch.equal(o, out[0]) for o in out)
 
     def _apply(self, optimizer, loss, stat, key):
         optimizer.zero_grad()
@@ -994,6 +1054,7 @@ class PGTrainer:
             if self._dist.get_backend() != "nccl":
                 flag = flag.cpu()
             self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX)
+            self.collectives["all_reduce_flag"] += 1
             return flag
 
         from .rollout import BatchedRollout

@@ -187,30 +187,37 @@ def _dp_batch(n, o, h, bs, seed):
                 action_avail=torch.ones(bs, n, 1), last_hid=0.3 * r(bs, n, h), hid=0.3 * r(bs, n, h))
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, reward_norm):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(100 + rank)                      # different initial weights: rank 0's must win (broadcast)
-    args = make_alg_args(3, 5, 1, hid_size=8, reward_normalisation=False)
+    args = make_alg_args(3, 5, 1, hid_size=8, reward_normalisation=reward_norm)
     tr = PGTrainer(args, "maddpg", env=None, device="cpu")
     assert tr._dist is not None
     stat = {}
     b = _dp_batch(3, 5, 8, 6, seed=7 + rank)
     tr.value_transition_process(stat, b)
     tr.policy_transition_process(stat, b)
+    assert tr.replicas_identical()
+    assert tr.collectives["all_reduce_grads"] == 2 and tr.collectives["broadcast"] > 0
+    assert tr.collectives["all_reduce_reward_stats"] == (2 if reward_norm else 0)
     q.put((rank, {k: v.numpy().copy() for k, v in tr.behaviour_net.state_dict().items()}))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_data_parallel_update_equals_union_batch():
+@pytest.mark.parametrize("reward_norm", [False, True])
+def test_data_parallel_update_equals_union_batch(reward_norm):
+    """two gloo ranks, one update round each on its own batch == one rank on the concatenated batch (round 6: with the reference's reward
+    BatchNorm ON as well — the ranks normalise with the statistics of the union — and the whole state_dict, running statistics included,
+    bit-identical across the ranks)"""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, reward_norm)) for r in range(2)]
     for p in ps:
         p.start()
     got = dict(q.get(timeout=180) for _ in range(2))
@@ -220,7 +227,7 @@ def test_data_parallel_update_equals_union_batch():
     for k in got[0]:
         assert np.array_equal(got[0][k], got[1][k]), k                   # replicas stay identical
     torch.manual_seed(100)
-    args = make_alg_args(3, 5, 1, hid_size=8, reward_normalisation=False)
+    args = make_alg_args(3, 5, 1, hid_size=8, reward_normalisation=reward_norm)
     tr = PGTrainer(args, "maddpg", env=None, device="cpu", data_parallel=False)
     b0, b1 = _dp_batch(3, 5, 8, 6, 7), _dp_batch(3, 5, 8, 6, 8)
     union = {k: torch.cat([b0[k], b1[k]]) for k in b0}
