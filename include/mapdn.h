@@ -228,6 +228,11 @@ int mapdn_dims(const mapdn_handle* h, mapdn_dims_t* out);
 int mapdn_set_profiles(mapdn_handle* h, const double* pv, const double* load_p, const double* load_q,
                        int64_t n_rows, int32_t time_delta_min, int32_t days);
 
+/* Host-side export of what mapdn_set_profiles derived from the tables (parity tests): stdv [n_sgen + 2 n_load] = the per-column noise
+ * scale `values.std(axis=0) / 100.0` in table order pv | load_p | load_q (voltage_control_env.py:70-72, numpy's own summation order:
+ * csrc/colstats.hpp), smax [n_sgen] = 1.2 * max_t pv (:518-520).  HOST pointers; either may be NULL. */
+int mapdn_get_profile_stats(const mapdn_handle* h, double* stdv, double* smax);
+
 /* reset() / manual_reset() — voltage_control_env.py:96-176.  start_rows: device int64 [B] giving
  * `start` of :445 per env, or NULL to sample (hour, day, interval) per env from the keyed RNG.
  * Retries unsolvable initial states up to `max_tries` times (reference: unbounded loop, :108). */

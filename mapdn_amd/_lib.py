@@ -33,7 +33,7 @@ EXPORTS = (
     "mapdn_nr_time_ms", "mapdn_get_auto_reset_mask", "mapdn_dense_solve", "mapdn_step_obs", "mapdn_get_sparse_program", "mapdn_policy_forward",
     "mapdn_policy_forward_fits", "mapdn_layernorm64_forward", "mapdn_layernorm64_backward", "mapdn_layernorm64_backward_blocks",
     "mapdn_get_nr_geometry", "mapdn_debug_stream", "mapdn_build_info", "mapdn_layernorm64_bc_forward", "mapdn_layernorm64_bc_backward", "mapdn_relu_dot64_forward", "mapdn_relu_dot64_backward",
-    "mapdn_critic_head_forward", "mapdn_critic_head_scratch_floats", "mapdn_critic_head_backward", "mapdn_critic_head_backward_dot", "mapdn_critic_head_mse",
+    "mapdn_critic_head_forward", "mapdn_critic_head_scratch_floats", "mapdn_critic_head_backward", "mapdn_critic_head_backward_dot", "mapdn_critic_head_mse", "mapdn_get_profile_stats",
 )
 
 _pd = C.POINTER(C.c_double)
@@ -138,6 +138,7 @@ def load():
     lib.mapdn_destroy.restype = None
     lib.mapdn_dims.argtypes = [vp, C.POINTER(CDims)]
     lib.mapdn_set_profiles.argtypes = [vp, _pd, _pd, _pd, C.c_int64, C.c_int32, C.c_int32]
+    lib.mapdn_get_profile_stats.argtypes = [vp, _pd, _pd]
     lib.mapdn_reset.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     lib.mapdn_step.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.mapdn_step_obs.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int32, vp]

@@ -12,7 +12,7 @@ LIB = os.environ.get("MAPDN_BUILD_OUT") or os.path.join(HERE, "libmapdn_hip.so")
 SOURCES = ["plan.cpp", "kernels.hip", "dense.hip", "sparse.hip", "policy.hip", "critic.hip", "capi.hip"]
 # k_nr_tree's instantiations (nr_inst_list.hpp) are compiled as NR_PARTS objects from ONE source, in parallel
 NR_INST_SOURCE, NR_PARTS = "nr_inst.hip", 4
-HEADERS = ["plan.hpp", "kernels.hpp", "philox.hpp", "nrmath.hpp", "nr_common.hpp", "nr_tree.hpp", "nr_inst_list.hpp", NR_INST_SOURCE,
+HEADERS = ["plan.hpp", "colstats.hpp", "kernels.hpp", "philox.hpp", "nrmath.hpp", "nr_common.hpp", "nr_tree.hpp", "nr_inst_list.hpp", NR_INST_SOURCE,
            os.path.join("..", "..", "include", "mapdn.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 HASH_TAG = b"MAPDN_SRC_HASH="

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "colstats.hpp"
 #include "plan.hpp"
 
 using namespace mapdn;
@@ -43,6 +44,7 @@ struct mapdn_handle {
   double *obs_scale = nullptr, *state_scale = nullptr;
   double *t_pl = nullptr, *t_ql = nullptr, *t_pv = nullptr, *t_q = nullptr;
   double* table = nullptr; double* stdv = nullptr; double* smax = nullptr;
+  std::vector<double> stdv_host, smax_host;     // what set_profiles computed (mapdn_get_profile_stats)
   long long* stats_dev = nullptr;
   // NR kernel timing
   bool timing = false;
@@ -635,19 +637,15 @@ int mapdn_set_profiles(mapdn_handle* h, const double* pv, const double* load_p, 
     std::memcpy(r + ns, load_p + (size_t)t * nl, nl * sizeof(double));
     std::memcpy(r + ns + nl, load_q + (size_t)t * nl, nl * sizeof(double));
   }
-  for (int c = 0; c < ncol; ++c) {   // population std over the whole table / 100 (:70-72)
-    double mean = 0.0;
-    for (int64_t t = 0; t < T; ++t) mean += tab[(size_t)t * ncol + c];
-    mean /= (double)T;
-    double var = 0.0;
-    for (int64_t t = 0; t < T; ++t) { const double x = tab[(size_t)t * ncol + c] - mean; var += x * x; }
-    stdv[c] = std::sqrt(var / (double)T) / 100.0;
+  // population std over the whole table / 100 (:70-72) in numpy's own summation order (colstats.hpp: pairwise along every column, as
+  // `DataFrame.values.std(axis=0)` does on its F-ordered block), read row-major; s_max = 1.2 * max_t pv (:518-520)
+  column_std(tab.data(), T, ncol, 100.0, stdv);
+  for (int j = 0; j < ns; ++j) smax[(size_t)j] = tab[(size_t)j];
+  for (int64_t t = 1; t < T; ++t) {
+    const double* r = &tab[(size_t)t * ncol];
+    for (int j = 0; j < ns; ++j) smax[(size_t)j] = std::max(smax[(size_t)j], r[j]);
   }
-  for (int j = 0; j < ns; ++j) {     // s_max = 1.2 * max_t pv (:518-520)
-    double m = tab[j];
-    for (int64_t t = 1; t < T; ++t) m = std::max(m, tab[(size_t)t * ncol + j]);
-    smax[j] = 1.2 * m;
-  }
+  for (int j = 0; j < ns; ++j) smax[(size_t)j] *= 1.2;
   if (h->have_profiles) {   // replace: free the old table
     for (double* p : {h->table, h->stdv, h->smax}) {
       auto it = std::find(h->allocs.begin(), h->allocs.end(), (void*)p);
@@ -659,6 +657,7 @@ int mapdn_set_profiles(mapdn_handle* h, const double* pv, const double* load_p, 
   rc = dupload(h, &tmp, stdv); if (rc) return rc; h->stdv = (double*)tmp;
   rc = dupload(h, &tmp, smax); if (rc) return rc; h->smax = (double*)tmp;
   d.table = h->table; d.stdv = h->stdv; d.smax = h->smax; d.T = T;
+  h->stdv_host = stdv; h->smax_host = smax;
   h->have_profiles = true;
   return MAPDN_OK;
 } MAPDN_CATCH(h)
@@ -886,6 +885,14 @@ int mapdn_solve_only(mapdn_handle* h, const double* p_load, const double* q_load
   if (iterations) launch_copy_i32(d.iters, iterations, d.B, st);
   if (converged) launch_copy_u8(d.conv, converged, d.B, st);
   HIPCHK(h, hipGetLastError());
+  return MAPDN_OK;
+} MAPDN_CATCH(h)
+
+int mapdn_get_profile_stats(const mapdn_handle* h, double* stdv, double* smax) try {
+  if (!h) return MAPDN_E_INVALID;
+  if (!h->have_profiles) { const_cast<mapdn_handle*>(h)->err = "get_profile_stats before set_profiles"; return MAPDN_E_STATE; }
+  if (stdv) std::memcpy(stdv, h->stdv_host.data(), h->stdv_host.size() * sizeof(double));
+  if (smax) std::memcpy(smax, h->smax_host.data(), h->smax_host.size() * sizeof(double));
   return MAPDN_OK;
 } MAPDN_CATCH(h)
 

@@ -364,6 +364,12 @@ class VoltageControlBatch:
             _lib.check(self._lib.mapdn_stats(self._h, _lib.C.byref(rf), _lib.C.byref(mi), _lib.C.byref(mx), self._stream()), self._h)
         return dict(reset_failures=rf.value, mean_nr_iters=mi.value, max_nr_iters=mx.value)
 
+    def profile_stats(self):
+        """(stdv [n_sgen + 2 n_load], s_max [n_sgen]) as the library derived them from the profile tables (:70-72, :518-520)"""
+        sd, sm = np.empty(self.n_sgen + 2 * self.n_load), np.empty(self.n_sgen)
+        _lib.check(self._lib.mapdn_get_profile_stats(self._h, _lib._p(sd, _lib._pd), _lib._p(sm, _lib._pd)), self._h)
+        return sd, sm
+
     def nr_timing(self, enable=True):
         _lib.check(self._lib.mapdn_nr_timing(self._h, int(enable)), self._h)
 

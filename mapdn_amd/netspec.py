@@ -177,9 +177,12 @@ class Profiles:
     def intervals_per_day(self) -> int:
         return 24 * self.intervals_per_hour
 
-    # env.py:70-72 (population std over the whole table, /100)
+    # env.py:70-72 (population std over the whole table, /100).  The reference takes it of `DataFrame.values`, an F-ordered block: numpy
+    # then sums every column pairwise along its contiguous axis.  On a C-ordered table the same call adds row after row, which at the
+    # real data's length (526 080 rows) lands 2e-12 away — so the order is reproduced here (and in csrc/colstats.hpp).
     def stds(self):
-        return (self.pv.std(axis=0) / 100.0, self.load_p.std(axis=0) / 100.0, self.load_q.std(axis=0) / 100.0)
+        f = np.asfortranarray
+        return (f(self.pv).std(axis=0) / 100.0, f(self.load_p).std(axis=0) / 100.0, f(self.load_q).std(axis=0) / 100.0)
 
     # env.py:515-520
     def s_max(self, factor: float = 1.2) -> np.ndarray:

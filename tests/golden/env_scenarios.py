@@ -28,6 +28,12 @@ SCENARIOS = {
     "c322_bowl": ("case322", dict(voltage_barrier_type="bowl"), (3, 12, 2), 6, True, False),
     "c322_hist3": ("case322", dict(voltage_barrier_type="l1", history=3), (5, 13, 17), 5, False, False),
 }
+# round 6 (VERDICT r5 missing #5): the REAL data's scale — 3 years of 3-minute rows = 1096 days x 480 = 526 080 rows
+# (voltage_control_env.py:407-438 reads tables of that size; reset samples day in [0, days - 1), :384-398) — a start in the LAST valid
+# window (day 1093 of 1094, 23:57) and a seeded random reset over the whole range.  `_days` selects the long table (scenario_data).
+LONG_DAYS = 1096
+SCENARIOS["c33_long"] = ("case33", dict(voltage_barrier_type="bowl", _days=LONG_DAYS), (1093, 23, 19), 6, False, False)
+SCENARIOS["c33_long_noisy"] = ("case33", dict(voltage_barrier_type="bowl", reset_action=True, seed=5, _days=LONG_DAYS), (1090, 7, 3), 5, False, True)
 DIGITS = 12     # profile tables are quantised to this many significant digits so that every CSV parser reads them exactly
 
 
@@ -48,3 +54,32 @@ def actions_for(name, n_sgen, n_steps, unsolvable_last, scale, bias=0.0):
     if unsolvable_last:
         a[-1] = 60.0          # not clipped by the env (:553): q far beyond any solvable injection
     return a
+
+
+def long_profiles(case, days=LONG_DAYS):
+    """the synthetic generator at the real data's length, every entry a multiple of 1e-6 (k / 1e6 prints exactly with %.12g and parses
+    back to the same double — quantized_profiles' per-value Python formatting would take minutes on 37 M entries)"""
+    from mapdn_amd.netspec import Profiles, make_case
+    _, prof = make_case(case, days=days)
+
+    def q(a):
+        return np.round(a * 1e6) / 1e6
+    return Profiles(pv=q(prof.pv), load_p=q(prof.load_p), load_q=q(prof.load_q), time_delta_min=prof.time_delta_min, days=prof.days)
+
+
+def scenario_data(name, scaled=True):
+    """(net, profiles, args, start, n_steps, noisy) of a scenario; profiles quantised as the generator wrote them to CSV, and — when
+    `scaled` — multiplied by pv_scale / demand_scale as the reference does on loading (:415,426,437)"""
+    from mapdn_amd.netspec import Profiles, make_case
+    case, over, start, n_steps, unsolv, noisy = SCENARIOS[name]
+    args = dict(BASE_ARGS)
+    args.update({k: v for k, v in over.items() if not k.startswith("_")})
+    net, prof = make_case(case)
+    ps, ds = (args["pv_scale"], args["demand_scale"]) if scaled else (1.0, 1.0)
+    if "_days" in over:
+        lp = long_profiles(case, over["_days"])
+        prof = lp if (ps, ds) == (1.0, 1.0) else Profiles(pv=lp.pv * ps, load_p=lp.load_p * ds, load_q=lp.load_q * ds,
+                                                         time_delta_min=lp.time_delta_min, days=lp.days)
+    else:
+        prof = quantized_profiles(prof, ps, ds)
+    return net, prof, args, start, n_steps, noisy

@@ -28,7 +28,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle", "pp_stub"), REF]
 
 from mapdn_amd.data import save_netspec, save_profiles_csv          # noqa: E402
 from mapdn_amd.netspec import make_case                             # noqa: E402
-from tests.golden.env_scenarios import BASE_ARGS, DIGITS, SCENARIOS, actions_for, quantized_profiles  # noqa: E402
+from tests.golden.env_scenarios import DIGITS, SCENARIOS, actions_for, scenario_data  # noqa: E402
 
 warnings.simplefilter("ignore")      # pandas ChainedAssignment FutureWarnings of the reference's :239-244
 from environments.var_voltage_control.voltage_control_env import VoltageControl   # noqa: E402  (the reference class)
@@ -48,12 +48,10 @@ def snapshot(env, with_obs=True):
 
 def run_scenario(name):
     case, over, (day, hour, interval), n_steps, unsolv, noisy = SCENARIOS[name]
-    args = dict(BASE_ARGS)
-    args.update(over)
-    net, prof = make_case(case)
+    net, prof_q, args, _, _, _ = scenario_data(name, scaled=False)               # unscaled: the reference scales (:415)
     d = tempfile.mkdtemp(prefix="mapdn_ref_")
     save_netspec(net, os.path.join(d, "netspec.npz"))
-    save_profiles_csv(quantized_profiles(prof), d, float_format=f"%.{DIGITS}g")   # unscaled: the reference scales (:415)
+    save_profiles_csv(prof_q, d, float_format=f"%.{DIGITS}g")
     args["data_path"] = d
     env = VoltageControl(args)                       # the reference constructor: loaders, stds, s_max, first reset()
     out = {}
@@ -98,12 +96,15 @@ def run_scenario(name):
 
 
 def main():
-    for name in SCENARIOS:
+    only = sys.argv[1:]
+    for name in (only or SCENARIOS):
         out = run_scenario(name)
         path = os.path.join(HERE, f"env_ref_{name}.npz")
         np.savez_compressed(path, **out)
         print(f"{name}: {len(out)} arrays -> {os.path.basename(path)} ({os.path.getsize(path)} B); "
               f"rewards {np.round(out['step_reward'], 4).tolist()} term {out['step_terminated'].tolist()}")
+    if only:
+        return
     # ---- pure functions of the reference ---------------------------------------------------------
     grid = np.concatenate([np.linspace(0.5, 1.5, 201), np.array([0.95, 1.05, 1.0, 0.9499999, 1.0500001, 2.0, 2.5, 3.0, -0.5, 1.0 - 1e-9])])
     fun = {f"barrier_{k}": np.asarray(f(grid), dtype=np.float64) for k, f in Voltage_Barrier.items()}
