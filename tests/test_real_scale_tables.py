@@ -60,7 +60,7 @@ def test_three_year_tables_through_the_c_abi(case):
     max_start = 19 + 23 * 20 + (n_days - 1) * 480
     assert n_days == DAYS - 2 and starts.min() >= 0 and starts.max() <= max_start
     assert starts.max() > 0.99 * max_start and starts.min() < 0.01 * max_start and len(np.unique(starts // 480)) > 900     # of 1094 days
-    assert starts.max() * (net.n_sgen + 2 * net.n_load) * 8 > (2 ** 31 if case != "case33" else 2 ** 28)     # byte offsets past 32 bits
+    assert starts.max() * (net.n_sgen + 2 * net.n_load) * 8 > {"case33": 2 ** 28, "case141": 2 ** 29, "case322": 2 ** 31}[case]   # 322-bus: byte offsets past 32 bits
     late = int(np.argmax(starts))
     for e in (0, 1, B - 1, late):
         o = VoltageControlOracle(net, prof, a, env_id=e, do_reset=False)
