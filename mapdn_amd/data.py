@@ -343,7 +343,8 @@ _BUILTINS_OK = {"dict", "list", "tuple", "set", "frozenset", "slice", "range", "
 _MISC_OK = {("collections", "OrderedDict"), ("collections", "defaultdict"), ("copyreg", "_reconstructor"), ("copy_reg", "_reconstructor"),
             ("datetime", "datetime"), ("datetime", "date"), ("datetime", "timedelta"), ("datetime", "timezone"),
             ("_codecs", "encode"), ("__builtin__", "object"), ("__builtin__", "dict"), ("__builtin__", "list"), ("__builtin__", "set"),
-            ("__builtin__", "tuple"), ("__builtin__", "slice"), ("__builtin__", "long"), ("__builtin__", "unicode")}
+            ("__builtin__", "tuple"), ("__builtin__", "slice"), ("__builtin__", "long"), ("__builtin__", "unicode"),
+            ("__builtin__", "bytes")}          # Python 3 writes b"" as bytes() under protocol <= 2 (the raw data of an EMPTY table's arrays)
 # pandas: an explicit (module, name) list of the DATA classes and the reconstructor functions a pickled DataFrame / Series /
 # Index references (enumerated with pickletools over frames of every column kind, protocols 2-5, plus the legacy paths of
 # pandas.compat.pickle_compat).  NOT a module-prefix rule: pandas modules re-export functions (import helpers, file

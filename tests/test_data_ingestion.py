@@ -372,6 +372,48 @@ def test_model_p_reads_without_pandapower_object_form(tmp_path):
     assert a.ext_grid_bus == net.ext_grid_bus and a.sn_mva == net.sn_mva
 
 
+@pytest.mark.parametrize("form", ["to_pickle_proto2", "object_proto3", "object_proto2"])
+def test_model_p_as_the_pinned_stack_writes_it(form, tmp_path):
+    """the real model.p (voltage_control_env.py:403-404) was written by Python 3.7 / numpy 1.19.5 / pandas
+    1.1.3 / pandapower 2.7.0 (environment.yml:66,125-134), the pickles of the other tests by today's pandas.  tests/pinned_stack_pickle.py
+    ASSEMBLES the bytes that stack would emit — opcode by opcode, old module paths (pandas.core.indexes.numeric.Int64Index,
+    numpy.core.multiarray._reconstruct), old state layouts (BlockManager's "0.14.1" dict, NDFrame's _mgr / _typ / attrs), bytes as
+    _codecs.encode under protocol 2 — for both on-disk forms, with an EMPTY table and a RangeIndex among them.  The restricted
+    unpickler must read them into the same NetSpec, every global on its allow-list, without importing a module that no longer exists."""
+    from mapdn_amd import data
+    from mapdn_amd.data import read_pandapower_pickle
+    from tests import pinned_stack_pickle as psp
+    pnet = substation_net()
+    items = dict(pnet)
+    items["ward"] = pd.DataFrame({"bus": np.zeros(0, dtype=np.int64), "ps_mw": np.zeros(0), "in_service": np.zeros(0, dtype=bool), "name": np.zeros(0, dtype=object)})
+    items.update(version="2.7.0", std_types={"line": {"NAYY 4x50 SE": {"r_ohm_per_km": 0.642, "type": "cs"}}, "trafo": {}, "trafo3w": {}},
+                 _options={"calculate_voltage_angles": "auto"}, converged=False, user_pf_options={})
+    if form == "to_pickle_proto2":
+        blob, want = psp.to_pickle_form(items), psp.GLOBALS_A
+    elif form == "object_proto3":
+        blob, want = psp.object_form(items, range_index_tables=("ext_grid",), proto=3), psp.GLOBALS_B
+    else:
+        blob = psp.object_form(items, range_index_tables=("ext_grid",), proto=2)
+        want = (psp.GLOBALS_B - {("builtins", "slice")}) | psp.GLOBALS_B2
+    assert blob[:2] == bytes([0x80, 3 if form == "object_proto3" else 2])
+    used = psp.globals_in(blob)
+    assert used == want, (used ^ want)
+    allowed = data._NUMPY_OK | data._MISC_OK | data._PANDAS_OK | data._PANDAS_LEGACY | {("builtins", b) for b in data._BUILTINS_OK}
+    assert all(g in allowed or g[0].startswith("pandapower") for g in used), [g for g in used if g not in allowed]
+    p = str(tmp_path / "model.p")
+    open(p, "wb").write(blob)
+    got = read_pandapower_pickle(p)
+    assert "pandapower" not in sys.modules and "pandas.core.indexes.numeric" not in sys.modules
+    assert got.sn_mva == 10.0 and got.version == "2.7.0" and len(got.ward) == 0 and list(got.ward.columns) == ["bus", "ps_mw", "in_service", "name"]
+    for name in ("bus", "line", "load", "sgen", "ext_grid", "trafo", "shunt", "switch"):
+        a, b = got[name], pnet[name]
+        assert list(a.columns) == list(b.columns) and list(a.index) == list(b.index), name
+        for c in b.columns:
+            assert a[c].dtype == b[c].dtype, (name, c, a[c].dtype, b[c].dtype)
+            assert all((x == y) or (x != x and y != y) or (x is None and y is None) for x, y in zip(a[c].tolist(), b[c].tolist())), (name, c)
+    _same_netspec(from_pandapower(got), from_pandapower(pnet))
+
+
 def test_model_p_with_code_in_it_is_refused(tmp_path):
     """a pickle is a program: anything that is not a numpy / pandas / builtin data class is refused, pandapower classes are
     replaced by inert stand-ins (their code never runs)"""
