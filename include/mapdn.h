@@ -172,7 +172,7 @@ typedef struct mapdn_env_config {
   int32_t nr_init;                  /* runpp(init=...): 0 "auto" / "flat" — every solve starts at the slack set-point, what the
                                        reference does (exact pandapower iterates).  1 ("results": start a step() solve from the
                                        env's last accepted voltages, fall back to the flat start after 3 iterations) is RESERVED
-                                       and refused (MAPDN_E_INVALID): the study that was to gate it (tools/warm_start_study.py,
+                                       and refused (MAPDN_E_INVALID): the study that was to gate it (tools/history/warm_start_study.py,
                                        profiles/r04_warm_start_study_*.json: 3.6 M solves on the oracle, 15 % of them stressed
                                        to and beyond voltage collapse) found it SAFE — never "converged" where the flat start
                                        reports LoadflowNotConverged, never another root, |dV| < 1e-9 — but USELESS for this
