@@ -98,6 +98,13 @@ class MapdnError(RuntimeError):
 _lib = None
 
 
+def _safe_source_hash(b):
+    try:
+        return b.source_hash()
+    except OSError:
+        return "sources unreadable"
+
+
 def load():
     """Load the shared library (once).  Raises if it was not built — never falls back to CPU."""
     global _lib
@@ -113,13 +120,20 @@ def load():
         # .so shipped with edited sources) — is compiled from the same HIP sources in-tree (hipcc cross-compiles gfx950), once,
         # race-free when several ranks start together; raise if that is impossible
         from . import build as _build
-        if _build.stale():
+        try:
+            is_stale = _build.stale()
+        except OSError:                       # a binary-only install: no csrc/ beside the library to hash — the library is what there is
+            is_stale = not os.path.exists(LIB_PATH)
+            if not is_stale:
+                import warnings
+                warnings.warn(f"mapdn_amd/csrc is not readable: {LIB_PATH} is loaded without the source-hash check", RuntimeWarning, stacklevel=2)
+        if is_stale:
             try:
                 _build.build_locked()
             except Exception as exc:
                 raise ImportError(
                     f"{LIB_PATH} is missing or was built from other sources than mapdn_amd/csrc (hash {_build.library_hash()} vs "
-                    f"{_build.source_hash()}) and could not be rebuilt ({exc}); build it with `python -m mapdn_amd.build` "
+                    f"{_safe_source_hash(_build)}) and could not be rebuilt ({exc}); build it with `python -m mapdn_amd.build` "
                     "(hipcc --offload-arch=gfx950); there is no CPU fallback") from exc
     lib = C.CDLL(os.environ.get("MAPDN_LIB_PATH", LIB_PATH))      # override: A/B experiments with debug builds only
     if "MAPDN_LIB_PATH" in os.environ:                              # an OLDER build for a same-box A/B may lack the newest exports

@@ -453,14 +453,18 @@ def read_pandapower_pickle(path: str) -> InertNet:
     return net
 
 
-def load_scenario(data_path: str, pv_scale: float = 1.0, demand_scale: float = 1.0):
+def load_scenario(data_path: str, pv_scale: float = 1.0, demand_scale: float = 1.0, hv_init: str = None):
     """(NetSpec, Profiles) of a scenario directory: netspec.npz or the reference's model.p (read as data by the restricted
-    unpickler above — pandapower is not needed) + the three CSVs."""
+    unpickler above — pandapower is not needed) + the three CSVs.  hv_init ("refuse" | "flat", see from_pandapower; default: the
+    MAPDN_HV_INIT environment variable, else "refuse") decides what happens to a model.p with a line at a bus above 70 kV — runpp
+    would start such a net from a DC power flow's angles, which the HIP solver does not do."""
     npz = os.path.join(data_path, "netspec.npz")
+    if hv_init is None:
+        hv_init = os.environ.get("MAPDN_HV_INIT", "refuse")
     if os.path.exists(npz):
         net = load_netspec(npz)
     elif os.path.exists(os.path.join(data_path, "model.p")):
-        net = from_pandapower(read_pandapower_pickle(os.path.join(data_path, "model.p")))
+        net = from_pandapower(read_pandapower_pickle(os.path.join(data_path, "model.p")), hv_init=hv_init)
     else:
         raise FileNotFoundError(f"no netspec.npz / model.p in {data_path}")
     return net, load_profiles_csv(data_path, pv_scale, demand_scale)

@@ -394,7 +394,7 @@ def _resolve_data(args):
     ps, ds = float(args.get("pv_scale", 1.0)), float(args.get("demand_scale", 1.0))       # :415,426,437
     if os.path.isdir(dp) and (os.path.exists(os.path.join(dp, "netspec.npz")) or os.path.exists(os.path.join(dp, "model.p"))):
         from .data import load_scenario
-        return load_scenario(dp, ps, ds)                                                  # real scenario directory
+        return load_scenario(dp, ps, ds, hv_init=args.get("hv_init"))                     # real scenario directory (hv_init: see load_scenario)
     name = os.path.basename(os.path.normpath(dp))
     if name not in _SCENARIOS:
         raise FileNotFoundError(f"unknown scenario {name!r}: pass net=/profiles=, a directory with netspec.npz + the three "

@@ -137,7 +137,7 @@ class _TallLinear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             rows, blk = x.shape[0], _TallLinear.BLOCK_ROWS
             full = rows // blk * blk
-            dy2, x2 = dy.reshape(rows, -1), x.reshape(rows, -1)
+            dy2, x2 = dy.reshape(rows, -1).contiguous(), x.reshape(rows, -1).contiguous()      # (a permuted upstream gradient is not viewable)
             dw = torch.bmm(dy2[:full].view(-1, blk, dy2.shape[1]).transpose(1, 2), x2[:full].view(-1, blk, x2.shape[1])).sum(0)
             if full < rows:
                 dw = dw + dy2[full:].t() @ x2[full:]
@@ -169,7 +169,8 @@ def _gru_fused_ok(device) -> bool:
         ok = False
         try:
             g = torch.Generator(device="cpu").manual_seed(1)
-            cell = nn.GRUCell(8, 8).to(device)
+            with torch.random.fork_rng(devices=[]):          # nn.GRUCell's initialisation draws from the GLOBAL generator: leave the caller's stream alone
+                cell = nn.GRUCell(8, 8).to(device)
             x = torch.randn(32, 8, generator=g).to(device).requires_grad_(True)
             h = torch.randn(32, 8, generator=g).to(device).requires_grad_(True)
             ref = cell(x, h)

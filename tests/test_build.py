@@ -65,3 +65,35 @@ def test_eight_ranks_build_once(tmp_path):
     calls = log.read_text().split()
     assert calls.count("link") == 1 and calls.count("cc") == 11, calls          # 4 NR parts + 7 sources (round 6: critic.hip)
     assert not os.path.exists(str(lib) + ".lock")
+
+
+def test_binary_only_install_loads_the_library_it_has(monkeypatch):
+    """a prebuilt library without mapdn_amd/csrc beside it (nothing to hash) must load — with a warning — instead of
+    raising a raw FileNotFoundError out of the staleness check."""
+    import warnings
+    from mapdn_amd import _lib, build
+
+    def gone():
+        raise FileNotFoundError("csrc/plan.cpp")
+    monkeypatch.setattr(build, "source_hash", gone)
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.delenv("MAPDN_LIB_PATH", raising=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        lib = _lib.load()
+    assert hasattr(lib, "mapdn_create") and any("source-hash check" in str(x.message) for x in w)
+
+
+def test_hv_init_reaches_the_converter_through_the_scenario_loader(tmp_path, monkeypatch):
+    """load_scenario / the env constructor pass hv_init (or MAPDN_HV_INIT) on to from_pandapower"""
+    from mapdn_amd import data
+    seen = []
+    monkeypatch.setattr(data, "read_pandapower_pickle", lambda p: "net")
+    monkeypatch.setattr(data, "from_pandapower", lambda net, hv_init="refuse": seen.append(hv_init) or "spec")
+    monkeypatch.setattr(data, "load_profiles_csv", lambda *a: "prof")
+    (tmp_path / "model.p").write_bytes(b"")
+    assert data.load_scenario(str(tmp_path)) == ("spec", "prof")
+    data.load_scenario(str(tmp_path), hv_init="flat")
+    monkeypatch.setenv("MAPDN_HV_INIT", "flat")
+    data.load_scenario(str(tmp_path))
+    assert seen == ["refuse", "flat", "flat"]
