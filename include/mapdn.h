@@ -397,6 +397,22 @@ int mapdn_critic_head_backward_dot(const float* dv, const float* x, const float*
                                    float eps, const float* w2, const float* b2, const float* w3, const float* b3, const float* dot_w,
                                    float* dact, int64_t rows, void* stream);
 
+/* The glue of one batched rollout step (models/model.py:197-262) as three launches instead of ~45 one-line PyTorch kernels
+ * (csrc/rollout.hip).  Device pointers, contiguous.
+ * mapdn_explore_actions: action = tanh(mean + std * eps) (utilities/util.py:57-66; no tanh when tanh_bound == 0), action_pol =
+ *   (avail != 0) * action (maddpg.py:92-93; avail / action_pol may be NULL), actual = translate_action(action) = 0.5 (clamp(action, -1,
+ *   1) + 1) (high - low) + low with low / high = bias -/+ scale (utilities/util.py:123-132); f32, the PyTorch chain's operations in
+ *   its order, bit-identical.
+ * mapdn_rollout_stats: sums[0..10] += sum over live envs of info[e][k], sums[11] += of reward[e], sums[12] += live envs; then
+ *   alive_out[e] = alive[e] & !done[e] (models/model.py:243-248, 225; alive_out may be alive); info [n_envs][11], reward [n_envs] f64; alive / done one byte per env.
+ * mapdn_copy_segments: dst[i][0 .. nbytes[i]) = src[i][...] for up to 48 segments in one launch (the fields of a transition into
+ *   their replay-ring positions, utilities/replay_buffer.py:25-29); HOST arrays of device pointers; 16-byte aligned, nbytes % 16 == 0. */
+int mapdn_explore_actions(const float* mean, const float* eps, const float* avail, float stdv, int32_t tanh_bound, double action_scale,
+                          double action_bias, float* action, float* action_pol, float* actual, int64_t n, void* stream);
+int mapdn_rollout_stats(const double* info, const double* reward, const uint8_t* alive, const uint8_t* done, uint8_t* alive_out, double* sums,
+                        int32_t n_envs, void* stream);
+int mapdn_copy_segments(const void* const* src, void* const* dst, const int64_t* nbytes, int32_t n_segments, void* stream);
+
 /* Calibration aid for the HBM counters (tools/calibrate_traffic.py): copies rows x Bp x 16 bytes from src to dst (device pointers) with
  * the solver's own global access pattern — raw-buffer 16-byte loads / stores of env-minor pair rows, 256 contiguous bytes per
  * 16-lane worker (pattern 0) — or with whole waves on one row (pattern 1), so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be read

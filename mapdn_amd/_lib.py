@@ -34,6 +34,7 @@ EXPORTS = (
     "mapdn_policy_forward_fits", "mapdn_layernorm64_forward", "mapdn_layernorm64_backward", "mapdn_layernorm64_backward_blocks",
     "mapdn_get_nr_geometry", "mapdn_debug_stream", "mapdn_build_info", "mapdn_layernorm64_bc_forward", "mapdn_layernorm64_bc_backward", "mapdn_relu_dot64_forward", "mapdn_relu_dot64_backward",
     "mapdn_critic_head_forward", "mapdn_critic_head_scratch_floats", "mapdn_critic_head_backward", "mapdn_critic_head_backward_dot", "mapdn_critic_head_mse", "mapdn_get_profile_stats",
+    "mapdn_explore_actions", "mapdn_rollout_stats", "mapdn_copy_segments",
 )
 
 _pd = C.POINTER(C.c_double)
@@ -184,6 +185,9 @@ def load():
     lib.mapdn_critic_head_scratch_floats.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.mapdn_critic_head_scratch_floats.restype = C.c_int64
     lib.mapdn_critic_head_backward.argtypes = [vp, vp, vp, C.c_int32, vp, vp, C.c_float] + [vp] * 7 + [C.c_int64, C.c_int32, vp]
+    lib.mapdn_explore_actions.argtypes = [vp, vp, vp, C.c_float, C.c_int32, C.c_double, C.c_double, vp, vp, vp, C.c_int64, vp]
+    lib.mapdn_rollout_stats.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32, vp]
+    lib.mapdn_copy_segments.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64), C.c_int32, vp]
     lib.mapdn_critic_head_mse.argtypes = [vp] * 5 + [C.c_int32, vp, vp, C.c_float] + [vp] * 7 + [C.c_int64, vp]
     lib.mapdn_critic_head_backward_dot.argtypes = [vp, vp, vp, C.c_int32, vp, vp, C.c_float] + [vp] * 6 + [C.c_int64, vp]
     lib.mapdn_dense_solve.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, vp]

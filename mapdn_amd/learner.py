@@ -1033,15 +1033,37 @@ class PGTrainer:
         prefix = "mean_train_" if train else "mean_test_"
         avail = env.get_avail_actions().to(dv)
 
+        fused_explore = (train and self.device.type == "cuda" and a.action_dim == 1 and a.continuous and not a.gaussian_policy
+                         and os.environ.get("MAPDN_FUSED_ROLLOUT", "1") != "0")
+        if fused_explore:
+            from . import _lib
+            lib = _lib.load()
+            # std = exp(log_std) with log_std = log(fixed_policy_std) (model.py:119-120, util.py:56), rounded as the f32 tensors are
+            std = float(torch.tensor(math.log(a.fixed_policy_std), dtype=torch.float32).exp()) if a.shared_params else 1.0
+
         def policy(obs, last_hid):
+            if fused_explore:
+                # get_actions(status="train", exploration=True) without the log-probability nobody reads in this loop (maddpg.py:81-101,
+                # util.py:52-76) and with translate_action (util.py:123-132) in the same launch: mapdn_explore_actions draws nothing itself —
+                # eps is torch.randn_like(means), the same draw from the same generator as Normal(mean, std).rsample()
+                means, _, hid = net.policy(obs, last_hid)
+                means = means.contiguous()
+                eps = torch.randn_like(means)
+                action, action_pol, actual = torch.empty_like(means), torch.empty_like(means), torch.empty_like(means)
+                av = avail.expand_as(means).contiguous() if avail.shape != means.shape else avail.contiguous()
+                with torch.cuda.device(dv):
+                    _lib.check(lib.mapdn_explore_actions(means.data_ptr(), eps.data_ptr(), av.data_ptr(), std, int(bool(a.action_enforcebound)),
+                                                         float(a.action_scale), float(a.action_bias), action.data_ptr(), action_pol.data_ptr(),
+                                                         actual.data_ptr(), means.numel(), torch.cuda.current_stream(dv).cuda_stream))
+                return action, hid, dict(action_pol=action_pol, last_hid=last_hid, hid=hid, actual=actual)
             if train:
                 action, action_pol, _, _, hid = net.get_actions(obs, "train", True, avail, False, last_hid)
             else:
                 action, action_pol, _, _, hid = net.get_actions(obs, "test", False, avail, False, last_hid)
-            return action, hid, (action_pol, last_hid, hid)
+            return action, hid, dict(action_pol=action_pol, last_hid=last_hid, hid=hid)
 
         def on_step(t, obs, action, reward, done, info, next_obs, alive, aux):
-            action_pol, last_hid, hid = aux
+            action_pol, last_hid, hid = aux["action_pol"], aux["last_hid"], aux["hid"]
             trans = dict(state=obs, action=action_pol, reward=reward.float().unsqueeze(-1).expand(B, net.n_).contiguous(),
                          next_state=next_obs, done=done.view(B, 1).float(),
                          last_step=(done | (t == a.max_steps - 1)).view(B, 1).float(), action_avail=avail,

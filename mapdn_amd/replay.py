@@ -75,23 +75,55 @@ class TransReplayBuffer:
         n = B - skip
         head = (self._tail + self._len) % self.size
         first = min(n, self.size - head)
+        pieces = []                              # (destination slice, source slice) of every field: ring, wrap-around, mirror
         for k, v in trans.items():
             if v.shape[0] != B:
                 raise ValueError(f"field {k}: leading dimension {v.shape[0]} != {B}")
             dst = self.store[k]
-            dst[head:head + first].copy_(v[skip:skip + first])
+            pieces.append((dst[head:head + first], v[skip:skip + first]))
             if n > first:
-                dst[0:n - first].copy_(v[skip + first:B])
+                pieces.append((dst[0:n - first], v[skip + first:B]))
             if self.window:                       # ring positions below `window` live a second time behind the ring
                 if head < self.window:
                     m = min(first, self.window - head)
-                    dst[self.size + head:self.size + head + m].copy_(v[skip:skip + m])
+                    pieces.append((dst[self.size + head:self.size + head + m], v[skip:skip + m]))
                 if n > first:
                     m = min(n - first, self.window)
-                    dst[self.size:self.size + m].copy_(v[skip + first:skip + first + m])
+                    pieces.append((dst[self.size:self.size + m], v[skip + first:skip + first + m]))
+        if not self._copy_in_one_launch(pieces):
+            for d, s_ in pieces:
+                d.copy_(s_)
         overflow = max(0, self._len + n - self.size)
         self._tail = (self._tail + overflow) % self.size
         self._len = min(self.size, self._len + n)
+
+    def _copy_in_one_launch(self, pieces) -> bool:
+        """all pieces of one insertion as ONE HIP launch (libmapdn_hip.so: mapdn_copy_segments) instead of ~20 copy launches — when every
+        piece is a contiguous same-dtype device-to-device copy of 16-byte granularity (the batched env's fields are); else False."""
+        import os
+        if not pieces or len(pieces) > 48 or os.environ.get("MAPDN_FUSED_ROLLOUT", "1") == "0":
+            return False
+        dev = pieces[0][0].device
+        if dev.type != "cuda":
+            return False
+        srcs = []
+        for d, s_ in pieces:
+            if s_.device != dev or s_.dtype != d.dtype or s_.shape != d.shape or not d.is_contiguous():
+                return False
+            s_ = s_ if s_.is_contiguous() else s_.contiguous()
+            nb = d.numel() * d.element_size()
+            if nb % 16 or d.data_ptr() % 16 or s_.data_ptr() % 16:
+                return False
+            srcs.append(s_)
+        from . import _lib
+        C = _lib.C
+        n = len(pieces)
+        sp = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+        dp = (C.c_void_p * n)(*[d.data_ptr() for d, _ in pieces])
+        nb = (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in pieces])
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mapdn_copy_segments(sp, dp, nb, n, torch.cuda.current_stream(dev).cuda_stream))
+        return True
 
     def get_single(self, index: int) -> Batch:
         if index < 0:

@@ -8,6 +8,7 @@ statistics all stay on the device — the reference crosses host<->GPU twice per
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -75,12 +76,22 @@ class BatchedRollout:
         rew_sum = torch.zeros((), dtype=torch.float64, device=env.device)
         alive_steps = torch.zeros((), dtype=torch.float64, device=env.device)
         alive = torch.ones(env.n_envs, dtype=torch.bool, device=env.device)
+        # the per-step bookkeeping as one launch (csrc/rollout.hip: k_rollout_stats) on the GPU: sums = info[11] | reward | live count
+        fused = torch.device(env.device).type == "cuda" and len(INFO_KEYS) == 11 and os.environ.get("MAPDN_FUSED_ROLLOUT", "1") != "0"
+        if fused:
+            from . import _lib
+            lib = _lib.load()
+            sums = torch.zeros(13, dtype=torch.float64, device=env.device)
+            alive_next = torch.ones_like(alive)
         t = 0
         for t in range(T):
             out = self.policy(obs, hidden)
             action, hidden, aux = out if len(out) == 3 else (out[0], out[1], None)
             action = action.reshape(env.n_envs, env.n_agents, 1).float()
-            actual = translate_action(action.squeeze(-1), self.action_scale, self.action_bias)
+            if isinstance(aux, dict) and aux.get("actual") is not None:     # the policy already ran translate_action (fused with its sampling)
+                actual = aux["actual"].reshape(env.n_envs, env.n_agents)
+            else:
+                actual = translate_action(action.squeeze(-1), self.action_scale, self.action_bias)
             reward, done, info = env.step(actual) if add_noise else env.step(actual, add_noise=False)
             nxt = self._own(env.get_obs().float())
             if win is not None:
@@ -88,12 +99,22 @@ class BatchedRollout:
                 win.reward[t].copy_(reward.float().unsqueeze(-1).expand(-1, env.n_agents))
                 win.next_state[t].copy_(nxt); win.done[t].copy_(done)
                 win.last_step[t].copy_(done | (t == T - 1))
-            w = alive.double()                                  # frozen (already terminated) envs do not count
-            info_sum += (info.double() * w.unsqueeze(-1)).sum(0); rew_sum += (reward.double() * w).sum(); alive_steps += w.sum()
+            use = fused and info.dtype == torch.float64 and reward.dtype == torch.float64 and done.dtype == torch.bool \
+                and info.is_contiguous() and reward.is_contiguous() and done.is_contiguous()
+            if use:                                             # frozen (already terminated) envs do not count
+                with torch.cuda.device(env.device):
+                    _lib.check(lib.mapdn_rollout_stats(info.data_ptr(), reward.data_ptr(), alive.data_ptr(), done.data_ptr(), alive_next.data_ptr(),
+                                                       sums.data_ptr(), env.n_envs, torch.cuda.current_stream(env.device).cuda_stream))
+            else:
+                w = alive.double()
+                info_sum += (info.double() * w.unsqueeze(-1)).sum(0); rew_sum += (reward.double() * w).sum(); alive_steps += w.sum()
             if self.on_step is not None:
                 with torch.enable_grad():
                     self.on_step(t, obs, action, reward, done, info, nxt, alive, aux)
-            alive = alive & ~done.bool()
+            if use:
+                alive, alive_next = alive_next, alive           # (the step's own `alive` stayed intact for on_step)
+            else:
+                alive = alive & ~done.bool()
             obs = nxt
             if t % 16 == 15:                                    # the only host sync, once per 16 steps
                 flag = alive.any().to(torch.int32)
@@ -103,6 +124,8 @@ class BatchedRollout:
                     break
         if win is not None:
             win.steps = t + 1
+        if fused:
+            info_sum = info_sum + sums[:11]; rew_sum = rew_sum + sums[11]; alive_steps = alive_steps + sums[12]
         denom = torch.clamp(alive_steps, min=1.0)
         stat = {prefix + k: float(v) for k, v in zip(INFO_KEYS, (info_sum / denom).tolist())}
         stat[prefix + "reward"] = float(rew_sum / denom)
