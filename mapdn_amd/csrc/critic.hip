@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "../../include/mapdn.h"
 
@@ -139,18 +140,25 @@ k_head_fwd(HeadArgs p, float* __restrict__ v, long rows) {
 //                    loss = sum_rows w[row] (ret[row] - v[row])^2, w[row] = scale[0] * wrow[row / n] (wrow may be null: 1), and dv is
 //                    formed in the kernel as -2 w (ret - v) — the forward launch and its product are not needed at all.
 // A wavefront owns a contiguous range of rows (whole groups of n for formed rows: the sum over a group never crosses wavefronts).
-template <bool BC, int MODE>
-__global__ void __launch_bounds__(256)
+// NT threads per workgroup: 256 = one wavefront per SIMD with the whole 512-register file (parameters in registers, the next tile
+// prefetched, two staging tiles); 512 = TWO wavefronts per SIMD, each within 256 registers (parameters read from LDS where used, no
+// prefetch, one staging tile used twice) — one wavefront's LayerNorm / staging / reduction VALU work then runs under the other's MFMAs.
+template <bool BC, int MODE, int NT>
+__global__ void __launch_bounds__(NT)
 k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, const float* __restrict__ dot_w, float* __restrict__ dact,
            float* __restrict__ partial, int pstride, long rows, const float* __restrict__ wrow, const float* __restrict__ scale) {
   constexpr bool PG = MODE == 0 || MODE == 3;        // parameter gradients wanted
+  constexpr int NW = NT / 64, TILES = NT == 512 ? 1 : 2;
+  constexpr bool SLIM = NT == 512;
   extern __shared__ float sm[];
   f4* sW = (f4*)sm;                         // [4 nt][4 c][64]: W2[16 nt + j][16 c + 4 g + q]       A operand of pre^T = W2 xn^T
   f4* sWT = sW + 1024;                      // [4 nt][4 c][64]: W2[16 c + 4 g + q][16 nt + j]       A operand of dxn^T = W2^T dpre^T
-  float* stage = (float*)(sWT + 1024) + (size_t)(threadIdx.x >> 6) * 2 * 16 * HS;       // two 16 x HS tiles per wavefront
-  float* accn = (float*)(sWT + 1024) + (size_t)4 * 2 * 16 * HS + (size_t)(threadIdx.x >> 6) * p.n * 64;   // [n][64] per wavefront (BC, MODE < 2)
+  float* sP = (float*)(sWT + 1024);         // gamma | beta | b2 | w3 [4][64]
+  float* stage = sP + 256 + (size_t)(threadIdx.x >> 6) * TILES * 16 * HS;                // TILES 16 x HS tiles per wavefront
+  float* accn = sP + 256 + (size_t)NW * TILES * 16 * HS + (size_t)(threadIdx.x >> 6) * p.n * 64;   // [n][64] per wavefront (BC, MODE != 2)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15;
-  for (int i = tid; i < 1024; i += 256) {
+  if (tid < 64) { sP[tid] = p.gamma[tid]; sP[64 + tid] = p.beta[tid]; sP[128 + tid] = p.b2[tid]; sP[192 + tid] = p.w3[tid]; }
+  for (int i = tid; i < 1024; i += NT) {
     const int l = i & 63, c = (i >> 6) & 3, nt = i >> 8, lj = l & 15, lg = l >> 4;
     sW[i] = *(const f4*)(p.w2 + (size_t)(16 * nt + lj) * 64 + 16 * c + 4 * lg);
     f4 t;
@@ -159,16 +167,20 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
     sWT[i] = t;
   }
   if (BC && MODE != 2) for (int i = lane; i < p.n * 64; i += 64) accn[i] = 0.0f;
-  f4 gam[4], bet[4], b2v[4], w3v[4];
+  f4 gam_[4], bet_[4], b2v_[4], w3v_[4];     // (dead in the SLIM build: the accessors below read LDS there)
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
-    gam[nt] = *(const f4*)(p.gamma + 16 * nt + 4 * g); bet[nt] = *(const f4*)(p.beta + 16 * nt + 4 * g);
-    b2v[nt] = *(const f4*)(p.b2 + 16 * nt + 4 * g); w3v[nt] = *(const f4*)(p.w3 + 16 * nt + 4 * g);
+    gam_[nt] = *(const f4*)(p.gamma + 16 * nt + 4 * g); bet_[nt] = *(const f4*)(p.beta + 16 * nt + 4 * g);
+    b2v_[nt] = *(const f4*)(p.b2 + 16 * nt + 4 * g); w3v_[nt] = *(const f4*)(p.w3 + 16 * nt + 4 * g);
   }
   __syncthreads();
+  auto GAM = [&](int c) -> f4 { return SLIM ? *(const f4*)(sP + 16 * c + 4 * g) : gam_[c]; };
+  auto BET = [&](int c) -> f4 { return SLIM ? *(const f4*)(sP + 64 + 16 * c + 4 * g) : bet_[c]; };
+  auto B2V = [&](int c) -> f4 { return SLIM ? *(const f4*)(sP + 128 + 16 * c + 4 * g) : b2v_[c]; };
+  auto W3V = [&](int c) -> f4 { return SLIM ? *(const f4*)(sP + 192 + 16 * c + 4 * g) : w3v_[c]; };
 
   // this wavefront's range of rows [r0, r1)
-  const long W = (long)gridDim.x * 4, w = (long)blockIdx.x * 4 + wave;
+  const long W = (long)gridDim.x * NW, w = (long)blockIdx.x * NW + wave;
   long r0, r1;
   if (BC) { const long G = rows / p.n; r0 = (G * w / W) * p.n; r1 = (G * (w + 1) / W) * p.n; }
   else { const long Tn = (rows + 15) >> 4; r0 = (Tn * w / W) * 16; r1 = (Tn * (w + 1) / W) * 16; if (r1 > rows) r1 = rows; }
@@ -189,7 +201,7 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
   // the HBM / L2 latency)
   f4 xnext[4];
   float dvnext = 0.0f;
-  if (r0 < r1) {
+  if (!SLIM && r0 < r1) {
     const long row = r0 + j;
     load_row<BC>(p, row < r1 ? row : r1 - 1, g, xnext);
     dvnext = row < r1 ? dv[row] : 0.0f;
@@ -198,19 +210,25 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
     const long row = row0 + j;
     const bool valid = row < r1;
     f4 xh[4];
+    float dvcur;
+    if (SLIM) {
+      load_row<BC>(p, valid ? row : r1 - 1, g, xh);
+      dvcur = valid ? dv[row] : 0.0f;
+    } else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) xh[c] = xnext[c];
-    const float dvcur = dvnext;
-    if (row0 + 16 < r1) {
-      const long rn = row + 16;
-      load_row<BC>(p, rn < r1 ? rn : r1 - 1, g, xnext);
-      dvnext = rn < r1 ? dv[rn] : 0.0f;
+      for (int c = 0; c < 4; ++c) xh[c] = xnext[c];
+      dvcur = dvnext;
+      if (row0 + 16 < r1) {
+        const long rn = row + 16;
+        load_row<BC>(p, rn < r1 ? rn : r1 - 1, g, xnext);
+        dvnext = rn < r1 ? dv[rn] : 0.0f;
+      }
     }
     const float rs = ln_stats(xh, p.eps);
     f4 xn[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const f4 y = xh[c] * gam[c] + bet[c];
+      const f4 y = xh[c] * GAM(c) + BET(c);
       xn[c] = f4{relu_nan(y.x), relu_nan(y.y), relu_nan(y.z), relu_nan(y.w)};
     }
     // ---- pre^T = W2 xn^T
@@ -230,9 +248,11 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
     if (MODE == 3) {
       float dot = 0.0f;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < 4; ++nt) {
+        const f4 bb = B2V(nt), ww = W3V(nt);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dot = fmaf(relu_nan(acc[nt][r] + b2v[nt][r]), w3v[nt][r], dot);
+        for (int r = 0; r < 4; ++r) dot = fmaf(relu_nan(acc[nt][r] + bb[r]), ww[r], dot);
+      }
       const float err = dvcur - (sum_g(dot) + b3);
       float wgt = lscale;
       if (wrow) { const unsigned rc = (unsigned)(valid ? row : r1 - 1); wgt *= wrow[BC ? rc / (unsigned)p.n : rc]; }
@@ -240,15 +260,17 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
       if (valid && g == 0) aloss = fmaf(wgt * err, err, aloss);
     }
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < 4; ++nt) {
+      const f4 bb = B2V(nt), ww = W3V(nt);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pre = acc[nt][r] + b2v[nt][r];
+        const float pre = acc[nt][r] + bb[r];
         const bool pos = pre > 0.0f;
-        const float dp = pos ? dvr * w3v[nt][r] : 0.0f;
+        const float dp = pos ? dvr * ww[r] : 0.0f;
         if (PG) { aw3[nt][r] = fmaf(pos ? pre : 0.0f, dvr, aw3[nt][r]); ab2[nt][r] += dp; }
         acc[nt][r] = dp;
       }
+    }
     if (PG && g == 0) ab3 += dvr;
     // ---- dxn^T = W2^T dpre^T
     f4 dxn[4] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
@@ -264,17 +286,35 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
     }
     // ---- dW2 += dpre^T xn: both operands through LDS into C layout (rows on the contraction axis)
     if (PG) {
-      float* s0 = stage; float* s1 = stage + 16 * HS;
+      float* s0 = stage; float* s1 = SLIM ? stage : stage + 16 * HS;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { *(f4*)(s0 + j * HS + 16 * c + 4 * g) = acc[c]; *(f4*)(s1 + j * HS + 16 * c + 4 * g) = xn[c]; }
+      for (int c = 0; c < 4; ++c) *(f4*)(s0 + j * HS + 16 * c + 4 * g) = acc[c];
+      if (!SLIM) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *(f4*)(s1 + j * HS + 16 * c + 4 * g) = xn[c];
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float dCs[4][4];                      // SLIM: dpre in C layout for all four steps, read before the one tile is reused for xn
+      if (SLIM) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) dCs[s][nt] = s0[(4 * g + s) * HS + 16 * nt + j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *(f4*)(s1 + j * HS + 16 * c + 4 * g) = xn[c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         float dC[4], xC[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) { dC[nt] = s0[(4 * g + s) * HS + 16 * nt + j]; xC[nt] = s1[(4 * g + s) * HS + 16 * nt + j]; }
+        for (int nt = 0; nt < 4; ++nt) { dC[nt] = SLIM ? dCs[s][nt] : s0[(4 * g + s) * HS + 16 * nt + j]; xC[nt] = s1[(4 * g + s) * HS + 16 * nt + j]; }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -289,7 +329,7 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
 #pragma unroll
       for (int q = 0; q < 4; ++q) d[q] = xn[c][q] > 0.0f ? dxn[c][q] : 0.0f;
       if (PG) { ag[c] += d * xh[c]; ab[c] += d; }
-      const f4 a = d * gam[c];
+      const f4 a = d * GAM(c);
       s1a += hsum(a); s2a += hsum(a * xh[c]);
       dxn[c] = a;
     }
@@ -326,26 +366,31 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
       unsigned grp = rel / (unsigned)p.n, i = rel - grp * (unsigned)p.n;
       float* pbase = dx + ((size_t)(r0 / p.n) + grp) * 64 + lane;
       if (p.n >= 16) {
+        unsigned i2 = i;                      // (i stays the tile's first agent index for the slot addresses)
         // the tile's 16 rows belong to 16 DIFFERENT agents: their dper_n slots are independent — 16 reads, 16 adds, 16 writes in flight
         // instead of 16 dependent LDS round trips
-        float val[16], cur[16];
+        constexpr int H = SLIM ? 4 : 16;      // rows in flight (the SLIM build has 256 registers: four at a time)
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          unsigned ii = i + rr; if (ii >= (unsigned)p.n) ii -= p.n;
-          val[rr] = rr < cnt ? s0[rr * HS + lane] : 0.0f;
-          cur[rr] = accn[ii * 64 + lane];
-        }
+        for (int h0 = 0; h0 < 16; h0 += H) {
+          float val[H], cur[H];
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          unsigned ii = i + rr; if (ii >= (unsigned)p.n) ii -= p.n;
-          accn[ii * 64 + lane] = cur[rr] + val[rr];
-        }
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr)
-          if (rr < cnt) {
-            carry += val[rr];
-            if (++i == (unsigned)p.n) { *pbase = carry; carry = 0.0f; i = 0; pbase += 64; }
+          for (int rr = 0; rr < H; ++rr) {
+            unsigned ii = i + h0 + rr; if (ii >= (unsigned)p.n) ii -= p.n;
+            val[rr] = h0 + rr < cnt ? s0[(h0 + rr) * HS + lane] : 0.0f;
+            cur[rr] = accn[ii * 64 + lane];
           }
+#pragma unroll
+          for (int rr = 0; rr < H; ++rr) {
+            unsigned ii = i + h0 + rr; if (ii >= (unsigned)p.n) ii -= p.n;
+            accn[ii * 64 + lane] = cur[rr] + val[rr];
+          }
+#pragma unroll
+          for (int rr = 0; rr < H; ++rr)
+            if (h0 + rr < cnt) {
+              carry += val[rr];
+              if (++i2 == (unsigned)p.n) { *pbase = carry; carry = 0.0f; i2 = 0; pbase += 64; }
+            }
+        }
       } else {
         for (int rr = 0; rr < cnt; ++rr) {
           const float val = s0[rr * HS + lane];
@@ -408,10 +453,24 @@ static int head_cus() {
   return cus;
 }
 // workgroups of the backward launch: one per CU (its wavefronts keep dW2 in registers, the weights in LDS), never more wavefronts
-// than units of work (groups of n formed rows / tiles of 16 rows)
-static int head_bwd_blocks(int64_t rows, int32_t n, bool bc) {
+// than units of work (groups of n formed rows / tiles of 16 rows); nw = wavefronts per workgroup (4, or 8 for the 512-thread build)
+static int head_bwd_blocks(int64_t rows, int32_t n, bool bc, int nw) {
   const int64_t units = bc ? rows / n : (rows + 15) / 16;
-  return (int)std::max<int64_t>(1, std::min<int64_t>((units + 3) / 4, head_cus()));
+  return (int)std::max<int64_t>(1, std::min<int64_t>((units + nw - 1) / nw, head_cus()));
+}
+static size_t head_bwd_lds(int threads, int32_t n, bool accn) {
+  const int nw = threads / 64, tiles = threads == 512 ? 1 : 2;
+  return (size_t)2 * 1024 * 16 + 256 * 4 + (size_t)nw * tiles * 16 * mapdn::HS * 4 + (accn ? (size_t)nw * n * 64 * 4 : 0);
+}
+// 512 threads (two wavefronts per SIMD) when its LDS fits a CU and the batch is big enough to give every wavefront work;
+// MAPDN_HEAD_BWD_THREADS = 256 / 512 forces one (A/B measurements)
+static int head_bwd_threads(int64_t rows, int32_t n, bool bc, bool accn) {
+  const char* e = getenv("MAPDN_HEAD_BWD_THREADS");
+  const bool fits = head_bwd_lds(512, n, accn) <= (size_t)160 * 1024;
+  if (e && atoi(e) == 256) return 256;
+  if (e && atoi(e) == 512 && fits) return 512;
+  const int64_t units = bc ? rows / n : (rows + 15) / 16;
+  return fits && units >= (int64_t)head_cus() * 8 ? 512 : 256;
 }
 static bool head_args_ok(const float* x, const float* per_n, int32_t n, const float* gamma, const float* beta, const float* w2, const float* b2,
                          const float* w3, const float* b3, int64_t rows) {
@@ -435,23 +494,32 @@ extern "C" int mapdn_critic_head_forward(const float* x, const float* per_n, int
 
 extern "C" int64_t mapdn_critic_head_scratch_floats(int64_t rows, int32_t n, int32_t formed) {
   if (rows < 1 || (formed && (n < 1 || rows % n))) return 0;
-  return (int64_t)head_bwd_blocks(rows, n, formed != 0) * 4 * (mapdn::HP + (formed ? n * 64 : 0));
+  const int64_t waves = std::max<int64_t>((int64_t)head_bwd_blocks(rows, n, formed != 0, 4) * 4, (int64_t)head_bwd_blocks(rows, n, formed != 0, 8) * 8);
+  return waves * (mapdn::HP + (formed ? n * 64 : 0));        // (whichever launch shape the backward picks)
 }
 
-template <bool BC, int MODE>
-static int head_bwd_launch(const mapdn::HeadArgs& a, const float* dv, float* dx, const float* dot_w, float* dact, float* scratch, float* grads,
-                           int64_t rows, hipStream_t st, const float* wrow = nullptr, const float* scale = nullptr) {
+template <bool BC, int MODE, int NT>
+static int head_bwd_launch_nt(const mapdn::HeadArgs& a, const float* dv, float* dx, const float* dot_w, float* dact, float* scratch, float* grads,
+                              int64_t rows, hipStream_t st, const float* wrow, const float* scale) {
   using namespace mapdn;
-  const int blocks = head_bwd_blocks(rows, a.n, BC), nw = blocks * 4;
+  constexpr int NW = NT / 64;
+  const int blocks = head_bwd_blocks(rows, a.n, BC, NW), nw = blocks * NW;
   const int pstride = HP + (BC ? a.n * 64 : 0);
-  const size_t lds = (size_t)2 * 1024 * 16 + (size_t)4 * 2 * 16 * HS * 4 + (BC && MODE != 2 ? (size_t)4 * a.n * 64 * 4 : 0);
+  const size_t lds = head_bwd_lds(NT, a.n, BC && MODE != 2);
   if (lds > (size_t)160 * 1024) return MAPDN_E_INVALID;
-  const void* fn = (const void*)k_head_bwd<BC, MODE>;
+  const void* fn = (const void*)k_head_bwd<BC, MODE, NT>;
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MAPDN_E_HIP;
-  hipLaunchKernelGGL((k_head_bwd<BC, MODE>), dim3(blocks), dim3(256), lds, st, a, dv, dx, dot_w, dact, scratch, pstride, (long)rows, wrow, scale);
+  hipLaunchKernelGGL((k_head_bwd<BC, MODE, NT>), dim3(blocks), dim3(NT), lds, st, a, dv, dx, dot_w, dact, scratch, pstride, (long)rows, wrow, scale);
   if (MODE == 0 || MODE == 3) hipLaunchKernelGGL(k_head_reduce, dim3((HP + 63) / 64), dim3(256), 0, st, scratch, nw, pstride, 0, HP, grads);
   if (BC && MODE != 2) hipLaunchKernelGGL(k_head_reduce, dim3(a.n), dim3(256), 0, st, scratch, nw, pstride, HP, HP + a.n * 64, grads);
   return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
+}
+template <bool BC, int MODE>
+static int head_bwd_launch(const mapdn::HeadArgs& a, const float* dv, float* dx, const float* dot_w, float* dact, float* scratch, float* grads,
+                           int64_t rows, hipStream_t st, const float* wrow = nullptr, const float* scale = nullptr) {
+  if (head_bwd_threads(rows, a.n, BC, BC && MODE != 2) == 512)
+    return head_bwd_launch_nt<BC, MODE, 512>(a, dv, dx, dot_w, dact, scratch, grads, rows, st, wrow, scale);
+  return head_bwd_launch_nt<BC, MODE, 256>(a, dv, dx, dot_w, dact, scratch, grads, rows, st, wrow, scale);
 }
 
 extern "C" int mapdn_critic_head_backward(const float* dv, const float* x, const float* per_n, int32_t n, const float* gamma, const float* beta,
