@@ -617,6 +617,22 @@ class DDPGNet(nn.Module):
         loss): the central critic may then skip the gradients of its own parameters, which the policy optimiser never reads."""
         return self._value_central(obs, act, own_action_only) if self.alg == "maddpg" else self._value_independent(obs, act)
 
+    def _independent_first_layer(self, cr, obs, act):
+        """IDDPG's shared critic, first layer on [obs_i | id_i | act_i] (iddpg.py:32-58) as  W_obs obs + id column + W_act act, [b, n, h];
+        on a tall GPU batch the observation product takes _TallLinear (its weight gradient is a [h, o] product with b * n rows of
+        reduction, which the BLAS back end runs on two workgroups)"""
+        b, n, o = obs.shape[0], self.n_, self.obs_dim
+        ids = n if self.args.agent_id else 0
+        w = cr.fc1.weight
+        if _tall_ok(obs, b * n, w):
+            x = _TallLinear.apply(obs.reshape(b * n, o), w[:, :o], cr.fc1.bias).view(b, n, -1)
+            x = x + _TallLinear.apply(act.reshape(b * n, -1), w[:, o + ids:], None).view(b, n, -1)
+        else:
+            x = F.linear(obs, w[:, :o], cr.fc1.bias) + F.linear(act, w[:, o + ids:])
+        if ids:
+            x = x + w[:, o:o + n].t().unsqueeze(0)
+        return x
+
     def _value_independent(self, obs, act):
         """IDDPG (iddpg.py:32-58): critic input [obs_i | id_i | act_i]"""
         b, n, o = obs.shape[0], self.n_, self.obs_dim
@@ -631,7 +647,7 @@ class DDPGNet(nn.Module):
 
         if self.args.shared_params:
             cr = self.value_dicts[0]
-            v, _ = cr.trunk(first_layer(cr, obs, act, None).reshape(b * n, -1))
+            v, _ = cr.trunk(self._independent_first_layer(cr, obs, act).reshape(b * n, -1))
             return v.view(b, n, -1)
         return torch.stack([cr.trunk(first_layer(cr, obs[:, i], act[:, i], i))[0] for i, cr in enumerate(self.value_dicts)], 1)
 
@@ -705,10 +721,7 @@ class DDPGNet(nn.Module):
                 x = F.linear(obs.reshape(b, n * o), w[:, :n * o], cr.fc1.bias) + F.linear(act.reshape(b, n * self.act_dim), w[:, n * o + ids:])
                 per_n = w[:, n * o:n * o + n].t()
             elif self.alg == "iddpg":
-                x = F.linear(obs, w[:, :o], cr.fc1.bias) + F.linear(act, w[:, o + ids:])
-                if ids:
-                    x = x + w[:, o:o + n].t().unsqueeze(0)
-                x = x.reshape(b * n, -1)
+                x = self._independent_first_layer(cr, obs, act).reshape(b * n, -1)
             if x is not None and critic_head_ok(cr, x, b * n):
                 if valid is None:
                     scale, wrow = x.new_full((1,), 1.0 / (b * n)), None
