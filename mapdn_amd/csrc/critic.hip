@@ -20,7 +20,8 @@
 //   "C layout"  lane holds rows 4 g + s, feature 16 nt + j: needed only by dW2 += dpre^T xn (the contraction runs over ROWS),
 //               reached through a per-wave 16 x 64 LDS tile.
 // dW2 / dgamma / dbeta / db2 / dw3 / db3 (and, for formed rows, dper_n) are accumulated per wavefront over its contiguous range of
-// rows and summed across wavefronts by a second small launch in a fixed order: deterministic, no atomics.
+// rows, summed across the wavefronts of a workgroup through LDS and across workgroups by a second small launch, both in a fixed
+// order: deterministic, no atomics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -404,16 +405,29 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
     }
   }
 
-  // ---- this wavefront's partial sums -> partial[w][...]
+  // ---- partial sums: the wavefronts of a workgroup are summed HERE, through LDS (the weights and staging tiles are dead by now), in a
+  // fixed order, so that the second launch reads one partial per workgroup (256) instead of one per wavefront (2048)
   if (MODE != 2) {
-    float* pp = partial + (size_t)w * pstride;
+    float* pp = partial + (size_t)blockIdx.x * pstride;
+    if (BC) {                                 // dper_n: the per-wavefront [n][64] accumulators are already in LDS
+      __syncthreads();
+      const float* a0 = sP + 256 + (size_t)NW * TILES * 16 * HS;
+      for (int i = tid; i < p.n * 64; i += NT) {
+        float t = a0[i];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) t += a0[(size_t)ww * p.n * 64 + i];
+        pp[HP + i] = t;
+      }
+    }
     if (PG) {
+      __syncthreads();                        // every wavefront is out of its tile loop (and done with accn)
+      float* red = sm + (size_t)wave * HP;    // [NW][HP] floats from the start of LDS (the launch sizes LDS for it)
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pp[(size_t)(16 * a + 4 * g + r) * 64 + 16 * b + j] = accW[a][b][r];
+          for (int r = 0; r < 4; ++r) red[(16 * a + 4 * g + r) * 64 + 16 * b + j] = accW[a][b][r];
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -421,15 +435,18 @@ k_head_bwd(HeadArgs p, const float* __restrict__ dv, float* __restrict__ dx, con
           const float tg = sum_j(ag[c][q]), tb = sum_j(ab[c][q]), t2 = sum_j(ab2[c][q]), t3 = sum_j(aw3[c][q]);
           if (j == 0) {
             const int col = 16 * c + 4 * g + q;
-            pp[4096 + col] = tg; pp[4160 + col] = tb; pp[4224 + col] = t2; pp[4288 + col] = t3;
+            red[4096 + col] = tg; red[4160 + col] = tb; red[4224 + col] = t2; red[4288 + col] = t3;
           }
         }
       const float t = sum_j(ab3), tl = sum_j(aloss);           // (lanes with g != 0 hold 0)
-      if (lane == 0) { pp[4352] = t; pp[4353] = tl; }
-    }
-    if (BC) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      for (int i = lane; i < p.n * 64; i += 64) pp[HP + i] = accn[i];
+      if (lane == 0) { red[4352] = t; red[4353] = tl; }
+      __syncthreads();
+      for (int col = tid; col < 4354; col += NT) {
+        float v = sm[col];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) v += sm[(size_t)ww * HP + col];
+        pp[col] = v;
+      }
     }
   }
 }
@@ -494,8 +511,8 @@ extern "C" int mapdn_critic_head_forward(const float* x, const float* per_n, int
 
 extern "C" int64_t mapdn_critic_head_scratch_floats(int64_t rows, int32_t n, int32_t formed) {
   if (rows < 1 || (formed && (n < 1 || rows % n))) return 0;
-  const int64_t waves = std::max<int64_t>((int64_t)head_bwd_blocks(rows, n, formed != 0, 4) * 4, (int64_t)head_bwd_blocks(rows, n, formed != 0, 8) * 8);
-  return waves * (mapdn::HP + (formed ? n * 64 : 0));        // (whichever launch shape the backward picks)
+  const int64_t blocks = std::max<int64_t>(head_bwd_blocks(rows, n, formed != 0, 4), head_bwd_blocks(rows, n, formed != 0, 8));
+  return blocks * (mapdn::HP + (formed ? n * 64 : 0));       // one partial per workgroup (whichever launch shape the backward picks)
 }
 
 template <bool BC, int MODE, int NT>
@@ -503,9 +520,10 @@ static int head_bwd_launch_nt(const mapdn::HeadArgs& a, const float* dv, float* 
                               int64_t rows, hipStream_t st, const float* wrow, const float* scale) {
   using namespace mapdn;
   constexpr int NW = NT / 64;
-  const int blocks = head_bwd_blocks(rows, a.n, BC, NW), nw = blocks * NW;
+  const int blocks = head_bwd_blocks(rows, a.n, BC, NW), nw = blocks;          // one partial per workgroup
   const int pstride = HP + (BC ? a.n * 64 : 0);
-  const size_t lds = head_bwd_lds(NT, a.n, BC && MODE != 2);
+  size_t lds = head_bwd_lds(NT, a.n, BC && MODE != 2);
+  if (MODE == 0 || MODE == 3) lds = std::max(lds, (size_t)NW * HP * 4);         // the end-of-kernel reduction across wavefronts
   if (lds > (size_t)160 * 1024) return MAPDN_E_INVALID;
   const void* fn = (const void*)k_head_bwd<BC, MODE, NT>;
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MAPDN_E_HIP;
