@@ -4,8 +4,8 @@ HIPCC ?= /opt/rocm/bin/hipcc
 FLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result
 LIB   := mapdn_amd/libmapdn_hip.so
 CSRC  := mapdn_amd/csrc
-SRC   := plan.cpp kernels.hip dense.hip sparse.hip policy.hip critic.hip rollout.hip capi.hip
-HDR   := $(CSRC)/plan.hpp $(CSRC)/colstats.hpp $(CSRC)/kernels.hpp $(CSRC)/philox.hpp $(CSRC)/nrmath.hpp $(CSRC)/nr_common.hpp $(CSRC)/nr_tree.hpp $(CSRC)/nr_inst_list.hpp include/mapdn.h
+SRC   := plan.cpp kernels.hip dense.hip sparse.hip policy.hip policy_bwd.hip critic.hip rollout.hip capi.hip
+HDR   := $(CSRC)/plan.hpp $(CSRC)/colstats.hpp $(CSRC)/rowtile.hpp $(CSRC)/kernels.hpp $(CSRC)/philox.hpp $(CSRC)/nrmath.hpp $(CSRC)/nr_common.hpp $(CSRC)/nr_tree.hpp $(CSRC)/nr_inst_list.hpp include/mapdn.h
 OBJ   := $(addprefix build/,$(addsuffix .o,$(basename $(SRC)))) build/nr_inst_0.o build/nr_inst_1.o build/nr_inst_2.o build/nr_inst_3.o
 
 lib: $(LIB)

@@ -338,6 +338,25 @@ int mapdn_policy_forward(const float* obs, const float* hid_in, const float* w1,
                          const float* w2, const float* b2, float* means, float* hid_out, int32_t rows, int32_t n_agents,
                          int32_t obs_dim, int32_t id_dim, float ln_eps, void* stream);
 
+/* The same launch for the learner's TRAINING-time forward (models/maddpg.py:103-125 through agents/rnn_agent.py:16-32): also writes
+ * x1 [rows, 64] = fc1(obs) + b1 + id column (the LayerNorm input, all the backward keeps); hid_out may be NULL (not stored). */
+int mapdn_policy_forward_train(const float* obs, const float* hid_in, const float* w1, const float* b1, const float* ln_g,
+                               const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                               const float* w2, const float* b2, float* means, float* hid_out, float* x1_out, int32_t rows,
+                               int32_t n_agents, int32_t obs_dim, int32_t id_dim, float ln_eps, void* stream);
+/* Backward of the agent's trunk LayerNorm -> ReLU -> GRUCell -> fc2 (agents/rnn_agent.py:16-32) for d loss / d means [rows], one launch
+ * (csrc/policy_bwd.hip) that recomputes the trunk from x1 and hid_in and writes what the remaining weight-gradient products need:
+ *   dx1 [rows, 64] = d loss / d x1 (-> fc1: dW1 = dx1^T [obs | id], db1);
+ *   dgates [rows, 256] = d loss / d gate pre-activations  r | z | n_input | n_hidden  (torch.nn.GRUCell: dW_ih = dgates[:, 0:192]^T xn,
+ *                        dW_hh = dgates[:, [0:128, 192:256]]^T hid_in);  xn [rows, 64] = relu(LayerNorm(x1));
+ *   small [512] = db_r | db_z | db_ni | db_nh | dgamma | dbeta | dw2 (64 each) | db2 (1) + pad, reduced in a fixed order (no atomics):
+ *                 b_ih gradient = db_r | db_z | db_ni, b_hh gradient = db_r | db_z | db_nh;
+ *   scratch: mapdn_policy_backward_scratch_floats(rows) floats.  Hidden size 64, one action output; fp32, contiguous device pointers. */
+int64_t mapdn_policy_backward_scratch_floats(int64_t rows);
+int mapdn_policy_backward(const float* dmeans, const float* x1, const float* hid_in, const float* ln_g, const float* ln_b, float ln_eps,
+                          const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* w2, float* dx1,
+                          float* dgates, float* xn, float* small, float* scratch, int64_t rows, void* stream);
+
 /* 1 when mapdn_policy_forward has a launch shape for this observation width (the parameter set and a tile's activations must
  * fit the 160 KB LDS of a CU: obs_dim up to ~2 400 columns without ids), else 0 — callers then keep their own forward. */
 int mapdn_policy_forward_fits(int32_t obs_dim, int32_t id_dim);

@@ -35,6 +35,7 @@ EXPORTS = (
     "mapdn_get_nr_geometry", "mapdn_debug_stream", "mapdn_build_info", "mapdn_layernorm64_bc_forward", "mapdn_layernorm64_bc_backward", "mapdn_relu_dot64_forward", "mapdn_relu_dot64_backward",
     "mapdn_critic_head_forward", "mapdn_critic_head_scratch_floats", "mapdn_critic_head_backward", "mapdn_critic_head_backward_dot", "mapdn_critic_head_mse", "mapdn_get_profile_stats",
     "mapdn_explore_actions", "mapdn_rollout_stats", "mapdn_copy_segments",
+    "mapdn_policy_forward_train", "mapdn_policy_backward", "mapdn_policy_backward_scratch_floats",
 )
 
 _pd = C.POINTER(C.c_double)
@@ -174,6 +175,10 @@ def load():
     lib.mapdn_get_sparse_program.argtypes = [vp, C.c_int32, _pi, _pi, _pi, _pi]
     lib.mapdn_policy_forward.argtypes = [vp] * 14 + [C.c_int32] * 4 + [C.c_float, vp]
     lib.mapdn_policy_forward_fits.argtypes = [C.c_int32, C.c_int32]
+    lib.mapdn_policy_forward_train.argtypes = [vp] * 15 + [C.c_int32] * 4 + [C.c_float, vp]
+    lib.mapdn_policy_backward_scratch_floats.argtypes = [C.c_int64]
+    lib.mapdn_policy_backward_scratch_floats.restype = C.c_int64
+    lib.mapdn_policy_backward.argtypes = [vp] * 5 + [C.c_float] + [vp] * 10 + [C.c_int64, vp]
     lib.mapdn_layernorm64_forward.argtypes = [vp] * 6 + [C.c_int64, C.c_float, C.c_int32, vp]
     lib.mapdn_layernorm64_backward_blocks.argtypes = [C.c_int64]
     lib.mapdn_layernorm64_backward.argtypes = [vp] * 10 + [C.c_int64, C.c_int32, vp]

@@ -9,10 +9,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("MAPDN_BUILD_OUT") or os.path.join(HERE, "libmapdn_hip.so")   # MAPDN_BUILD_OUT: debug variants beside the product library
-SOURCES = ["plan.cpp", "kernels.hip", "dense.hip", "sparse.hip", "policy.hip", "critic.hip", "rollout.hip", "capi.hip"]
+SOURCES = ["plan.cpp", "kernels.hip", "dense.hip", "sparse.hip", "policy.hip", "policy_bwd.hip", "critic.hip", "rollout.hip", "capi.hip"]
 # k_nr_tree's instantiations (nr_inst_list.hpp) are compiled as NR_PARTS objects from ONE source, in parallel
 NR_INST_SOURCE, NR_PARTS = "nr_inst.hip", 4
-HEADERS = ["plan.hpp", "colstats.hpp", "kernels.hpp", "philox.hpp", "nrmath.hpp", "nr_common.hpp", "nr_tree.hpp", "nr_inst_list.hpp", NR_INST_SOURCE,
+HEADERS = ["plan.hpp", "colstats.hpp", "rowtile.hpp", "kernels.hpp", "philox.hpp", "nrmath.hpp", "nr_common.hpp", "nr_tree.hpp", "nr_inst_list.hpp", NR_INST_SOURCE,
            os.path.join("..", "..", "include", "mapdn.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 HASH_TAG = b"MAPDN_SRC_HASH="

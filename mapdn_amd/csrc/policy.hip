@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(PT)
 k_policy_fwd(const float* __restrict__ obs, const float* __restrict__ hid_in, const float* __restrict__ w1, const float* __restrict__ b1,
              const float* __restrict__ ln_g, const float* __restrict__ ln_b, const float* __restrict__ w_ih, const float* __restrict__ w_hh,
              const float* __restrict__ b_ih, const float* __restrict__ b_hh, const float* __restrict__ w2, const float* __restrict__ b2,
-             float* __restrict__ means, float* __restrict__ hid_out, int rows, int n_agents, int o, int ids, float ln_eps, int ids_lds) {
+             float* __restrict__ means, float* __restrict__ hid_out, int rows, int n_agents, int o, int ids, float ln_eps, int ids_lds,
+             float* __restrict__ x1_out) {
   extern __shared__ float sm[];
   const int KC1 = (o + 15) >> 4;                                  // 16-wide k chunks of fc1 (zero-padded weights)
   f4* sW1 = (f4*)sm;                                              // [4][KC1][64]
@@ -100,6 +101,7 @@ k_policy_fwd(const float* __restrict__ obs, const float* __restrict__ hid_in, co
       for (int nt = 0; nt < 4; ++nt) {
         const int u = 16 * nt + j;
         acc[nt][r] += sB1[u] + (ids ? (ids_lds ? sW1id[(size_t)agent * PH + u] : w1[(size_t)u * in1 + o + agent]) : 0.0f);
+        if (x1_out && row0 + 4 * g + r < rows) x1_out[(size_t)(row0 + 4 * g + r) * PH + u] = acc[nt][r];   // (training: the LayerNorm input, for the backward)
         sum += acc[nt][r];
       }
       mean[r] = row_sum16(sum) * (1.0f / PH);
@@ -152,7 +154,7 @@ k_policy_fwd(const float* __restrict__ obs, const float* __restrict__ hid_in, co
         const float nn = tanhf(fmaf(rg, aHN[r] + sBhh[2 * PH + u], aIN[r] + sBih[2 * PH + u]));
         const float hu = hid_in[(size_t)rc * PH + u];
         const float hnew = fmaf(zg, hu - nn, nn);                 // (1 - z) n + z h
-        if (row < rows) hid_out[(size_t)row * PH + u] = hnew;
+        if (hid_out && row < rows) hid_out[(size_t)row * PH + u] = hnew;
         outp[r] = fmaf(sW2[u], hnew, outp[r]);
       }
     }
@@ -395,12 +397,12 @@ extern "C" int mapdn_policy_forward_fits(int32_t obs_dim, int32_t id_dim) {
   return obs_dim >= 1 && id_dim >= 0 && policy_geometry(obs_dim, id_dim, pt, il, lds) ? 1 : 0;
 }
 
-extern "C" int mapdn_policy_forward(const float* obs, const float* hid_in, const float* w1, const float* b1, const float* ln_g,
-                                    const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
-                                    const float* w2, const float* b2, float* means, float* hid_out, int32_t rows, int32_t n_agents,
-                                    int32_t obs_dim, int32_t id_dim, float ln_eps, void* stream) {
+static int policy_forward_launch(const float* obs, const float* hid_in, const float* w1, const float* b1, const float* ln_g,
+                                 const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                                 const float* w2, const float* b2, float* means, float* hid_out, float* x1_out, int32_t rows, int32_t n_agents,
+                                 int32_t obs_dim, int32_t id_dim, float ln_eps, void* stream) {
   using namespace mapdn;
-  if (!obs || !hid_in || !w1 || !means || !hid_out || rows < 1 || n_agents < 1 || obs_dim < 1 || id_dim < 0) return MAPDN_E_INVALID;
+  if (!obs || !hid_in || !w1 || !means || rows < 1 || n_agents < 1 || obs_dim < 1 || id_dim < 0) return MAPDN_E_INVALID;
   int pt = 512, ids_lds = 1;
   size_t lds = 0;
   if (!policy_geometry(obs_dim, id_dim, pt, ids_lds, lds)) return MAPDN_E_INVALID;   // callers ask mapdn_policy_forward_fits first
@@ -413,9 +415,29 @@ extern "C" int mapdn_policy_forward(const float* obs, const float* hid_in, const
   const int blocks = std::min((tiles + pt / 64 - 1) / (pt / 64), cus);   // one resident workgroup per CU (its LDS is the parameter set)
   if (pt == 512)
     hipLaunchKernelGGL(k_policy_fwd<512>, dim3(blocks), dim3(512), lds, (hipStream_t)stream, obs, hid_in, w1, b1, ln_g, ln_b, w_ih, w_hh,
-                       b_ih, b_hh, w2, b2, means, hid_out, rows, n_agents, obs_dim, id_dim, ln_eps, ids_lds);
+                       b_ih, b_hh, w2, b2, means, hid_out, rows, n_agents, obs_dim, id_dim, ln_eps, ids_lds, x1_out);
   else
     hipLaunchKernelGGL(k_policy_fwd<256>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, obs, hid_in, w1, b1, ln_g, ln_b, w_ih, w_hh,
-                       b_ih, b_hh, w2, b2, means, hid_out, rows, n_agents, obs_dim, id_dim, ln_eps, ids_lds);
+                       b_ih, b_hh, w2, b2, means, hid_out, rows, n_agents, obs_dim, id_dim, ln_eps, ids_lds, x1_out);
   return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
+}
+
+extern "C" int mapdn_policy_forward(const float* obs, const float* hid_in, const float* w1, const float* b1, const float* ln_g,
+                                    const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                                    const float* w2, const float* b2, float* means, float* hid_out, int32_t rows, int32_t n_agents,
+                                    int32_t obs_dim, int32_t id_dim, float ln_eps, void* stream) {
+  if (!hid_out) return MAPDN_E_INVALID;
+  return policy_forward_launch(obs, hid_in, w1, b1, ln_g, ln_b, w_ih, w_hh, b_ih, b_hh, w2, b2, means, hid_out, nullptr, rows, n_agents, obs_dim,
+                               id_dim, ln_eps, stream);
+}
+
+// the same launch for the learner's TRAINING-time forward: also writes x1 [rows, 64] — the LayerNorm input fc1(obs) + b1 + id column, which
+// mapdn_policy_backward starts from — and skips the hidden-state output when hid_out is NULL
+extern "C" int mapdn_policy_forward_train(const float* obs, const float* hid_in, const float* w1, const float* b1, const float* ln_g,
+                                          const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                                          const float* w2, const float* b2, float* means, float* hid_out, float* x1_out, int32_t rows,
+                                          int32_t n_agents, int32_t obs_dim, int32_t id_dim, float ln_eps, void* stream) {
+  if (!x1_out) return MAPDN_E_INVALID;
+  return policy_forward_launch(obs, hid_in, w1, b1, ln_g, ln_b, w_ih, w_hh, b_ih, b_hh, w2, b2, means, hid_out, x1_out, rows, n_agents, obs_dim,
+                               id_dim, ln_eps, stream);
 }

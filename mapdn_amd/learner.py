@@ -452,6 +452,77 @@ def layernorm_act(ln: nn.LayerNorm, act, x: torch.Tensor) -> torch.Tensor:
     return act(ln(x))
 
 
+def _splitk_dw(dy2: torch.Tensor, x2: torch.Tensor, blk: int = 16384) -> torch.Tensor:
+    """dy2^T x2 ([out, in]) for [rows, out] x [rows, in] with millions of rows: the rows cut into blocks whose partial products are one
+    batched GEMM, then summed (what _TallLinear.backward does for its weight).  dy2 may be a column slice of a wider tensor."""
+    rows = x2.shape[0]
+    full = rows // blk * blk
+    dw = None
+    if full:
+        a = dy2[:full].unflatten(0, (-1, blk)).transpose(1, 2)
+        dw = torch.bmm(a, x2[:full].unflatten(0, (-1, blk))).sum(0)
+    if full < rows:
+        rest = dy2[full:].t() @ x2[full:]
+        dw = rest if dw is None else dw + rest
+    return dw
+
+
+class _PolicyTrunk(torch.autograd.Function):
+    """means = fc2(GRUCell(relu(LayerNorm(fc1(obs) + id column)), last_hid)) of the shared recurrent agent (agents/rnn_agent.py:5-32) for the
+    policy UPDATE (models/maddpg.py:103-125: only the means carry gradient — the loss does not read the new hidden state), forward and
+    backward as HIP launches: mapdn_policy_forward_train (the rollout's one-launch forward; keeps x1 = the LayerNorm input) and
+    mapdn_policy_backward (csrc/policy_bwd.hip: recomputes the trunk, writes d gate pre-activations / xn / dx1 and the small gradients).
+    What is left for the BLAS back end are the three K = rows weight-gradient products, run block-wise (_splitk_dw).  The PyTorch route
+    moved ~100 GB per update through the projections, ATen's fused cell and its workspace."""
+
+    @staticmethod
+    def forward(ctx, obs2, hid2, n_agents, ids, eps, w1, b1, lnw, lnb, w_ih, w_hh, b_ih, b_hh, w2, b2):
+        from . import _lib
+        lib = _lib.load()
+        obs2, hid2 = obs2.contiguous(), hid2.contiguous()
+        rows, o = obs2.shape
+        prm = tuple(t.detach().contiguous() for t in (w1, b1, lnw, lnb, w_ih, w_hh, b_ih, b_hh, w2, b2))
+        means = torch.empty(rows, dtype=torch.float32, device=obs2.device)
+        x1 = torch.empty(rows, 64, dtype=torch.float32, device=obs2.device)
+        with torch.cuda.device(obs2.device):
+            _lib.check(lib.mapdn_policy_forward_train(obs2.data_ptr(), hid2.data_ptr(), *(t.data_ptr() for t in prm), means.data_ptr(), None,
+                                                      x1.data_ptr(), rows, int(n_agents), o, int(ids), float(eps),
+                                                      torch.cuda.current_stream(obs2.device).cuda_stream))
+        ctx.save_for_backward(obs2, hid2, x1, *prm)
+        ctx.n_agents, ctx.ids, ctx.eps = int(n_agents), int(ids), float(eps)
+        return means
+
+    @staticmethod
+    def backward(ctx, dmeans):
+        from . import _lib
+        lib = _lib.load()
+        obs2, hid2, x1, w1, b1, lnw, lnb, w_ih, w_hh, b_ih, b_hh, w2, b2 = ctx.saved_tensors
+        rows, o = obs2.shape
+        n, dev = ctx.n_agents, obs2.device
+        dm = dmeans.reshape(rows).contiguous()
+        dx1 = torch.empty_like(x1)
+        xn = torch.empty_like(x1)
+        dg = torch.empty(rows, 256, dtype=torch.float32, device=dev)
+        small = torch.empty(512, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            scratch = torch.empty(max(1, lib.mapdn_policy_backward_scratch_floats(rows)), dtype=torch.float32, device=dev)
+            _lib.check(lib.mapdn_policy_backward(dm.data_ptr(), x1.data_ptr(), hid2.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), ctx.eps, w_ih.data_ptr(),
+                                                 w_hh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(), w2.data_ptr(), dx1.data_ptr(), dg.data_ptr(), xn.data_ptr(),
+                                                 small.data_ptr(), scratch.data_ptr(), rows, torch.cuda.current_stream(dev).cuda_stream))
+        dw_ih = _splitk_dw(dg[:, :192], xn)
+        dw_hh = torch.cat((_splitk_dw(dg[:, :128], hid2), _splitk_dw(dg[:, 192:], hid2)), 0)
+        db_ih = small[:192].clone()
+        db_hh = torch.cat((small[:128], small[192:256]))
+        dw1 = torch.empty_like(w1)
+        dw1[:, :o] = _splitk_dw(dx1, obs2)
+        per_agent = dx1.view(-1, n, 64).sum(0)                   # [n, 64]: sum over the batch for every agent
+        if ctx.ids:
+            dw1[:, o:] = per_agent.t()
+        db1 = per_agent.sum(0)
+        return (None, None, None, None, None, dw1, db1, small[256:320], small[320:384], dw_ih, dw_hh, db_ih, db_hh, small[384:448].view(1, 64),
+                small[448:449])
+
+
 class RNNAgent(nn.Module):
     """fc1 -> LayerNorm -> act -> GRUCell -> fc2 (agents/rnn_agent.py:5-32)."""
 
@@ -593,11 +664,29 @@ class DDPGNet(nn.Module):
                 torch.cuda.current_stream(obs.device).cuda_stream))
         return means, torch.full_like(means, math.log(self.args.fixed_policy_std)), hid
 
-    def policy(self, obs: torch.Tensor, last_hid: torch.Tensor):
-        """obs [b, n, o], last_hid [b, n, h] -> means [b, n, a], log_stds, hiddens [b, n, h]"""
+    def _fused_policy_train_ok(self, obs: torch.Tensor, last_hid: torch.Tensor) -> bool:
+        a = self.args
+        if not (torch.is_grad_enabled() and obs.is_cuda and obs.dtype == torch.float32 and last_hid.dtype == torch.float32 and a.shared_params
+                and a.layernorm and a.hid_activation == "relu" and self.hid_dim == 64 and self.act_dim == 1 and not last_hid.requires_grad
+                and not obs.requires_grad and obs.shape[0] * self.n_ >= 4096 and os.environ.get("MAPDN_FUSED_POLICY_TRAIN", "1") != "0"):
+            return False
+        if self._fused_fits is None:
+            from . import _lib
+            self._fused_fits = bool(_lib.load().mapdn_policy_forward_fits(self.obs_dim, self.n_ if a.agent_id else 0))
+        return self._fused_fits
+
+    def policy(self, obs: torch.Tensor, last_hid: torch.Tensor, means_grad_only: bool = False):
+        """obs [b, n, o], last_hid [b, n, h] -> means [b, n, a], log_stds, hiddens [b, n, h].  means_grad_only: the caller differentiates the
+        means alone (the policy loss; the new hidden state is then not returned) — the HIP forward / backward pair of _PolicyTrunk."""
         b, n, o = obs.shape[0], self.n_, self.obs_dim
         if self._fused_policy_ok(obs, last_hid):
             return self._fused_policy(obs, last_hid)
+        if means_grad_only and self._fused_policy_train_ok(obs, last_hid):
+            ag = self.policy_dicts[0]
+            means = _PolicyTrunk.apply(obs.reshape(b * n, o), last_hid.reshape(b * n, -1), n, n if self.args.agent_id else 0, ag.layernorm.eps,
+                                       ag.fc1.weight, ag.fc1.bias, ag.layernorm.weight, ag.layernorm.bias, ag.rnn.weight_ih, ag.rnn.weight_hh,
+                                       ag.rnn.bias_ih, ag.rnn.bias_hh, ag.fc2.weight, ag.fc2.bias).view(b, n, 1)
+            return means, torch.full_like(means, math.log(self.args.fixed_policy_std)), None
         if self.args.shared_params:
             ag = self.policy_dicts[0]
             w = ag.fc1.weight
@@ -749,9 +838,9 @@ class DDPGNet(nn.Module):
         return d2.mean() if valid is None else (d2 * valid.float().view(-1, 1)).sum() / (valid.float().sum().clamp(min=1.0) * d2.shape[1])
 
     # ---- action selection (maddpg.py:81-101 == iddpg.py:60-80; utilities/util.py:52-98) ----------
-    def get_actions(self, state, status, exploration, actions_avail, target=False, last_hid=None):
+    def get_actions(self, state, status, exploration, actions_avail, target=False, last_hid=None, means_grad_only=False):
         net = self.target_net if (target and self.args.target) else self
-        means, log_stds, hiddens = net.policy(state, last_hid)
+        means, log_stds, hiddens = net.policy(state, last_hid, means_grad_only)
         if means.size(-1) > 1:                                   # maddpg.py:85-87 (action_dim > 1 sums over agents)
             means_, log_stds_ = means.sum(dim=1, keepdim=True), log_stds.sum(dim=1, keepdim=True)
         else:
@@ -817,7 +906,7 @@ class DDPGNet(nn.Module):
             (lambda t: (t * valid.float().view(-1, 1)).sum() / (valid.float().sum().clamp(min=1.0) * t.shape[1]))
         policy_loss = value_loss = action_out = None
         if "policy" in want:
-            _, actions_pol, _, action_out, _ = self.get_actions(state, "train", False, avail, False, last_hid)
+            _, actions_pol, _, action_out, _ = self.get_actions(state, "train", False, avail, False, last_hid, means_grad_only=True)
             advantages = self.value(state, actions_pol, own_action_only=True).view(-1, n)
             if self.args.normalize_advantages:
                 advantages = self._adv_batchnorm.to(advantages.device)(advantages)

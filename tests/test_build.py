@@ -63,7 +63,7 @@ def test_eight_ranks_build_once(tmp_path):
     assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
     assert all(o[0].strip() == str(lib) for o in outs)
     calls = log.read_text().split()
-    assert calls.count("link") == 1 and calls.count("cc") == 12, calls          # 4 NR parts + 8 sources (round 6: critic.hip, rollout.hip)
+    assert calls.count("link") == 1 and calls.count("cc") == 13, calls          # 4 NR parts + 9 sources (round 6: critic.hip, rollout.hip, policy_bwd.hip)
     assert not os.path.exists(str(lib) + ".lock")
 
 
