@@ -332,7 +332,7 @@ int mapdn_dense_solve(const double* a, const double* b, double* x, int32_t n, in
  * models/model.py:101-139): fc1 (+ one-hot agent-id column) -> LayerNorm -> ReLU -> GRUCell -> fc2, one launch, inference only.
  * Device pointers, fp32, contiguous: obs [rows, obs_dim] (rows = envs x agents, agent = row % n_agents), hid_in / hid_out
  * [rows, 64], w1 [64, obs_dim + id_dim] (id_dim = n_agents or 0), w_ih / w_hh [192, 64] (torch.nn.GRUCell layout: r, z, n),
- * w2 [1, 64]; means [rows].  Hidden size 64, action_dim 1 (the reference's defaults). */
+ * w2 [1, 64]; means [rows].  Hidden size 64, action_dim 1 (the reference's defaults).  hid_out may be NULL (the new hidden state is not stored). */
 int mapdn_policy_forward(const float* obs, const float* hid_in, const float* w1, const float* b1, const float* ln_g,
                          const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                          const float* w2, const float* b2, float* means, float* hid_out, int32_t rows, int32_t n_agents,

@@ -12,13 +12,14 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "../../include/mapdn.h"
+#include "rowtile.hpp"
 
 namespace mapdn {
 
 constexpr int PH = 64;          // hidden size (args.hid_size of the reference's default.yaml)
-typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 // sum over the 16 lanes of a DPP row (lanes that share lane >> 4)
@@ -164,6 +165,147 @@ k_policy_fwd(const float* __restrict__ obs, const float* __restrict__ hid_in, co
       const float tot = row_sum16(outp[r]);
       if (j == 0 && row < rows) means[row] = tot + bias2;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the same forward with every product taken TRANSPOSED (the weight is the MFMA A operand, the activations the B operand), so
+// that a lane keeps ONE row of the tile from the observation to the action ("A layout", rowtile.hpp: lane (j, g) = row j, features
+// 16 c + 4 g + q): the D registers of x1^T = W1 obs^T and of gates^T = W x^T line up element by element with the row's hidden state,
+// which is loaded once (as B operand AND for the gate arithmetic) and stored as float4; LayerNorm is 16 in-lane adds + two row swaps;
+// no LDS round trip for the activations and no per-element global accesses (the first form issued 16 scalar loads and 16 scalar
+// stores of the hidden state per lane and tile, plus an LDS transposition of x).  Same LDS weight images, same arithmetic per element.
+template <int PT>
+__global__ void __launch_bounds__(PT)
+k_policy_fwd2(const float* __restrict__ obs, const float* __restrict__ hid_in, const float* __restrict__ w1, const float* __restrict__ b1,
+              const float* __restrict__ ln_g, const float* __restrict__ ln_b, const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+              const float* __restrict__ b_ih, const float* __restrict__ b_hh, const float* __restrict__ w2, const float* __restrict__ b2,
+              float* __restrict__ means, float* __restrict__ hid_out, int rows, int n_agents, int o, int ids, float ln_eps, int ids_lds,
+              float* __restrict__ x1_out) {
+  extern __shared__ float sm[];
+  const int KC1 = (o + 15) >> 4;
+  f4* sW1 = (f4*)sm;                                              // [4][KC1][64]
+  f4* sWih = sW1 + (size_t)4 * KC1 * 64;                          // [12][4][64]
+  f4* sWhh = sWih + 12 * 4 * 64;                                  // [12][4][64]
+  float* sW1id = (float*)(sWhh + 12 * 4 * 64);                    // [ids][64]
+  float* sB1 = sW1id + (size_t)(ids_lds ? ids : 0) * PH;
+  float* sG = sB1 + PH; float* sB = sG + PH;
+  float* sBih = sB + PH; float* sBhh = sBih + 3 * PH; float* sW2 = sBhh + 3 * PH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15, in1 = o + ids;
+  for (int i = tid; i < 4 * KC1 * 64; i += PT) {
+    const int l = i & 63, c = (i >> 6) % KC1, nt = (i >> 6) / KC1;
+    f4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int k = 16 * c + 4 * (l >> 4) + q; v[q] = k < o ? w1[(size_t)(16 * nt + (l & 15)) * in1 + k] : 0.0f; }
+    sW1[i] = v;
+  }
+  for (int i = tid; i < 12 * 4 * 64; i += PT) {
+    const int l = i & 63, c = (i >> 6) & 3, nt = i >> 8;
+    const size_t base = (size_t)(16 * nt + (l & 15)) * PH + 16 * c + 4 * (l >> 4);
+    sWih[i] = *(const f4*)(w_ih + base); sWhh[i] = *(const f4*)(w_hh + base);
+  }
+  if (ids_lds) for (int i = tid; i < ids * PH; i += PT) sW1id[i] = w1[(size_t)(i % PH) * in1 + o + i / PH];      // [agent][unit]
+  for (int i = tid; i < PH; i += PT) { sB1[i] = b1[i]; sG[i] = ln_g[i]; sB[i] = ln_b[i]; sW2[i] = w2[i]; }
+  for (int i = tid; i < 3 * PH; i += PT) { sBih[i] = b_ih[i]; sBhh[i] = b_hh[i]; }
+  __syncthreads();
+  const float bias2 = b2[0];
+  const bool even = (o & 1) == 0;
+  const int n_tiles = (rows + 15) >> 4;
+  for (int T = blockIdx.x * (PT / 64) + wave; T < n_tiles; T += gridDim.x * (PT / 64)) {
+    const int row = (T << 4) + j;
+    const bool valid = row < rows;
+    const int rc = valid ? row : rows - 1;
+    // ---- fc1, transposed: x1^T[u][row] = sum_k W1[u][k] obs[row][k]
+    f4 x[4] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
+    const float* ob = obs + (size_t)rc * o;
+    for (int c = 0; c < KC1; ++c) {
+      const int k0 = 16 * c + 4 * g;
+      f4 a;
+      if (even && k0 + 3 < o) {                                   // two 8-byte loads (a row of an even width starts 8-byte aligned)
+        const float2 lo = *(const float2*)(ob + k0), hi = *(const float2*)(ob + k0 + 2);
+        a = f4{lo.x, lo.y, hi.x, hi.y};
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = k0 + q < o ? ob[k0 + q] : 0.0f;
+      }
+      f4 wv[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) wv[nt] = sW1[(size_t)(nt * KC1 + c) * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) x[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][q], a[q], x[nt], 0, 0, 0);
+    }
+    // ---- + bias + one-hot id column; LayerNorm (biased variance, eps inside the root); ReLU
+    const int agent = rc % n_agents;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int u0 = 16 * nt + 4 * g;
+      x[nt] += *(const f4*)(sB1 + u0);
+      if (ids) {
+        if (ids_lds) x[nt] += *(const f4*)(sW1id + (size_t)agent * PH + u0);
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[nt][r] += w1[(size_t)(u0 + r) * in1 + o + agent];
+        }
+      }
+    }
+    if (x1_out && valid) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) *(f4*)(x1_out + (size_t)row * PH + 16 * nt + 4 * g) = x[nt];
+    }
+    ln_stats(x, ln_eps);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const f4 y = x[nt] * *(const f4*)(sG + 16 * nt + 4 * g) + *(const f4*)(sB + 16 * nt + 4 * g);
+      x[nt] = f4{relu_nan(y.x), relu_nan(y.y), relu_nan(y.z), relu_nan(y.w)};
+    }
+    f4 hv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hv[c] = *(const f4*)(hid_in + (size_t)rc * PH + 16 * c + 4 * g);
+    // ---- GRUCell pre-activations, transposed: r, z over [x | h], n_input over x, n_hidden over h
+    f4 aR[4], aZ[4], aI[4], aH[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) aR[nt] = aZ[nt] = aI[nt] = aH[nt] = f4{0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const f4 wir = sWih[((0 + nt) * 4 + c) * 64 + lane], wiz = sWih[((4 + nt) * 4 + c) * 64 + lane], win = sWih[((8 + nt) * 4 + c) * 64 + lane];
+        const f4 whr = sWhh[((0 + nt) * 4 + c) * 64 + lane], whz = sWhh[((4 + nt) * 4 + c) * 64 + lane], whn = sWhh[((8 + nt) * 4 + c) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          aR[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wir[q], x[c][q], aR[nt], 0, 0, 0);
+          aZ[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wiz[q], x[c][q], aZ[nt], 0, 0, 0);
+          aI[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[q], x[c][q], aI[nt], 0, 0, 0);
+          aR[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(whr[q], hv[c][q], aR[nt], 0, 0, 0);
+          aZ[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(whz[q], hv[c][q], aZ[nt], 0, 0, 0);
+          aH[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(whn[q], hv[c][q], aH[nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the scheduler from hoisting all 96 weight loads of the tile)
+      }
+    // ---- gates (torch.nn.GRUCell), new hidden state, fc2
+    float outp = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int u0 = 16 * nt + 4 * g;
+      const f4 bir = *(const f4*)(sBih + u0), biz = *(const f4*)(sBih + PH + u0), bin = *(const f4*)(sBih + 2 * PH + u0);
+      const f4 bhr = *(const f4*)(sBhh + u0), bhz = *(const f4*)(sBhh + PH + u0), bhn = *(const f4*)(sBhh + 2 * PH + u0);
+      const f4 w2v = *(const f4*)(sW2 + u0);
+      f4 hn4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float rg = sigmoidf_(aR[nt][r] + bir[r] + bhr[r]);
+        const float zg = sigmoidf_(aZ[nt][r] + biz[r] + bhz[r]);
+        const float nn = tanhf(fmaf(rg, aH[nt][r] + bhn[r], aI[nt][r] + bin[r]));
+        const float hnew = fmaf(zg, hv[nt][r] - nn, nn);              // (1 - z) n + z h
+        hn4[r] = hnew;
+        outp = fmaf(w2v[r], hnew, outp);
+      }
+      if (hid_out && valid) *(f4*)(hid_out + (size_t)row * PH + u0) = hn4;
+    }
+    const float tot = sum_g(outp);
+    if (g == 0 && valid) means[row] = tot + bias2;
   }
 }
 
@@ -407,18 +549,20 @@ static int policy_forward_launch(const float* obs, const float* hid_in, const fl
   size_t lds = 0;
   if (!policy_geometry(obs_dim, id_dim, pt, ids_lds, lds)) return MAPDN_E_INVALID;   // callers ask mapdn_policy_forward_fits first
   // (per call, not once per process: the attribute belongs to the current device)
-  const void* fn = pt == 512 ? (const void*)k_policy_fwd<512> : (const void*)k_policy_fwd<256>;
+  static const bool v1 = [] { const char* e = getenv("MAPDN_POLICY_FWD_V1"); return e && atoi(e) != 0; }();   // A/B: the rounds-2-5 form
+  const void* fn = v1 ? (pt == 512 ? (const void*)k_policy_fwd<512> : (const void*)k_policy_fwd<256>)
+                      : (pt == 512 ? (const void*)k_policy_fwd2<512> : (const void*)k_policy_fwd2<256>);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MAPDN_E_HIP;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int tiles = (rows + 15) / 16;
   const int blocks = std::min((tiles + pt / 64 - 1) / (pt / 64), cus);   // one resident workgroup per CU (its LDS is the parameter set)
-  if (pt == 512)
-    hipLaunchKernelGGL(k_policy_fwd<512>, dim3(blocks), dim3(512), lds, (hipStream_t)stream, obs, hid_in, w1, b1, ln_g, ln_b, w_ih, w_hh,
-                       b_ih, b_hh, w2, b2, means, hid_out, rows, n_agents, obs_dim, id_dim, ln_eps, ids_lds, x1_out);
-  else
-    hipLaunchKernelGGL(k_policy_fwd<256>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, obs, hid_in, w1, b1, ln_g, ln_b, w_ih, w_hh,
-                       b_ih, b_hh, w2, b2, means, hid_out, rows, n_agents, obs_dim, id_dim, ln_eps, ids_lds, x1_out);
+#define MAPDN_POLICY_LAUNCH(K, P)                                                                                                         \
+  hipLaunchKernelGGL((K<P>), dim3(blocks), dim3(P), lds, (hipStream_t)stream, obs, hid_in, w1, b1, ln_g, ln_b, w_ih, w_hh, b_ih, b_hh, w2, b2, \
+                     means, hid_out, rows, n_agents, obs_dim, id_dim, ln_eps, ids_lds, x1_out)
+  if (v1) { if (pt == 512) MAPDN_POLICY_LAUNCH(k_policy_fwd, 512); else MAPDN_POLICY_LAUNCH(k_policy_fwd, 256); }
+  else { if (pt == 512) MAPDN_POLICY_LAUNCH(k_policy_fwd2, 512); else MAPDN_POLICY_LAUNCH(k_policy_fwd2, 256); }
+#undef MAPDN_POLICY_LAUNCH
   return hipGetLastError() == hipSuccess ? MAPDN_OK : MAPDN_E_HIP;
 }
 
@@ -426,7 +570,6 @@ extern "C" int mapdn_policy_forward(const float* obs, const float* hid_in, const
                                     const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                                     const float* w2, const float* b2, float* means, float* hid_out, int32_t rows, int32_t n_agents,
                                     int32_t obs_dim, int32_t id_dim, float ln_eps, void* stream) {
-  if (!hid_out) return MAPDN_E_INVALID;
   return policy_forward_launch(obs, hid_in, w1, b1, ln_g, ln_b, w_ih, w_hh, b_ih, b_hh, w2, b2, means, hid_out, nullptr, rows, n_agents, obs_dim,
                                id_dim, ln_eps, stream);
 }

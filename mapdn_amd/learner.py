@@ -643,13 +643,13 @@ class DDPGNet(nn.Module):
             self._fused_fits = bool(_lib.load().mapdn_policy_forward_fits(self.obs_dim, self.n_ if a.agent_id else 0))
         return self._fused_fits
 
-    def _fused_policy(self, obs: torch.Tensor, last_hid: torch.Tensor):
+    def _fused_policy(self, obs: torch.Tensor, last_hid: torch.Tensor, need_hidden: bool = True):
         from . import _lib
         ag = self.policy_dicts[0]
         b, n, o = obs.shape[0], self.n_, self.obs_dim
         obs_c, hid_c = obs.contiguous(), last_hid.contiguous()
         means = torch.empty(b, n, 1, dtype=torch.float32, device=obs.device)
-        hid = torch.empty(b, n, self.hid_dim, dtype=torch.float32, device=obs.device)
+        hid = torch.empty(b, n, self.hid_dim, dtype=torch.float32, device=obs.device) if need_hidden else None
         keep = []                                  # contiguous views stay referenced until the launch is enqueued
 
         def P(t):
@@ -660,7 +660,7 @@ class DDPGNet(nn.Module):
             _lib.check(_lib.load().mapdn_policy_forward(
                 obs_c.data_ptr(), hid_c.data_ptr(), P(ag.fc1.weight), P(ag.fc1.bias), P(ag.layernorm.weight), P(ag.layernorm.bias),
                 P(ag.rnn.weight_ih), P(ag.rnn.weight_hh), P(ag.rnn.bias_ih), P(ag.rnn.bias_hh), P(ag.fc2.weight), P(ag.fc2.bias),
-                means.data_ptr(), hid.data_ptr(), b * n, n, o, ids, float(ag.layernorm.eps),
+                means.data_ptr(), hid.data_ptr() if hid is not None else None, b * n, n, o, ids, float(ag.layernorm.eps),
                 torch.cuda.current_stream(obs.device).cuda_stream))
         return means, torch.full_like(means, math.log(self.args.fixed_policy_std)), hid
 
@@ -680,7 +680,7 @@ class DDPGNet(nn.Module):
         means alone (the policy loss; the new hidden state is then not returned) — the HIP forward / backward pair of _PolicyTrunk."""
         b, n, o = obs.shape[0], self.n_, self.obs_dim
         if self._fused_policy_ok(obs, last_hid):
-            return self._fused_policy(obs, last_hid)
+            return self._fused_policy(obs, last_hid, need_hidden=not means_grad_only)
         if means_grad_only and self._fused_policy_train_ok(obs, last_hid):
             ag = self.policy_dicts[0]
             means = _PolicyTrunk.apply(obs.reshape(b * n, o), last_hid.reshape(b * n, -1), n, n if self.args.agent_id else 0, ag.layernorm.eps,
@@ -1106,7 +1106,8 @@ class PGTrainer:
         with torch.no_grad():
             for lo in range(0, n_ring, chunk):
                 hi = min(lo + chunk, n_ring)
-                _, na, _, _, _ = net.get_actions(st["next_state"][lo:hi], "train", False, st["action_avail"][lo:hi], not a.double_q, st["hid"][lo:hi])
+                _, na, _, _, _ = net.get_actions(st["next_state"][lo:hi], "train", False, st["action_avail"][lo:hi], not a.double_q, st["hid"][lo:hi],
+                                                 means_grad_only=True)          # (only the actions are read: the new hidden state is not stored)
                 cache[lo:hi] = na
                 if values is not None:
                     values[lo:hi] = net.target_net.value(st["next_state"][lo:hi], na).view(-1, net.n_)
