@@ -295,9 +295,9 @@ k_policy_fwd2(const float* __restrict__ obs, const float* __restrict__ hid_in, c
       f4 hn4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float rg = sigmoidf_(aR[nt][r] + bir[r] + bhr[r]);
-        const float zg = sigmoidf_(aZ[nt][r] + biz[r] + bhz[r]);
-        const float nn = tanhf(fmaf(rg, aH[nt][r] + bhn[r], aI[nt][r] + bin[r]));
+        const float rg = fast_sigmoid(aR[nt][r] + bir[r] + bhr[r]);
+        const float zg = fast_sigmoid(aZ[nt][r] + biz[r] + bhz[r]);
+        const float nn = fast_tanh(fmaf(rg, aH[nt][r] + bhn[r], aI[nt][r] + bin[r]));
         const float hnew = fmaf(zg, hv[nt][r] - nn, nn);              // (1 - z) n + z h
         hn4[r] = hnew;
         outp = fmaf(w2v[r], hnew, outp);

@@ -34,8 +34,6 @@ struct PolBwdArgs {
   float* dx1; float* dG; float* xn_out; float* partial; long rows;
 };
 
-__device__ __forceinline__ float sigmoid_(float v) { return 1.0f / (1.0f + __expf(-v)); }
-
 __global__ void __launch_bounds__(256)
 k_policy_bwd(PolBwdArgs p) {
   extern __shared__ float sm[];
@@ -112,10 +110,10 @@ k_policy_bwd(PolBwdArgs p) {
       const f4 w2v = *(const f4*)(sP + 512 + u0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float rg = sigmoid_(aR[nt][r] + bir[r] + bhr[r]);
-        const float zg = sigmoid_(aZ[nt][r] + biz[r] + bhz[r]);
+        const float rg = fast_sigmoid(aR[nt][r] + bir[r] + bhr[r]);
+        const float zg = fast_sigmoid(aZ[nt][r] + biz[r] + bhz[r]);
         const float hnb = aH[nt][r] + bhn[r];
-        const float ng = tanhf(fmaf(rg, hnb, aI[nt][r] + bin[r]));
+        const float ng = fast_tanh(fmaf(rg, hnb, aI[nt][r] + bin[r]));
         const float hu = hv[nt][r];
         const float hnew = fmaf(zg, hu - ng, ng);                 // (1 - z) n + z h
         aw2[nt][r] = fmaf(hnew, dm, aw2[nt][r]);

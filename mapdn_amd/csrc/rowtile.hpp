@@ -35,6 +35,11 @@ __device__ __forceinline__ float sum_j(float v) {
 }
 __device__ __forceinline__ float relu_nan(float o) { return o > 0.0f ? o : (o != o ? o : 0.0f); }      // torch.relu keeps NaN
 __device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
+// GRU gate non-linearities on the hardware transcendentals: v_exp_f32 + v_rcp_f32 (each ~1 ulp) instead of the library's tanhf (~40
+// instructions) and a full-precision division (~10): absolute error ~2e-7, the size of one f32 rounding of the gate pre-activation —
+// the gate arithmetic was 45 % of the policy kernels' VALU instructions, and those bound them (SQ counters, profiles/r06_*)
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ float fast_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v) + 1.0f); }
 
 // LayerNorm statistics of the lane's row; xa becomes xhat = (x - mean) rstd
 __device__ __forceinline__ float ln_stats(f4 (&xa)[4], float eps) {
