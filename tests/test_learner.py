@@ -495,3 +495,28 @@ def test_relu_dot64_kernels_match_pytorch(rows):
     pre.grad = None
     v2 = _ReluDot64.apply(pre, w, b); v2.backward(dv)
     assert torch.equal(v2.detach(), got[0]) and torch.equal(pre.grad, got[1])
+
+
+def test_splitk_weight_gradient_helper_on_column_slices():
+    """round 6: learner._splitk_dw (the K = rows products behind _PolicyTrunk / tall_linear_w): dy^T x in blocks, dy possibly a COLUMN
+    SLICE of a wider tensor (the GRU's gate-gradient tensor [rows, 256] is read as [:, :192], [:, :128], [:, 192:])"""
+    from mapdn_amd.learner import _splitk_dw
+    g = torch.Generator().manual_seed(0)
+    rows = 1000
+    dg = torch.randn(rows, 256, generator=g, dtype=torch.float64)
+    x = torch.randn(rows, 64, generator=g, dtype=torch.float64)
+    for sl in (slice(0, 192), slice(0, 128), slice(192, 256), slice(0, 256)):
+        for blk in (64, 128, 1000, 4096):
+            got = _splitk_dw(dg[:, sl], x, blk=blk)
+            assert torch.allclose(got, dg[:, sl].t() @ x, rtol=0, atol=1e-10), (sl, blk)
+
+
+def test_policy_means_grad_only_falls_back_to_the_modules_on_cpu():
+    """DDPGNet.policy(..., means_grad_only=True) without a GPU is the stock route: same means, hidden state returned"""
+    torch.manual_seed(0)
+    args = make_alg_args(3, 5, 1)
+    net = DDPGNet(args, "maddpg")
+    obs, hid = torch.randn(7, 3, 5), torch.randn(7, 3, 64)
+    m1, s1, h1 = net.policy(obs, hid)
+    m2, s2, h2 = net.policy(obs, hid, means_grad_only=True)
+    assert torch.equal(m1, m2) and torch.equal(h1, h2) and torch.equal(s1, s2)
