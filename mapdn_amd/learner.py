@@ -419,9 +419,13 @@ class _CriticHeadMSE(torch.autograd.Function):
                 gs[:4096].view(64, 64), gs[4224:4288], gs[4288:4352].view(1, 64), gs[4352:4353], None, None, None)
 
 
-def critic_head_ok(cr: "MLPCritic", x: torch.Tensor, rows: int) -> bool:
-    """the one-launch critic head covers the reference's default critic (LayerNorm, ReLU, hidden size 64, one output) in fp32 on the GPU"""
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[-1] == 64 and rows >= 1024 and rows < 2 ** 31 and cr.use_ln
+HEAD_MAX_FORMED_N = 88      # formed rows keep one [n][64] LDS accumulator per wavefront: n <= 88 fits the 160 KB of a CU with four of them
+
+
+def critic_head_ok(cr: "MLPCritic", x: torch.Tensor, rows: int, formed_n: int = 0) -> bool:
+    """the one-launch critic head covers the reference's default critic (LayerNorm, ReLU, hidden size 64, one output) in fp32 on the GPU
+    (formed_n: the number of agents when the rows are formed as base[b] + per_n[i])"""
+    return (formed_n <= HEAD_MAX_FORMED_N and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[-1] == 64 and rows >= 1024 and rows < 2 ** 31 and cr.use_ln
             and cr.act is F.relu and cr.layernorm.elementwise_affine and cr.layernorm.bias is not None and cr.fc2.in_features == 64
             and cr.fc2.out_features == 64 and cr.fc2.bias is not None and cr.fc3.out_features == 1 and cr.fc3.bias is not None
             and cr.fc2.weight.dtype == torch.float32 and os.environ.get("MAPDN_FUSED_HEAD", "1") != "0")
@@ -782,7 +786,7 @@ class DDPGNet(nn.Module):
 
         if self.args.shared_params:
             cr = self.value_dicts[0]
-            if ids and cr.use_ln and own is not None and a == 1 and own_action_only and critic_head_ok(cr, obs_all.new_empty(0, 64), b * n):
+            if ids and cr.use_ln and own is not None and a == 1 and own_action_only and critic_head_ok(cr, obs_all.new_empty(0, 64), b * n, n):
                 # the policy update (maddpg.py:52-58, 103-125): value = the head on base[b] + id_column[i] (the own-action term is zero in
                 # value), gradient = d/d act[b, i] only, from the kernel; the critic's own parameters are not differentiated
                 w = cr.fc1.weight.detach()
@@ -797,7 +801,7 @@ class DDPGNet(nn.Module):
                 # LayerNorm + ReLU straight from the two small operands, the [b, n, h] sum is never written
                 w = cr.fc1.weight
                 base = tall_linear_w(obs_all, w[:, :n * o], cr.fc1.bias) + tall_linear_w(act_all.detach(), w[:, n * o + ids:])
-                if critic_head_ok(cr, base, b * n):
+                if critic_head_ok(cr, base, b * n, n):
                     return critic_head(cr, base, w[:, n * o:n * o + n].t()).view(b, n, 1)
                 xn = layernorm_act_bc(cr.layernorm, cr.act, base, w[:, n * o:n * o + n].t())
                 if xn is not None:
@@ -823,7 +827,7 @@ class DDPGNet(nn.Module):
                 per_n = w[:, n * o:n * o + n].t()
             elif self.alg == "iddpg":
                 x = self._independent_first_layer(cr, obs, act).reshape(b * n, -1)
-            if x is not None and critic_head_ok(cr, x, b * n):
+            if x is not None and critic_head_ok(cr, x, b * n, n if per_n is not None else 0):
                 if valid is None:
                     scale, wrow = x.new_full((1,), 1.0 / (b * n)), None
                 else:

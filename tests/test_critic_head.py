@@ -68,7 +68,7 @@ def test_head_on_read_rows_matches_the_modules(rows):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nb,n", [(27, 38), (700, 38), (4096, 6), (9001, 22), (70000, 3)])
+@pytest.mark.parametrize("nb,n", [(27, 38), (700, 38), (4096, 6), (9001, 22), (70000, 3), (3000, 50), (600, 88), (200, 1)])
 def test_head_on_formed_rows_matches_the_modules(nb, n):
     """x[b, i] = base[b] + per_n[i] never exists: values, dbase (summed over the agents IN the kernel), dper_n (summed over the batch) and
     the parameter gradients against autograd through the materialised sum"""
@@ -206,3 +206,26 @@ def test_fused_value_loss_matches_the_modules(nb, n, formed, weighted):
         assert a.shape == b.shape
         err, ref_max = float((a.double() - b).abs().max()), float(b.abs().max())
         assert err <= 2e-4 * ref_max, (i, err, ref_max)                  # (the weights are 1 / rows: gradients of order 1e-6 — relative bar)
+
+
+@pytest.mark.gpu
+def test_many_agent_nets_fall_back_to_the_unfused_route():
+    """formed rows keep an [n][64] accumulator per wavefront in LDS: beyond 88 agents the central critic takes the round-5 route (and the
+    library itself refuses such a launch by code instead of overrunning LDS)"""
+    from mapdn_amd import _lib
+    from mapdn_amd.learner import HEAD_MAX_FORMED_N, critic_head_ok
+    dev = torch.device("cuda:0")
+    cr = _critic(dev, 1)
+    base = torch.randn(64, 64, device=dev)
+    assert critic_head_ok(cr, base, 64 * HEAD_MAX_FORMED_N, HEAD_MAX_FORMED_N) and not critic_head_ok(cr, base, 64 * 120, 120)
+    n, rows = 200, 200 * 64
+    t = torch.zeros(max(rows, 64 * 64) * 64, device=dev)
+    p = t.data_ptr()
+    lib = _lib.load()
+    scratch = torch.zeros(max(1, lib.mapdn_critic_head_scratch_floats(rows, n, 1)), device=dev)
+    assert lib.mapdn_critic_head_backward(p, p, p, n, p, p, 1e-5, p, p, p, p, p, p, scratch.data_ptr(), rows, 1, None) == -1
+    args = make_alg_args(120, 4, 1, reward_normalisation=False)
+    net = DDPGNet(args, "maddpg").to(dev)
+    v = net.value(torch.randn(32, 120, 4, device=dev), torch.randn(32, 120, 1, device=dev))
+    v.mean().backward()
+    assert v.shape == (32, 120, 1) and net.value_dicts[0].fc2.weight.grad is not None
