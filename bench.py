@@ -482,6 +482,41 @@ def main():
                    "phase_seconds": last.get("phase_seconds"), "sampled_transitions_per_env_step": last["sampled_transitions_per_env_step"],
                    "hbm_gb": last["hbm_gb"], "wall_seconds_total": time.perf_counter() - t_e2e,
                    "env_share_note": "rollout_and_host is where step()+get_obs()+policy forward live: the env is a single-digit share of this loop"}
+            # the MFMA-bound kernels of that loop, timed on their own at the loop's size (32 steps x 8192 envs x 38 agents = 9.96 M rows of 64):
+            # the critic head (csrc/critic.hip) forward and backward against the dense f32 MFMA peak (157.3 TFLOP/s)
+            try:
+                from mapdn_amd.learner import MLPCritic, critic_head, make_alg_args
+                nb_, n_ = 32 * 8192, 38
+                cr = MLPCritic(7, 1, make_alg_args(3, 5, 1)).to(dev)
+                base = torch.randn(nb_, 64, device=dev, requires_grad=True); pern = torch.randn(n_, 64, device=dev, requires_grad=True)
+                dv = torch.randn(nb_ * n_, 1, device=dev)
+
+                def _ms(f, reps=5):
+                    for _ in range(2):
+                        f()
+                    a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a_.record()
+                    for _ in range(reps):
+                        f()
+                    b_.record(); torch.cuda.synchronize(dev)
+                    return a_.elapsed_time(b_) / reps
+
+                def _f():
+                    with torch.no_grad():
+                        critic_head(cr, base, pern)
+
+                def _fb():
+                    critic_head(cr, base, pern).backward(dv)
+                tf, tfb = _ms(_f), _ms(_fb)
+                gf = nb_ * n_ * 64 * 64 * 2 / 1e9
+                e2e["critic_head"] = {"rows": nb_ * n_, "forward_ms": tf, "backward_ms": tfb - tf, "peak_tflops_f32_mfma": 157.3,
+                                      "forward": {"products_per_row": 1, "achieved_tflops": gf / tf, "frac": gf / tf / 157.3},
+                                      "backward": {"products_per_row": 3, "achieved_tflops": 3 * gf / (tfb - tf), "frac": 3 * gf / (tfb - tf) / 157.3},
+                                      "note": "v_mfma_f32_16x16x4_f32; the backward recomputes the forward product (3 of 64 x 64 per row); counters: "
+                                              "profiles/r06_final_critic_head_mfma_counters.txt"}
+                del base, pern, dv, cr
+            except Exception as exc:      # noqa: BLE001
+                e2e["critic_head"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         except Exception as exc:          # noqa: BLE001 — the headline line must still be printed
             e2e = {"error": f"{type(exc).__name__}: {exc}"[:500]}
         finally:
