@@ -48,7 +48,9 @@ def test_learner_rccl_first_contact_at_world_size_one(alg):
 
 @pytest.mark.gpu
 def test_eight_rank_learner_preflight_keeps_replicas_identical():
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29613",
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()          # a free port, not a fixed one
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
            CLI, "--backend", "gloo", "--alg", "maddpg"] + SMALL
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=_clean_env())
     assert r.returncode == 0, r.stderr[-4000:]
