@@ -24,6 +24,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -44,12 +46,27 @@ class TransReplayBuffer:
         if self.size <= 0:
             raise ValueError("replay buffer size must be positive")
         self.device = torch.device(device) if device is not None else None
-        self.store: Dict[str, torch.Tensor] = {}
+        self._store: Dict[str, torch.Tensor] = {}
+        self._side = None       # side stream of the asynchronous insertion (see _copy_in_one_launch) and the event of its last copy
+        self._pending = None
         self._tail = 0          # ring position of the oldest entry
         self._len = 0
 
     def __len__(self) -> int:
         return self._len
+
+    @property
+    def store(self) -> Dict[str, torch.Tensor]:
+        """field -> ring tensor [size (+ window), ...].  Reading it makes the current stream wait for an insertion that is still in
+        flight on the side stream (sync())."""
+        self.sync()
+        return self._store
+
+    def sync(self) -> None:
+        """the current stream waits for the last asynchronous insertion (a no-op when none is pending)"""
+        if self._pending is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._pending)
+            self._pending = None
 
     @property
     def buffer(self):
@@ -60,16 +77,16 @@ class TransReplayBuffer:
     def _allocate(self, trans: Batch) -> None:
         for k, v in trans.items():
             dev = self.device if self.device is not None else v.device
-            self.store[k] = torch.empty((self.size + self.window,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev)
+            self._store[k] = torch.empty((self.size + self.window,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev)
         if self.device is None:
-            self.device = next(iter(self.store.values())).device
+            self.device = next(iter(self._store.values())).device
 
     def add_experience(self, trans: Batch) -> None:
         """trans[field]: [B, ...] — B transitions appended in env order (replay_buffer.py:25-29)."""
-        if not self.store:
+        if not self._store:
             self._allocate(trans)
-        if trans.keys() != self.store.keys():
-            raise KeyError(f"transition fields {sorted(trans)} != buffer fields {sorted(self.store)}")
+        if trans.keys() != {k for k in self._store if not k.endswith("_cached")}:
+            raise KeyError(f"transition fields {sorted(trans)} != buffer fields {sorted(self._store)}")
         B = next(iter(trans.values())).shape[0]
         skip = max(0, B - self.size)            # more than a buffer-full at once: only the newest survive
         n = B - skip
@@ -79,7 +96,7 @@ class TransReplayBuffer:
         for k, v in trans.items():
             if v.shape[0] != B:
                 raise ValueError(f"field {k}: leading dimension {v.shape[0]} != {B}")
-            dst = self.store[k]
+            dst = self._store[k]
             pieces.append((dst[head:head + first], v[skip:skip + first]))
             if n > first:
                 pieces.append((dst[0:n - first], v[skip + first:B]))
@@ -91,6 +108,7 @@ class TransReplayBuffer:
                     m = min(n - first, self.window)
                     pieces.append((dst[self.size:self.size + m], v[skip + first:skip + first + m]))
         if not self._copy_in_one_launch(pieces):
+            self.sync()
             for d, s_ in pieces:
                 d.copy_(s_)
         overflow = max(0, self._len + n - self.size)
@@ -100,7 +118,6 @@ class TransReplayBuffer:
     def _copy_in_one_launch(self, pieces) -> bool:
         """all pieces of one insertion as ONE HIP launch (libmapdn_hip.so: mapdn_copy_segments) instead of ~20 copy launches — when every
         piece is a contiguous same-dtype device-to-device copy of 16-byte granularity (the batched env's fields are); else False."""
-        import os
         if not pieces or len(pieces) > 48 or os.environ.get("MAPDN_FUSED_ROLLOUT", "1") == "0":
             return False
         dev = pieces[0][0].device
@@ -122,7 +139,23 @@ class TransReplayBuffer:
         dp = (C.c_void_p * n)(*[d.data_ptr() for d, _ in pieces])
         nb = (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in pieces])
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().mapdn_copy_segments(sp, dp, nb, n, torch.cuda.current_stream(dev).cuda_stream))
+            if os.environ.get("MAPDN_REPLAY_ASYNC", "1") != "0":
+                # the copy (0.6 GB per step of the 322-bus shard: HBM-bound) runs on a SIDE stream, under the next step's policy forward and
+                # power flow (MFMA / latency-bound): it starts after everything enqueued so far (the producers of the sources; earlier
+                # readers of the ring slots it overwrites), and whoever reads the ring next waits for it (the `store` property, get_batch)
+                main = torch.cuda.current_stream(dev)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dev)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self._side.wait_event(ev)
+                _lib.check(_lib.load().mapdn_copy_segments(sp, dp, nb, n, self._side.cuda_stream))
+                for t in srcs:
+                    t.record_stream(self._side)        # (the allocator must not hand a source's memory out again before the copy has read it)
+                self._pending = torch.cuda.Event()
+                self._pending.record(self._side)
+            else:
+                _lib.check(_lib.load().mapdn_copy_segments(sp, dp, nb, n, torch.cuda.current_stream(dev).cuda_stream))
         return True
 
     def get_single(self, index: int) -> Batch:

@@ -60,7 +60,8 @@ def test_replay_insertion_in_one_launch_fills_the_same_ring(monkeypatch):
     B, n, o = 64, 6, 26
 
     def run(flag):
-        monkeypatch.setenv("MAPDN_FUSED_ROLLOUT", flag)
+        monkeypatch.setenv("MAPDN_FUSED_ROLLOUT", flag[0])
+        monkeypatch.setenv("MAPDN_REPLAY_ASYNC", flag[1])
         g = torch.Generator(device="cpu").manual_seed(1)
         rb = TransReplayBuffer(5 * B + 32, device=dev, window=2 * B)             # not a multiple of B: insertions wrap mid-batch
         for t in range(13):
@@ -70,11 +71,12 @@ def test_replay_insertion_in_one_launch_fills_the_same_ring(monkeypatch):
             rb.add_experience(tr)
         torch.cuda.synchronize()
         return {k: v.clone() for k, v in rb.store.items()}, len(rb)
-    a, la = run("1")
-    b, lb = run("0")
-    assert la == lb
-    for k in a:
-        assert torch.equal(a[k][:5 * B + 32], b[k][:5 * B + 32]) and torch.equal(a[k][5 * B + 32:], b[k][5 * B + 32:]), k
+    b, lb = run("00")
+    for flags in ("11", "10"):                                    # one launch on a side stream (round 6) / on the current stream
+        a, la = run(flags)
+        assert la == lb
+        for k in a:
+            assert torch.equal(a[k][:5 * B + 32], b[k][:5 * B + 32]) and torch.equal(a[k][5 * B + 32:], b[k][5 * B + 32:]), (flags, k)
 
 
 @pytest.mark.gpu
@@ -89,8 +91,9 @@ def test_training_episode_with_and_without_the_fused_glue(alg, monkeypatch):
     dev = torch.device("cuda:0")
     net, prof = make_case("case33")
 
-    def run(flag):
+    def run(flag, async_insert="1"):
         monkeypatch.setenv("MAPDN_FUSED_ROLLOUT", flag)
+        monkeypatch.setenv("MAPDN_REPLAY_ASYNC", async_insert)
         torch.manual_seed(5); np.random.seed(5)
         env = VoltageControlBatch(net, prof, dict(episode_limit=24, action_scale=0.8, action_bias=0.0, voltage_barrier_type="bowl", seed=0),
                                   n_envs=64, device=dev, copy=True)
@@ -104,7 +107,8 @@ def test_training_episode_with_and_without_the_fused_glue(alg, monkeypatch):
         return {k: v.clone() for k, v in tr.behaviour_net.state_dict().items()}, stat
     a, sa = run("1")
     b, sb = run("0")
+    c, _ = run("1", async_insert="0")
     for k in a:
-        assert torch.equal(a[k], b[k]), k
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
     for k in sb:
         assert abs(sa[k] - sb[k]) <= 1e-11 * max(1.0, abs(sb[k])), k
