@@ -397,7 +397,7 @@ int mapdn_relu_dot64_backward(const float* dv, const float* pre, const float* w,
  *   dx      [rows][64]                       (x read)   — or dbase [rows / n][64] = sum of dx over every group of n rows (x formed);
  *   grads   [4416 (+ n * 64)] when param_grads != 0 or x is formed:  dW2 [64][64] | dgamma | dbeta | db2 | dw3 [64 each] | db3 [1] + pad to
  *           4416 | dper_n [n][64] (formed rows only; with param_grads == 0 only dper_n is written);
- *   scratch mapdn_critic_head_scratch_floats(rows, n, formed) floats (per-wavefront partial sums, reduced in a fixed order: deterministic).
+ *   scratch mapdn_critic_head_scratch_floats(rows, n, formed) floats (per-workgroup partial sums — the wavefronts of a workgroup are summed through LDS —, reduced in a fixed order: deterministic).
  * _backward_dot: only dact[row] = dx[row] . dot_w[row % n] (dot_w [n][64]; n = 1 when x is read) — the policy update through the
  * central critic, whose own-action column of fc1 (models/maddpg.py:52-58) is the only gradient path back to the policy. */
 int mapdn_critic_head_forward(const float* x, const float* per_n, int32_t n, const float* gamma, const float* beta, float eps,

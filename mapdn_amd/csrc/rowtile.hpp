@@ -11,7 +11,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
 constexpr int HS = 68;                 // row stride (floats) of a 16 x 64 LDS staging tile: C-layout reads hit 64 distinct banks
-constexpr int HP = 4416;               // floats of parameter-gradient partials per wavefront: dW2 4096 | dgamma | dbeta | db2 | dw3 | db3 + pad
+constexpr int HP = 4416;               // floats of parameter-gradient partials per wavefront / workgroup: dW2 4096 | dgamma | dbeta | db2 | dw3 | db3 + pad
 
 struct HeadArgs {
   const float* x;                      // [rows][64] — or base [rows / n][64] when per_n != nullptr
