@@ -730,8 +730,11 @@ class DDPGNet(nn.Module):
         ids = n if self.args.agent_id else 0
         w = cr.fc1.weight
         if _tall_ok(obs, b * n, w):
-            x = _TallLinear.apply(obs.reshape(b * n, o), w[:, :o], cr.fc1.bias).view(b, n, -1)
-            x = x + _TallLinear.apply(act.reshape(b * n, -1), w[:, o + ids:], None).view(b, n, -1)
+            x = _TallLinear.apply(obs.reshape(b * n, o), w[:, :o], cr.fc1.bias)
+            if self.act_dim == 1:        # a one-column product is an outer product: one fused multiply-add pass instead of a GEMM + an add
+                x = torch.addcmul(x, act.reshape(b * n, 1), w[:, o + ids:].t()).view(b, n, -1)
+            else:
+                x = (x + _TallLinear.apply(act.reshape(b * n, -1), w[:, o + ids:], None)).view(b, n, -1)
         else:
             x = F.linear(obs, w[:, :o], cr.fc1.bias) + F.linear(act, w[:, o + ids:])
         if ids:
