@@ -229,3 +229,33 @@ def test_many_agent_nets_fall_back_to_the_unfused_route():
     v = net.value(torch.randn(32, 120, 4, device=dev), torch.randn(32, 120, 1, device=dev))
     v.mean().backward()
     assert v.shape == (32, 120, 1) and net.value_dicts[0].fc2.weight.grad is not None
+
+
+@pytest.mark.gpu
+def test_head_at_the_end_to_end_size_is_the_sum_of_its_halves():
+    """BASELINE configs[4]'s per-GPU batch (32 steps x 8192 envs x 38 agents = 9 961 472 rows, the size bench.py times): a size-independent
+    property instead of an oracle — per-row arithmetic does not depend on the launch shape, so v and dbase of the full batch are
+    BIT-identical to those of its two halves, and the parameter gradients are their sum to f32 summation order."""
+    from mapdn_amd.learner import critic_head
+    dev = torch.device("cuda:0")
+    nb, n = 32 * 8192, 38
+    cr = _critic(dev, 7)
+    prm = [dict(cr.named_parameters())[k] for k in HEAD_PARAMS]
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    base = torch.randn(nb, 64, device=dev, generator=g).requires_grad_(True)
+    pern = (0.7 * torch.randn(n, 64, device=dev, generator=g)).requires_grad_(True)
+    dv = torch.randn(nb * n, 1, device=dev, generator=g) / (nb * n)
+    v = critic_head(cr, base, pern)
+    full = torch.autograd.grad(v, [base, pern] + prm, dv)
+    h = nb // 2
+    parts = []
+    for lo, hi in ((0, h), (h, nb)):
+        b2 = base.detach()[lo:hi].clone().requires_grad_(True)
+        vv = critic_head(cr, b2, pern)
+        assert torch.equal(vv, v[lo * n:hi * n])
+        parts.append(torch.autograd.grad(vv, [b2, pern] + prm, dv[lo * n:hi * n]))
+    assert torch.equal(torch.cat((parts[0][0], parts[1][0])), full[0])                        # dbase: row-local, bit-identical
+    for a, b, c in zip(full[1:], parts[0][1:], parts[1][1:]):
+        ref = b.double() + c.double()
+        assert float((a.double() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1e-12)
+    assert torch.isfinite(v).all()

@@ -71,3 +71,28 @@ def test_policy_loss_gradients_with_and_without_the_fused_trunk(alg, monkeypatch
     assert torch.allclose(res["1"][2], res["0"][2], rtol=1e-4, atol=1e-5)
     for a, b in zip(res["1"][1], res["0"][1]):
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-6), ((a - b).abs().max().item(), b.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_policy_trunk_at_two_million_rows_is_the_sum_of_its_halves():
+    """a size-independent property at a batch far beyond what the float64 modules can replay quickly (65 536 x 38 = 2.5 M rows of the 322-bus
+    shape): means of the full batch are bit-identical to those of its halves, parameter gradients their sum to f32 summation order"""
+    dev = torch.device("cuda:0")
+    n, o, b = 38, 82, 65536
+    torch.manual_seed(1)
+    net = DDPGNet(make_alg_args(n, o, 1), "maddpg").to(dev)
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    obs = torch.randn(b, n, o, device=dev, generator=g)
+    hid = 0.5 * torch.randn(b, n, 64, device=dev, generator=g)
+    dm = torch.randn(b, n, 1, device=dev, generator=g) / (b * n)
+    params = [p for _, p in net.policy_dicts.named_parameters()]
+    means, _, _ = net.policy(obs, hid, means_grad_only=True)
+    full = torch.autograd.grad(means, params, dm)
+    parts = []
+    for lo, hi in ((0, b // 2), (b // 2, b)):
+        m, _, _ = net.policy(obs[lo:hi], hid[lo:hi], means_grad_only=True)
+        assert torch.equal(m, means[lo:hi])
+        parts.append(torch.autograd.grad(m, params, dm[lo:hi]))
+    for a, x, y in zip(full, parts[0], parts[1]):
+        ref = x.double() + y.double()
+        assert float((a.double() - ref).abs().max()) <= 3e-5 * max(float(ref.abs().max()), 1e-12)
