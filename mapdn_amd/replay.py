@@ -82,7 +82,9 @@ class TransReplayBuffer:
             self.device = next(iter(self._store.values())).device
 
     def add_experience(self, trans: Batch) -> None:
-        """trans[field]: [B, ...] — B transitions appended in env order (replay_buffer.py:25-29)."""
+        """trans[field]: [B, ...] — B transitions appended in env order (replay_buffer.py:25-29).  On the GPU the copy may run on a side
+        stream (_copy_in_one_launch): the field tensors may be dropped right away (their memory is kept until the copy has read it), but
+        must not be modified IN PLACE afterwards — the rollout hands over fresh tensors every step."""
         if not self._store:
             self._allocate(trans)
         if trans.keys() != {k for k in self._store if not k.endswith("_cached")}:

@@ -112,3 +112,32 @@ def test_training_episode_with_and_without_the_fused_glue(alg, monkeypatch):
         assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
     for k in sb:
         assert abs(sa[k] - sb[k]) <= 1e-11 * max(1.0, abs(sb[k])), k
+
+
+@pytest.mark.gpu
+def test_reading_the_ring_right_after_an_asynchronous_insertion_sees_it(monkeypatch):
+    """the insertion runs on a side stream: every read path (`store`, get_batch, get_single) must wait for it, and the memory of a source
+    that the caller drops right after the call must not be handed out again before the copy has read it (record_stream) — sources are
+    freed and same-sized tensors of garbage allocated immediately.  (Contract: a source is not modified IN PLACE after add_experience.)"""
+    from mapdn_amd.replay import TransReplayBuffer
+    monkeypatch.setenv("MAPDN_FUSED_ROLLOUT", "1"); monkeypatch.setenv("MAPDN_REPLAY_ASYNC", "1")
+    dev = torch.device("cuda:0")
+    B = 256
+    rb = TransReplayBuffer(8 * B, device=dev, window=3 * B)
+    big = torch.empty(64 << 20, device=dev)                       # some work for the main stream between the calls
+    for t in range(40):
+        x = torch.full((B, 6, 64), float(t), device=dev)
+        y = torch.full((B, 1), float(-t), device=dev)
+        rb.add_experience(dict(state=x, done=y))
+        del x, y                                                  # dropped at once: the allocator would reuse their blocks ...
+        junk = [torch.full((B, 6, 64), 1e9, device=dev), torch.full((B, 1), 1e9, device=dev)]      # ... for these, on the main stream
+        big.add_(1.0)
+        k = t % 3
+        if k == 0:
+            last = rb.get_batch(B, start=len(rb) - B)
+        elif k == 1:
+            last = {f: v[((rb._tail + len(rb) - B) % rb.size):][:B] for f, v in rb.store.items()}
+        else:
+            last = {f: v.unsqueeze(0) for f, v in rb.get_single(-1).items()}
+        assert float(last["state"].min()) == float(last["state"].max()) == float(t), t
+        assert float(last["done"].max()) == float(-t)
